@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: all-pairs Hamming search() over random VideoHashes (BASELINE.json configs[1]:
+1 M hashes, default tolerance 0.35 -> 350, one MI355X), plus the DCT-hash throughput on 64x64 frame stacks
+(configs[2]) reported in the same JSON line under "hash".
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full pass of the search hot path over the database resident in HBM: (N > 1: RCCL all-gather of the
+per-rank shards,) duration windows + tile list, the tiled XOR+popcount kernel, hit download, host replay of the
+greedy grouping.  value = hash pairs admitted by the reference's duration windows / wall time, whole job.
+Scaling is weak: the database grows as sqrt(N) so the pairs PER GPU stay fixed (~5e11).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-ops/s
+BYTES_PER_PAIR = 128  # one 128-B candidate streamed per comparison
+LANEOPS_PER_PAIR = 64  # 32 dwords x (v_xor_b32 + v_bcnt_u32_b32)
+BYTES_PER_FRAME = 4104  # 4096 B read + 8 B written per 64x64 frame
+
+
+def make_hashes(n, seed, planted_every=1000):
+    """random_hash-style database (bits 1000..1023 zero, durations 0) with planted near-duplicates: every
+    `planted_every`-th hash gets 1-4 copies with 0..379 flipped bits (some land on/over the 350 threshold)."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, 2**64, size=(n, 16), dtype=np.uint64)
+    words[:, 15] &= np.uint64((1 << 40) - 1)
+    src = np.arange(0, n - 8, planted_every)
+    for s in src:
+        for c in range(int(rng.integers(1, 5))):
+            t = s + 1 + c
+            k = int(rng.integers(0, 380))
+            bits = np.unpackbits(words[s].view(np.uint8), bitorder="little")
+            bits[rng.choice(1024, size=k, replace=False)] ^= 1
+            words[t] = np.packbits(bits, bitorder="little").view(np.uint64)
+    return words
+
+
+def cpu_baseline(words, tol_int, target_seconds=12.0):
+    """The oracle (C port of Search::search_self, single thread like the reference) on a prefix of the same
+    database.  Sized to ~10-20 s from a short calibration run."""
+    from oracle import vdf_oracle as orc
+
+    cal = 6000
+    d = np.zeros(cal, np.uint32)
+    t0 = time.perf_counter()
+    orc.search_self_sorted(words[:cal], d, tol_int)
+    dt = time.perf_counter() - t0
+    rate = cal * (cal - 1) / 2 / dt
+    n = int(min(len(words), max(cal, (2 * rate * target_seconds) ** 0.5)))
+    d = np.zeros(n, np.uint32)
+    t0 = time.perf_counter()
+    orc.search_self_sorted(words[:n], d, tol_int)
+    dt = time.perf_counter() - t0
+    pairs = n * (n - 1) / 2
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
+
+
+def cpu_baseline_hash(n_clips=1500):
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import vdf_oracle as orc
+
+    rng = np.random.default_rng(20250617)
+    frames = rng.integers(0, 256, size=(n_clips, 16, 64, 64), dtype=np.uint8)
+    cores = os.cpu_count() or 1
+    chunks = np.array_split(np.arange(n_clips), cores * 4)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: the analogue of the app's rayon par_bridge
+        list(ex.map(lambda idx: orc.hash_clips(frames[idx]) if len(idx) else None, chunks))
+    dt = time.perf_counter() - t0
+    return {"value": n_clips * 16 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle from_frames over a {cores}-thread pool, {n_clips} clips of 16x64x64"}
+
+
+def read_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(name)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-hashes", type=int, default=1_000_000, help="database size at 1 GPU (grows as sqrt(gpus))")
+    ap.add_argument("--hash-clips", type=int, default=100_000, help="clips for the DCT-hash leg (0 = skip)")
+    ap.add_argument("--tolerance", type=float, default=0.35)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import distributed as vd
+    from vid_dup_finder_lib_amd import engine as ve
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local_rank)
+    eng = vdf.Engine(local_rank)
+    tol_int = ve.tolerance_int(args.tolerance)
+
+    # ---- database: n grows as sqrt(world) so that pairs per GPU stay fixed (weak scaling) ----------------
+    n_total = int(round(args.n_hashes * world ** 0.5))
+    words = make_hashes(n_total, 20250613)
+    lo, hi = vd.split_range(n_total, rank, world)
+    shard_w = torch.from_numpy(words[lo:hi].view(np.int64)).to(dev)
+    shard_d = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
+    pairs = n_total * (n_total - 1) // 2  # all durations equal: one window, the full triangle
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = []
+    n_groups = None
+
+    def step():
+        nonlocal n_groups
+        full_w, full_d = vd.all_gather_database(shard_w, shard_d)
+        groups = vd.search_self_sharded(eng, full_w, full_d, tol_int, stream=stream)
+        st = eng.last_stats()
+        kernel_ms.append((st["kernel_ms"], st["n_launches"], st["pairs"], st["pairs_computed"], st["n_hits"]))
+        if rank == 0:
+            n_groups = len(groups)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # ---- dominant kernel: hamming_tile_kernel, HIP-event time on its own stream --------------------------
+    k_ms = float(np.mean([k[0] / max(k[1], 1) for k in kernel_ms]))
+    k_pairs = float(np.mean([k[2] for k in kernel_ms]))  # pairs admitted on THIS rank per launch
+    k_comp = float(np.mean([k[3] for k in kernel_ms]))
+    achieved_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "hamming_tile_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": read_traffic("hamming_tile_kernel"),
+                "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
+                "note": "operand-stream model of the reference loop (128 B per pair, SURVEY 8d); tiles keep targets in "
+                        "VGPRs and candidates in SGPRs so real HBM traffic is ~0.25 B/pair and the true ceiling is VALU"}
+    valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
+    valu["frac"] = valu["achieved"] / valu["peak"]
+
+    out = {
+        "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
+        "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32 (xor + popcount over 32 dwords per hash)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, all durations 0, all-pairs "
+                               "search_self at tolerance 350, planted near-duplicates every 1000th hash",
+                   "n_hashes": n_total, "hashes_per_gpu_shard": hi - lo, "pairs": pairs, "tolerance_int": tol_int,
+                   "parallelism": f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1
+                   else "single GPU"},
+        "roofline": roofline, "valu": valu, "match_groups": n_groups,
+    }
+
+    # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM ------------------------------------------
+    if args.hash_clips > 0 and rank == 0:
+        nc = args.hash_clips
+        g = torch.Generator(device=dev)
+        g.manual_seed(20250617)
+        frames = torch.randint(0, 256, (nc, 16, 64, 64), dtype=torch.uint8, device=dev, generator=g)
+        out_h = torch.zeros((nc, 16), dtype=torch.int64, device=dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(max(args.warmup, 1)):
+            eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(args.steps):
+            eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / args.steps
+        fps = nc * 16 / (ms * 1e-3)
+        h_gbs = fps * BYTES_PER_FRAME / 1e9
+        out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": fps,
+                       "unit": "frames/s", "clips": nc, "ms_per_step": ms, "dtype": "u8 -> i32 fixed point -> f64",
+                       "roofline": {"bound": "hbm", "kernel": "resize + dct_hash", "achieved": h_gbs,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS,
+                                    "traffic": read_traffic("dct_hash")}}
+        del frames, out_h
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(words, tol_int)
+        if args.hash_clips > 0:
+            out["hash"]["cpu_baseline"] = cpu_baseline_hash()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

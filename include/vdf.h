@@ -1,0 +1,181 @@
+/*
+ * vdf.h -- C ABI of the MI355X-native VideoHash construction + Hamming search engine.
+ *
+ * This is the drop-in boundary for the hot path of Farmadupe/vid_dup_finder_lib.  The
+ * reference has no FFI layer of its own (it is one Rust crate); the entry points below are
+ * what a `vdf-sys` binding would declare to replace the loops named next to each function.
+ * The Rust-side stub is shown in INTEGRATION.md.  Citations are relative to the reference
+ * repository root.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  No Rust, C++ or torch type crosses this boundary.
+ *   - Return value: VDF_OK (0) or a negative vdf_status.  A human-readable message for the
+ *     last failure on a context is available from vdf_last_error().
+ *   - A hash is 16 x uint64_t = 1024 bits: bit i of the hash is bit (i & 63) of word (i >> 6)
+ *     (bitvec Lsb0 over [usize;16], vid_dup_finder_lib/src/video_hashing/video_hash.rs:29,64-68).
+ *   - "sorted order" means the order Search::sort leaves the entries in
+ *     (src/video_hashing/search_algorithm.rs:55-61: stable by (duration, src_path)).  Sorting
+ *     needs paths and stays on the caller's side; every index this library returns is an index
+ *     into the arrays the caller passed.
+ *   - Functions with the suffix _device take DEVICE pointers (HIP allocations on the
+ *     context's GPU) and a hipStream_t passed as void*; everything else takes host pointers.
+ *   - A context is bound to one GPU.  Multi-GPU runs use one process (and one context) per
+ *     GPU; see DESIGN.md "Multi-GPU".
+ *   - Thread safety: a context serialises its own calls with an internal mutex, so
+ *     vdf_hash_frames_u8 may be called from many threads (the app hashes from rayon workers,
+ *     vid_dup_finder_app/src/video_hash_filesystem_cache/video_hash_filesystem_cache.rs:246).
+ */
+#ifndef VDF_H
+#define VDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDF_DCT_SIZE 16    /* src/definitions.rs:34 */
+#define VDF_HASH_SIZE 10   /* src/definitions.rs:36 */
+#define VDF_HASH_BITS 1000 /* src/definitions.rs:42 */
+#define VDF_HASH_WORDS 16  /* src/definitions.rs:43 */
+#define VDF_DEFAULT_SEARCH_TOLERANCE 0.35 /* src/definitions.rs:5 */
+
+typedef enum vdf_status {
+    VDF_OK = 0,
+    VDF_E_NOT_ENOUGH_FRAMES = -1, /* Error::NotEnoughFrames, src/video_hashing/mod.rs:27 */
+    VDF_E_BAD_DIMS = -2,          /* the size asserts of dct_3d.rs:31-38 / Error::VidProc */
+    VDF_E_HIP = -3,               /* HIP runtime failure or no usable GPU */
+    VDF_E_OOM = -4,
+    VDF_E_INVAL = -5,
+    VDF_E_OVERFLOW = -6           /* a caller-provided hit buffer was too small */
+} vdf_status;
+
+typedef struct vdf_ctx vdf_ctx;
+
+/* One thresholded pair.  Self-search: row = target index i, col = candidate index j > i.
+ * Reference search: row = reference index (caller's order), col = candidate index. */
+typedef struct vdf_hit {
+    uint32_t row;
+    uint32_t col;
+} vdf_hit;
+
+/* CSR result, the C form of Vec<MatchGroup> (src/video_hashing/matches/match_group.rs:10-13).
+ * members[offsets[g] .. offsets[g+1]) are the duplicates of group g, already in the
+ * reference's order.  ref_index[g] is the reference's position for search_with_references
+ * and -1 for search().  Payload is library-allocated; release with vdf_groups_free(). */
+typedef struct vdf_groups {
+    uint64_t n_groups;
+    uint64_t *offsets;  /* n_groups + 1 */
+    uint64_t *members;  /* offsets[n_groups] */
+    int64_t *ref_index; /* n_groups */
+} vdf_groups;
+
+/* Statistics of the last search on a context (for benchmarks and profiles). */
+typedef struct vdf_search_stats {
+    uint64_t pairs;         /* comparisons the reference's duration windows admit */
+    uint64_t pairs_computed;/* pairs the tiles actually evaluated (>= pairs) */
+    uint64_t n_hits;        /* thresholded pairs produced by the device */
+    uint64_t n_tiles;       /* workgroups launched for the distance kernel */
+    uint32_t n_launches;    /* distance-kernel launches (1 unless the hit buffer overflowed) */
+    float kernel_ms;        /* HIP-event time of the distance kernel(s), on their stream */
+} vdf_search_stats;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int vdf_ctx_create(int device_id, vdf_ctx **out);
+void vdf_ctx_destroy(vdf_ctx *ctx);
+const char *vdf_last_error(const vdf_ctx *ctx); /* ctx may be NULL: last ctx_create failure */
+const char *vdf_version(void);
+int vdf_ctx_device(const vdf_ctx *ctx);
+/* Hit-buffer capacity (entries) used by the host-level search calls; default 1<<24. */
+int vdf_ctx_set_hit_capacity(vdf_ctx *ctx, uint64_t capacity);
+int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out);
+
+/* ---- host helpers (no GPU needed) ------------------------------------------------------------ */
+/* VideoHash::hamming_distance, video_hash.rs:190-192,311-317: all 16 words, padding included. */
+uint32_t vdf_hamming_u1024(const uint64_t *a, const uint64_t *b);
+/* `(tolerance * TOLERANCE_SCALING_FACTOR) as u32`, search_algorithm.rs:64,82. */
+uint32_t vdf_tolerance_int(double tolerance);
+/* Sum over targets of the candidates inside the one-sided x1.1 window (search_algorithm.rs:99). */
+uint64_t vdf_count_pairs_self(const uint32_t *sorted_durations, size_t n);
+/* Sum over references of the +-5% window sizes (search_algorithm.rs:173-185). */
+uint64_t vdf_count_pairs_refs(const uint32_t *sorted_cand_durations, size_t n_cand, const uint32_t *ref_durations,
+                              size_t n_ref);
+void vdf_groups_free(vdf_groups *g);
+
+/* ---- hash construction: replaces VideoHash::from_frames, video_hash.rs:45-73 ----------------
+ * (crop_resize_buf per frame, vid_dup_finder_common/src/resize_gray.rs:11-54; Dct3d::from_images
+ * + dct_3d, dct_3d.rs:15-53 and raw_dct_ops.rs:107-142; hash_bits, dct_3d.rs:55-66; Lsb0 pack).
+ * frames: n_clips clips of frames_per_clip gray u8 frames of w x h (row-major, tightly packed rows);
+ * frame f of clip c starts at frames + c*clip_stride + f*frame_stride (bytes).  Only the first 16
+ * frames of a clip are read.  frames_per_clip < 16 (or 0) -> VDF_E_NOT_ENOUGH_FRAMES.
+ * out_hashes: n_clips x 16 words.  out_dontcare (nullable): per clip, the number of the 1000
+ * coefficients with |coef| < 1e-6 (their sign is rounding noise; DESIGN.md "Parity rule"). */
+int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                       uint32_t *out_dontcare);
+int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                              uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,
+                              uint32_t *d_out_dontcare, void *stream);
+
+/* ---- search(): replaces Search::search_self, search_algorithm.rs:81-171 (hot loop :150-156) --
+ * hashes: n x 16 words, durations: n, both in sorted order.  tol_int from vdf_tolerance_int().
+ * Groups come back exactly as search() builds them (video_dup_finder.rs:7-13): members = hits in
+ * sorted order then the target; groups in descending target order; every group has >= 2 members. */
+int vdf_search_self(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, size_t n, uint32_t tol_int,
+                    vdf_groups *out);
+
+/* ---- search_with_references(): replaces Search::search_one + duration_slice,
+ * search_algorithm.rs:63-77,173-185, driven as video_dup_finder.rs:19-46 does (one reference at a
+ * time, consume = false).  Candidates in sorted order; references in the caller's order.
+ * Groups: one per reference with >= 1 hit, in reference input order; members ascending. */
+int vdf_search_refs(vdf_ctx *ctx, const uint64_t *cand_hashes, const uint32_t *cand_durations, size_t n_cand,
+                    const uint64_t *ref_hashes, const uint32_t *ref_durations, size_t n_ref, uint32_t tol_int,
+                    vdf_groups *out);
+
+/* ---- device-resident pieces (what the host-level calls above are built from) -----------------
+ * These let a caller keep the hash database in HBM, shard the work over several processes
+ * (one GPU each) and merge on the host.  All produce the thresholded adjacency; the greedy,
+ * order-dependent part of search_self is replayed on the host by vdf_replay_self().
+ *
+ * vdf_search_self_device: emits every pair (i, j), i < j < rhs(i), hamming <= tol_int, where
+ *   rhs(i) = first index with duration > (f64(duration[i]) * 1.1) as u32   (search_algorithm.rs:99).
+ *   Row tiles (vdf_row_tile_size() consecutive targets) are dealt round-robin: this call handles
+ *   tiles t with t % shard_count == shard_index.  Only rows in [row_begin, row_end) are searched.
+ *   d_matched (nullable): bitmap, 1 bit per entry, bit set = entry already consumed; such
+ *   entries are skipped both as targets and as candidates (exactly the `matched` flag).
+ *   hits (HOST buffer, capacity entries) receives the pairs sorted by (row, col); *n_hits is the
+ *   number produced by the device (may exceed capacity); *overflow_row is the smallest row that
+ *   lost a hit, or UINT32_MAX.  Rows below *overflow_row are complete.
+ *   Returns VDF_OK also when the buffer overflowed: check *overflow_row. */
+int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
+                           uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
+                           uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
+                           uint64_t *n_hits, uint32_t *overflow_row, void *stream);
+
+/* vdf_search_refs_device: emits every pair (r, j) with j inside reference r's +-5% window
+ * (search_algorithm.rs:173-185) and hamming <= tol_int; row = r + ref_index_base, hits (HOST
+ * buffer) sorted by (row, col).  Every hit is part of the output here (consume = false), so an
+ * undersized buffer is simply an error: VDF_E_OVERFLOW with *n_hits = the size required. */
+int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
+                           size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
+                           size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
+                           uint64_t capacity, uint64_t *n_hits, void *stream);
+
+uint32_t vdf_row_tile_size(void);
+
+/* Host replay of search_self's consumption order (search_algorithm.rs:131-170) over hits sorted
+ * by (row, col).  matched (nullable, n bytes, in/out) carries consumption state between partial
+ * replays; rows in [row_begin, row_end) are replayed.  Appends groups in ASCENDING target order
+ * to *out (which must be zero-initialised before the first call); call vdf_groups_finish_self()
+ * once at the end to apply ret.reverse() (search_algorithm.rs:167). */
+int vdf_replay_self(size_t n, const vdf_hit *hits, uint64_t n_hits, uint32_t row_begin, uint32_t row_end,
+                    uint8_t *matched, vdf_groups *out);
+int vdf_groups_finish_self(vdf_groups *g);
+/* Groups for search_with_references from hits sorted by (row, col). */
+int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDF_H */

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """The HIP engine.  No fallback: on a box without a GPU (or without libvdf_hip.so) this raises."""
+    import vid_dup_finder_lib_amd as vdf
+
+    eng = vdf.Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,176 @@
+"""HIP search path (through the C ABI) vs the CPU oracle: bit-exact MatchGroup index lists."""
+import numpy as np
+import pytest
+
+import hashgen as hg
+from oracle import vdf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+SCALE = 1000.0
+
+
+def _both_self(engine, words, dur, tol_int):
+    got = engine.search_self_sorted(words, dur, tol_int)
+    want = orc.search_self_sorted(words, dur, tol_int)
+    assert got == want
+    return got
+
+
+def _both_refs(engine, cw, cd, rw, rd, tol_int):
+    got = engine.search_refs_sorted(cw, cd, rw, rd, tol_int)
+    want = orc.search_refs_sorted(cw, cd, rw, rd, tol_int)
+    assert got == want
+    return got
+
+
+def test_reference_scenario_known_group(engine):
+    rng = np.random.default_rng(1)
+    members = np.stack(hg.HashesWithDistanceSet(1, 50, 201, 100, rng).all_members(rng))
+    groups = _both_self(engine, members, np.zeros(len(members), np.uint32), 200)
+    assert [len(g) for g in groups] == [50]
+
+
+def test_reference_scenario_duration(engine):
+    rng = np.random.default_rng(2)
+    short = hg.HashesWithDistanceSet(1, 100, 201, 100, rng).groups[0].members(rng)
+    words = np.stack(list(short) + list(short[:50]))
+    dur = np.array([50] * 100 + [250] * 50, np.uint32)
+    perm = rng.permutation(150)
+    w, d, _ = hg.sort_by_duration(words[perm], dur[perm])
+    groups = _both_self(engine, w, d, 200)
+    assert sorted(len(g) for g in groups) == [50, 100]
+
+
+def test_reference_scenario_distance(engine):
+    rng = np.random.default_rng(3)
+    allh = np.stack(hg.HashesWithDistanceSet(2, 100, 150, 50, rng).all_members(rng))
+    groups = _both_self(engine, allh, np.zeros(len(allh), np.uint32), 100)
+    assert sorted(len(g) for g in groups) == [100, 110]
+
+
+def test_reference_scenario_refs(engine):
+    rng = np.random.default_rng(4)
+    gs = hg.HashesWithDistanceSet(5, 100, 150, 50, rng)
+    cands = np.stack(gs.all_members(rng))
+    zeros = np.zeros(len(cands), np.uint32)
+    r1 = _both_refs(engine, cands, zeros, gs.groups[3].start_hash[None], np.zeros(1, np.uint32), 50)
+    assert [(r, len(m)) for r, m in r1] == [(0, 130)]
+    starts = np.stack([gs.groups[0].start_hash, gs.groups[4].start_hash])
+    r2 = _both_refs(engine, cands, zeros, starts, np.zeros(2, np.uint32), 50)
+    assert [(r, len(m)) for r, m in r2] == [(0, 100), (1, 140)]
+
+
+def test_empty_and_tiny(engine):
+    assert engine.search_self_sorted(np.zeros((0, 16), np.uint64), np.zeros(0, np.uint32), 1000) == []
+    one = hg.random_hashes(np.random.default_rng(0), 1)
+    assert engine.search_self_sorted(one, np.zeros(1, np.uint32), 1024) == []
+    two = np.concatenate([one, one])
+    assert _both_self(engine, two, np.zeros(2, np.uint32), 0) == [[1, 0]]
+    assert engine.search_refs_sorted(one, np.zeros(1, np.uint32), np.zeros((0, 16), np.uint64), np.zeros(0, np.uint32), 5) == []
+
+
+@pytest.mark.parametrize("n,seed", [(700, 10), (3000, 11), (20000, 12)])
+@pytest.mark.parametrize("durations", ["zero", "windowed"])
+def test_planted_sets_match_oracle(engine, n, seed, durations):
+    rng = np.random.default_rng(seed)
+    words, dur = hg.planted_set(rng, n, n_clusters=max(4, n // 50), durations=durations)
+    w, d, _ = hg.sort_by_duration(words, dur)
+    for tol in (350, 0, 120):
+        groups = _both_self(engine, w, d, tol)
+        if tol == 350:
+            assert len(groups) > 0
+    stats = engine.last_stats()
+    assert stats["pairs"] == orc.pairs_self(d)
+
+
+def test_padding_bits_count(engine):
+    """hash_with_spatial_distance may set bits 1000..1023; the kernel must not mask them (video_hash.rs:311-317)."""
+    base = np.zeros((1, 16), np.uint64)
+    other = base.copy()
+    other[0, 15] = np.uint64(0xFFFFFF) << np.uint64(40)  # 24 padding bits
+    w = np.concatenate([base, other])
+    d = np.zeros(2, np.uint32)
+    assert _both_self(engine, w, d, 23) == []
+    assert _both_self(engine, w, d, 24) == [[1, 0]]
+
+
+def test_all_identical_and_hit_buffer_overflow(engine):
+    """Adversarial: every pair is a hit.  Forces the hit-buffer overflow protocol (rows replayed in chunks with
+    the consumption bitmap fed back); the result must still be the single group the reference builds."""
+    n = 3000
+    one = hg.random_hashes(np.random.default_rng(5), 1)
+    w = np.repeat(one, n, axis=0)
+    d = np.zeros(n, np.uint32)
+    engine.set_hit_capacity(5000)
+    try:
+        groups = _both_self(engine, w, d, 0)
+        assert len(groups) == 1 and len(groups[0]) == n
+        assert engine.last_stats()["n_launches"] > 1
+        # clustered + overflow
+        rng = np.random.default_rng(6)
+        words, dur = hg.planted_set(rng, 4000, n_clusters=40, max_copies=60, max_flips=100)
+        w2, d2, _ = hg.sort_by_duration(words, dur)
+        engine.set_hit_capacity(700)
+        _both_self(engine, w2, d2, 350)
+    finally:
+        engine.set_hit_capacity(1 << 24)
+
+
+def test_duration_window_edges(engine):
+    """One-sided x1.1 window with truncation: (f64(d) * 1.1) as u32 (search_algorithm.rs:99)."""
+    one = hg.random_hashes(np.random.default_rng(7), 1)
+    durs = np.array([10, 11, 12, 100, 109, 110, 111, 1000, 1100, 1101, 4000000000, 4294967295], np.uint32)
+    w = np.repeat(one, len(durs), axis=0)
+    _both_self(engine, w, durs, 0)
+    # +-5% windows for references: (d*0.95) as u32 .. (d*1.05) as u32, both truncating
+    cd = np.arange(0, 400, dtype=np.uint32)
+    cw = np.repeat(one, len(cd), axis=0)
+    rd = np.array([0, 1, 19, 20, 21, 100, 199, 200, 399, 1000], np.uint32)
+    rw = np.repeat(one, len(rd), axis=0)
+    _both_refs(engine, cw, cd, rw, rd, 0)
+
+
+@pytest.mark.parametrize("n_cand,n_ref,seed", [(2500, 300, 20), (12000, 900, 21)])
+def test_refs_planted_match_oracle(engine, n_cand, n_ref, seed):
+    rng = np.random.default_rng(seed)
+    words, dur = hg.planted_set(rng, n_cand, n_clusters=n_cand // 40, durations="windowed")
+    cw, cd, _ = hg.sort_by_duration(words, dur)
+    # references: half near-copies of candidates (matching durations), half fresh
+    pick = rng.choice(n_cand, size=n_ref // 2, replace=False)
+    rw = cw[pick].copy()
+    rd = cd[pick].copy()
+    for i in range(len(rw)):
+        flips = rng.choice(1024, size=int(rng.integers(0, 340)), replace=False)
+        bits = np.unpackbits(rw[i].view(np.uint8), bitorder="little")
+        bits[flips] ^= 1
+        rw[i] = np.packbits(bits, bitorder="little").view(np.uint64)
+    fresh = hg.random_hashes(rng, n_ref - len(rw))
+    fd = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=len(fresh)))).astype(np.uint32)
+    rw = np.concatenate([rw, fresh])
+    rd = np.concatenate([rd, fd])
+    perm = rng.permutation(len(rw))
+    res = _both_refs(engine, cw, cd, rw[perm], rd[perm], 350)
+    assert len(res) > 0
+    engine.set_hit_capacity(16)  # every hit is output: the buffer is resized exactly once
+    try:
+        _both_refs(engine, cw, cd, rw[perm], rd[perm], 350)
+    finally:
+        engine.set_hit_capacity(1 << 24)
+
+
+def test_public_api_matches_oracle(engine):
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(30)
+    words, dur = hg.planted_set(rng, 1200, n_clusters=30, durations="windowed")
+    paths = [f"dir{int(rng.integers(0, 5))}/v{i}.mp4" if i % 3 else f"dir.{i}/v.mp4" for i in range(len(words))]
+    hashes = [vdf.VideoHash(words[i], paths[i], int(dur[i])) for i in range(len(words))]
+    got = vdf.search(hashes, 0.35, engine=engine)
+    want = orc.search(words, dur, paths, 0.35)
+    assert [list(g.duplicates()) for g in got] == want
+    assert all(g.reference() is None and g.len() >= 2 for g in got)
+    refs = hashes[:40]
+    got_r = vdf.search_with_references(refs, hashes[20:], 0.2, engine=engine)
+    want_r = orc.search_with_references(words[:40], dur[:40], paths[:40], words[20:], dur[20:], paths[20:], 0.2)
+    assert [(g.reference(), list(g.duplicates())) for g in got_r] == want_r
+    assert vdf.search([], 1.0, engine=engine) == []

@@ -1,0 +1,117 @@
+"""ctypes binding of include/vdf.h (libvdf_hip.so).
+
+This is the Python twin of the `vdf-sys` binding shown in INTEGRATION.md: every symbol
+declared in include/vdf.h is bound here with its exact C signature.  There is no fallback:
+if the shared library is missing the import of the compute API fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdf_hip.so")
+
+VDF_OK = 0
+VDF_E_NOT_ENOUGH_FRAMES = -1
+VDF_E_BAD_DIMS = -2
+VDF_E_HIP = -3
+VDF_E_OOM = -4
+VDF_E_INVAL = -5
+VDF_E_OVERFLOW = -6
+
+DCT_SIZE = 16
+HASH_SIZE = 10
+HASH_BITS = 1000
+HASH_WORDS = 16
+DEFAULT_SEARCH_TOLERANCE = 0.35  # vid_dup_finder_lib/src/definitions.rs:5
+TOLERANCE_SCALING_FACTOR = 1000.0  # definitions.rs:40
+
+
+class VdfHit(C.Structure):
+    _fields_ = [("row", C.c_uint32), ("col", C.c_uint32)]
+
+
+class VdfGroups(C.Structure):
+    _fields_ = [
+        ("n_groups", C.c_uint64),
+        ("offsets", C.POINTER(C.c_uint64)),
+        ("members", C.POINTER(C.c_uint64)),
+        ("ref_index", C.POINTER(C.c_int64)),
+    ]
+
+
+class VdfSearchStats(C.Structure):
+    _fields_ = [
+        ("pairs", C.c_uint64),
+        ("pairs_computed", C.c_uint64),
+        ("n_hits", C.c_uint64),
+        ("n_tiles", C.c_uint64),
+        ("n_launches", C.c_uint32),
+        ("kernel_ms", C.c_float),
+    ]
+
+
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes).  Keep in step with include/vdf.h; tests/test_capi_symbols.py checks both ways.
+SIGNATURES = {
+    "vdf_ctx_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "vdf_ctx_destroy": (None, [_ctx]),
+    "vdf_last_error": (C.c_char_p, [_ctx]),
+    "vdf_version": (C.c_char_p, []),
+    "vdf_ctx_device": (C.c_int, [_ctx]),
+    "vdf_ctx_set_hit_capacity": (C.c_int, [_ctx, C.c_uint64]),
+    "vdf_ctx_last_search_stats": (C.c_int, [_ctx, C.POINTER(VdfSearchStats)]),
+    "vdf_hamming_u1024": (C.c_uint32, [_u64p, _u64p]),
+    "vdf_tolerance_int": (C.c_uint32, [C.c_double]),
+    "vdf_count_pairs_self": (C.c_uint64, [_u32p, C.c_size_t]),
+    "vdf_count_pairs_refs": (C.c_uint64, [_u32p, C.c_size_t, _u32p, C.c_size_t]),
+    "vdf_groups_free": (None, [C.POINTER(VdfGroups)]),
+    "vdf_hash_frames_u8": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t,
+                                     C.c_size_t, C.c_void_p, C.c_void_p]),
+    "vdf_hash_frames_u8_device": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdf_search_self": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(VdfGroups)]),
+    "vdf_search_refs": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_uint32, C.POINTER(VdfGroups)]),
+    "vdf_search_self_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]),
+    "vdf_search_refs_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.c_void_p]),
+    "vdf_row_tile_size": (C.c_uint32, []),
+    "vdf_replay_self": (C.c_int, [C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                  C.POINTER(VdfGroups)]),
+    "vdf_groups_finish_self": (C.c_int, [C.POINTER(VdfGroups)]),
+    "vdf_groups_from_ref_hits": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(VdfGroups)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libvdf_hip.so and bind every entry point; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C vid_dup_finder_lib_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class VdfError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"vdf error {code}: {message}")
+        self.code = code

@@ -1,0 +1,279 @@
+"""Python mirror of the reference crate's public surface for the hot path
+(vid_dup_finder_lib/src/lib.rs:132-140): VideoHash, MatchGroup, Error, search,
+search_with_references.  Same names, argument meaning and error behaviour; the compute goes
+through the C ABI to the GPU.  The Rust-side shim a maintainer would add is in INTEGRATION.md.
+
+Out of scope here (callers of the path, decode-bound): VideoHashBuilder / CreationOptions
+(video_hash_builder.rs) -- their output contract (16 equal-size gray frames + duration in
+seconds) is exactly the input of VideoHash.from_frames below.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+from typing import Iterable, Iterator, List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from ._capi import DEFAULT_SEARCH_TOLERANCE, HASH_BITS, HASH_WORDS, TOLERANCE_SCALING_FACTOR, VdfError
+from .engine import Engine, hamming_distance_words, tolerance_int
+
+__all__ = ["VideoHash", "MatchGroup", "Error", "NotEnoughFrames", "NotVideo", "VidProc", "TooFewEntries", "search",
+           "search_with_references", "default_engine", "hash_frame_stacks", "rust_path_key", "sort_order",
+           "DEFAULT_SEARCH_TOLERANCE", "TOLERANCE_SCALING_FACTOR"]
+
+
+# ---- Error (vid_dup_finder_lib/src/video_hashing/mod.rs:17-28) --------------------------------------
+class Error(Exception):
+    """An error that prevented a video hash from being created."""
+
+
+class NotVideo(Error):
+    def __init__(self):
+        super().__init__("File is not a video")
+
+
+class VidProc(Error):
+    def __init__(self, msg: str):
+        super().__init__(f"Video processing error: {msg}")
+
+
+class NotEnoughFrames(Error):
+    def __init__(self):
+        super().__init__("Could not extract enough frames")
+
+
+class TooFewEntries(Exception):
+    """match_group.rs:15-16"""
+
+
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    """Process-wide engine on GPU LOCAL_RANK (or 0).  Fails loudly without a GPU or the built library."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+# ---- Rust `PathBuf: Ord` --------------------------------------------------------------------------
+def rust_path_key(path) -> tuple:
+    """Key reproducing std::path::Path's component-wise ordering on Unix (Search::sort uses
+    (duration, src_path.to_owned()) as its key, search_algorithm.rs:55-61).  Components:
+    RootDir < CurDir < ParentDir < Normal(bytes); repeated '/' and inner '.' are not components."""
+    b = path if isinstance(path, bytes) else os.fsencode(path)
+    comps = []
+    if b.startswith(b"/"):
+        comps.append((1, b""))
+    elif b == b"." or b.startswith(b"./"):
+        comps.append((2, b""))
+    for part in b.split(b"/"):
+        if part in (b"", b"."):
+            continue
+        comps.append((3, b"") if part == b".." else (4, part))
+    return tuple(comps)
+
+
+def sort_order(hashes: Sequence["VideoHash"]) -> List[int]:
+    """Stable permutation that Search::sort applies (search_algorithm.rs:55-61)."""
+    idx = list(range(len(hashes)))
+    idx.sort(key=lambda i: (hashes[i].duration(), rust_path_key(hashes[i].src_path())))
+    return idx
+
+
+# ---- VideoHash (video_hash.rs:26-32) ----------------------------------------------------------------
+class VideoHash:
+    """hash: 16 x u64 (1024 bits, Lsb0; bits 1000..1023 are zero when built from frames),
+    src_path, duration in seconds."""
+
+    __slots__ = ("hash", "_src_path", "_duration")
+
+    def __init__(self, hash_words=None, src_path="", duration: int = 0):
+        if hash_words is None:
+            hash_words = np.zeros(HASH_WORDS, np.uint64)  # Default, video_hash.rs:34-42
+        self.hash = np.ascontiguousarray(hash_words, dtype=np.uint64).reshape(HASH_WORDS).copy()
+        self._src_path = src_path
+        self._duration = int(duration)
+
+    @classmethod
+    def from_frames(cls, frames: Iterable[np.ndarray], src_path, duration: int,
+                    engine: Optional[Engine] = None) -> "VideoHash":
+        """video_hash.rs:45-73.  frames: iterable of equal-size 2-D u8 arrays (gray, row-major).
+        Empty or fewer than 16 -> NotEnoughFrames; only the first 16 are used (dct_3d.rs:25)."""
+        taken = list(itertools.islice(iter(frames), _capi.DCT_SIZE))
+        if len(taken) < _capi.DCT_SIZE:
+            raise NotEnoughFrames()
+        first = np.asarray(taken[0])
+        for f in taken:
+            if np.asarray(f).shape != first.shape or np.asarray(f).ndim != 2:
+                raise VidProc("frames must be equal-size 2-D gray images")
+        stack = np.stack([np.ascontiguousarray(f, dtype=np.uint8) for f in taken])[None]
+        try:
+            words = (engine or default_engine()).hash_frames(stack)[0]
+        except VdfError as e:
+            if e.code == _capi.VDF_E_NOT_ENOUGH_FRAMES:
+                raise NotEnoughFrames() from e
+            if e.code == _capi.VDF_E_BAD_DIMS:
+                raise VidProc(str(e)) from e
+            raise
+        return cls(words, src_path, duration)
+
+    def src_path(self):
+        return self._src_path
+
+    def duration(self) -> int:
+        return self._duration
+
+    def hamming_distance(self, other: "VideoHash") -> int:
+        """video_hash.rs:190-192: raw distance over all 16 words."""
+        return hamming_distance_words(self.hash, other.hash)
+
+    def normalized_hamming_distance(self, other: "VideoHash") -> float:
+        """video_hash.rs:200-204 (feature app_only_fns)."""
+        return float(self.hamming_distance(other)) / TOLERANCE_SCALING_FACTOR
+
+    def hash_bits(self) -> np.ndarray:
+        """The 1000 hash bits as a bool array (video_hash.rs:226-228)."""
+        bits = np.unpackbits(self.hash.view(np.uint8), bitorder="little")
+        return bits[:HASH_BITS].astype(bool)
+
+    # test_util-style constructors (video_hash.rs:240-308) that need no RNG
+    def with_duration(self, duration: int) -> "VideoHash":
+        return VideoHash(self.hash, self._src_path, duration)
+
+    def with_src_path(self, src_path) -> "VideoHash":
+        return VideoHash(self.hash, src_path, self._duration)
+
+    @classmethod
+    def full_hash(cls, name) -> "VideoHash":
+        return cls(np.full(HASH_WORDS, np.uint64(0xFFFFFFFFFFFFFFFF)), name, 0)
+
+    @classmethod
+    def empty_hash(cls, name) -> "VideoHash":
+        return cls(np.zeros(HASH_WORDS, np.uint64), name, 0)
+
+    def _key(self):
+        return (tuple(int(x) for x in self.hash), rust_path_key(self._src_path), self._duration)
+
+    def __eq__(self, other):
+        return isinstance(other, VideoHash) and self._key() == other._key()
+
+    def __lt__(self, other):  # derive(Ord): field order hash, src_path, duration
+        return self._key() < other._key()
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __repr__(self):
+        return f"VideoHash(src_path={self._src_path!r}, duration={self._duration}, hash=0x{int(self.hash[0]):016x}..)"
+
+
+# ---- MatchGroup (matches/match_group.rs) --------------------------------------------------------------
+class MatchGroup:
+    __slots__ = ("_reference", "_duplicates")
+
+    def __init__(self, reference, duplicates: List):
+        self._reference = reference
+        self._duplicates = list(duplicates)
+
+    @classmethod
+    def new(cls, entries: Iterable) -> "MatchGroup":
+        dups = list(entries)
+        if len(dups) < 2:  # match_group.rs:25
+            raise TooFewEntries()
+        return cls(None, dups)
+
+    @classmethod
+    def new_with_reference(cls, reference, entries: Iterable) -> "MatchGroup":
+        dups = list(entries)
+        if not dups:  # match_group.rs:41
+            raise TooFewEntries()
+        return cls(reference, dups)
+
+    def len(self) -> int:
+        return len(self._duplicates)
+
+    __len__ = len
+
+    def reference(self):
+        return self._reference
+
+    def duplicates(self) -> Iterator:
+        return iter(self._duplicates)
+
+    def contained_paths(self) -> Iterator:
+        """duplicates, then the reference if there is one (match_group.rs:68-81)."""
+        yield from self._duplicates
+        if self._reference is not None:
+            yield self._reference
+
+    def dup_combinations(self) -> List["MatchGroup"]:
+        """match_group.rs:87-105."""
+        if self._reference is not None:
+            return [MatchGroup.new_with_reference(self._reference, [d]) for d in self._duplicates]
+        return [MatchGroup.new([a, b]) for a, b in itertools.combinations(self._duplicates, 2)]
+
+    def __eq__(self, other):
+        return (isinstance(other, MatchGroup) and self._reference == other._reference
+                and self._duplicates == other._duplicates)
+
+    def __repr__(self):
+        return f"MatchGroup(reference={self._reference!r}, duplicates={self._duplicates!r})"
+
+
+# ---- search / search_with_references (video_dup_finder.rs) -------------------------------------------
+def _soa(hashes: Sequence[VideoHash], order: Sequence[int]):
+    if not order:
+        return np.zeros((0, HASH_WORDS), np.uint64), np.zeros(0, np.uint32)
+    words = np.stack([hashes[i].hash for i in order])
+    dur = np.array([hashes[i].duration() for i in order], dtype=np.uint32)
+    return words, dur
+
+
+def search(hashes: Iterable[VideoHash], tolerance: float, engine: Optional[Engine] = None) -> List[MatchGroup]:
+    """video_dup_finder.rs:7-13.  Sort (host, needs paths), GPU all-pairs search inside the one-sided
+    x1.1 duration window, host replay of the greedy consumption; groups come back in the reference's order."""
+    hashes = list(hashes)
+    if not hashes:
+        return []  # search_algorithm.rs:89-91
+    order = sort_order(hashes)
+    words, dur = _soa(hashes, order)
+    groups = (engine or default_engine()).search_self_sorted(words, dur, tolerance_int(tolerance))
+    out = []
+    for g in groups:
+        try:
+            out.append(MatchGroup.new(hashes[order[m]].src_path() for m in g))
+        except TooFewEntries:  # filter_map(.. .ok()), video_dup_finder.rs:11
+            pass
+    return out
+
+
+def search_with_references(ref_hashes: Iterable[VideoHash], new_hashes: Iterable[VideoHash], tolerance: float,
+                           engine: Optional[Engine] = None) -> List[MatchGroup]:
+    """video_dup_finder.rs:19-46: one group per reference with >= 1 match, in reference input order."""
+    refs = list(ref_hashes)
+    news = list(new_hashes)
+    if not refs or not news:
+        return []
+    order = sort_order(news)
+    words, dur = _soa(news, order)
+    rwords, rdur = _soa(refs, list(range(len(refs))))
+    res = (engine or default_engine()).search_refs_sorted(words, dur, rwords, rdur, tolerance_int(tolerance))
+    return [MatchGroup.new_with_reference(refs[r].src_path(), [news[order[m]].src_path() for m in ms])
+            for r, ms in res]
+
+
+def hash_frame_stacks(frames: np.ndarray, src_paths: Sequence, durations: Sequence[int],
+                      engine: Optional[Engine] = None) -> List[VideoHash]:
+    """Batched VideoHash.from_frames: frames [n_clips, n_frames >= 16, H, W] u8 -> one VideoHash per clip
+    (the batching a caller of VideoHashBuilder::hash would do to feed the GPU)."""
+    try:
+        words = (engine or default_engine()).hash_frames(frames)
+    except VdfError as e:
+        if e.code == _capi.VDF_E_NOT_ENOUGH_FRAMES:
+            raise NotEnoughFrames() from e
+        raise
+    return [VideoHash(words[i], src_paths[i], durations[i]) for i in range(len(words))]

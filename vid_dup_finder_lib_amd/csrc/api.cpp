@@ -1,0 +1,546 @@
+// C-ABI layer (include/vdf.h): context, device scratch, launch orchestration, the hit-buffer
+// overflow protocol and the host-level convenience calls.  Compiled with hipcc; the kernels live
+// in hamming.hip and dct_hash.hip.  There is deliberately NO CPU fallback for the compute path:
+// without a usable GPU every compute entry point fails with VDF_E_HIP.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "resize_tables.h"
+#include "vdf_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct DeviceAxisTable {
+    DevBuf start, size, w;
+    vdf::HostAxisTable host;
+};
+
+}  // namespace
+
+struct vdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+    std::string err;
+    uint64_t hit_capacity = 1ull << 24;
+    vdf_search_stats stats{};
+    uint32_t tile_rows = 256 * vdf::kDefaultRowsPerLane;
+    uint32_t chunk_cols = vdf::kDefaultChunkCols;
+    // search scratch
+    DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
+    DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
+    // hash scratch
+    DevBuf small, frames, out_hashes, out_dc, cos_table;
+    std::map<uint32_t, DeviceAxisTable *> axis_tables;
+    std::vector<vdf_hit> host_hits;
+
+    ~vdf_ctx()
+    {
+        for (auto &kv : axis_tables) {
+            kv.second->start.release(); kv.second->size.release(); kv.second->w.release();
+            delete kv.second;
+        }
+        DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
+                         &hits, &perm, &matched, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
+                         &out_hashes, &out_dc, &cos_table};
+        for (DevBuf *b : all) b->release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int fail(vdf_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int fail_hip(vdf_ctx *ctx, hipError_t e, const char *what)
+{
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return fail(ctx, e == hipErrorOutOfMemory ? VDF_E_OOM : VDF_E_HIP, msg);
+}
+
+#define VDF_HIP(ctx, call)                                           \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);   \
+    } while (0)
+
+bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; }
+
+// Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
+int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
+                const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
+                uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
+                const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream)
+{
+    *n_hits_out = 0;
+    *overflow_row_out = 0xFFFFFFFFu;
+    if (n_rows == 0 || n_cols == 0) return VDF_OK;
+    if (n_rows >= 0xFFFFFFFFull || n_cols >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(ctx, VDF_E_INVAL, "bad shard index/count");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+
+    vdf::SearchLaunch L{};
+    L.tile_rows = ctx->tile_rows;
+    L.chunk_cols = ctx->chunk_cols;
+    L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
+    const size_t padded_rows = (size_t)L.n_row_tiles * L.tile_rows;
+    VDF_HIP(ctx, ctx->row_lo.reserve(padded_rows * 4));
+    VDF_HIP(ctx, ctx->row_hi.reserve(padded_rows * 4));
+    VDF_HIP(ctx, ctx->tile_lo.reserve((size_t)L.n_row_tiles * 4));
+    VDF_HIP(ctx, ctx->tile_hi.reserve((size_t)L.n_row_tiles * 4));
+    VDF_HIP(ctx, ctx->tile_first.reserve((size_t)L.n_row_tiles * 4));
+    VDF_HIP(ctx, ctx->tile_count.reserve((size_t)L.n_row_tiles * 4));
+    VDF_HIP(ctx, ctx->tile_offset.reserve(((size_t)L.n_row_tiles + 1) * 4));
+    VDF_HIP(ctx, ctx->counters.reserve(64));
+    const uint64_t dev_cap = std::max<uint64_t>(capacity, 1);
+    VDF_HIP(ctx, ctx->hits.reserve(dev_cap * sizeof(vdf_hit)));
+
+    L.row_hashes = reinterpret_cast<const uint32_t *>(d_row_hashes);
+    L.row_perm = d_row_perm;
+    L.n_rows = (uint32_t)n_rows;
+    L.row_index_base = row_index_base;
+    L.col_hashes = reinterpret_cast<const uint32_t *>(d_col_hashes);
+    L.n_cols = (uint32_t)n_cols;
+    L.row_lo = ctx->row_lo.as<uint32_t>();
+    L.row_hi = ctx->row_hi.as<uint32_t>();
+    L.tile_lo = ctx->tile_lo.as<uint32_t>();
+    L.tile_hi = ctx->tile_hi.as<uint32_t>();
+    L.tile_first = ctx->tile_first.as<uint32_t>();
+    L.tile_count = ctx->tile_count.as<uint32_t>();
+    L.tile_offset = ctx->tile_offset.as<uint32_t>();
+    L.tol = tol_int;
+    L.matched = d_matched;
+    L.self_mode = (mode == 0);
+    L.hits = ctx->hits.as<vdf_hit>();
+    L.capacity = capacity;
+    L.counters = ctx->counters.as<unsigned long long>();
+    L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
+
+    // counters[0..2] = 0, overflow_row = UINT32_MAX
+    unsigned long long init[8] = {0, 0, 0, 0, 0xFFFFFFFFull, 0, 0, 0};
+    VDF_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+    VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
+                                           row_begin, row_end, shard_index, shard_count, L, stream));
+    uint32_t total_tiles = 0;
+    VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, L.tile_offset + L.n_row_tiles, 4, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
+
+    VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
+    VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
+    VDF_HIP(ctx, hipEventRecord(ctx->ev1, stream));
+    unsigned long long fin[8];
+    VDF_HIP(ctx, hipMemcpyAsync(fin, ctx->counters.p, sizeof fin, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    float ms = 0.f;
+    VDF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+
+    const uint64_t produced = fin[0];
+    const uint64_t stored = std::min<uint64_t>(produced, capacity);
+    if (stored) {
+        VDF_HIP(ctx, hipMemcpyAsync(hits, ctx->hits.p, stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
+        VDF_HIP(ctx, hipStreamSynchronize(stream));
+        std::sort(hits, hits + stored, hit_less);
+    }
+    *n_hits_out = produced;
+    *overflow_row_out = (uint32_t)fin[4];
+    ctx->stats.pairs += fin[2];
+    ctx->stats.pairs_computed += fin[1];
+    ctx->stats.n_hits += produced;
+    ctx->stats.n_tiles += total_tiles;
+    ctx->stats.n_launches += 1;
+    ctx->stats.kernel_ms += ms;
+    return VDF_OK;
+}
+
+int upload(vdf_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, hipStream_t stream)
+{
+    VDF_HIP(ctx, buf.reserve(std::max<size_t>(bytes, 16)));
+    if (bytes) VDF_HIP(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, stream));
+    return VDF_OK;
+}
+
+DeviceAxisTable *axis_table(vdf_ctx *ctx, uint32_t in_size, hipStream_t stream, int *rc)
+{
+    auto it = ctx->axis_tables.find(in_size);
+    if (it != ctx->axis_tables.end()) { *rc = VDF_OK; return it->second; }
+    DeviceAxisTable *t = new DeviceAxisTable();
+    if (!vdf::build_axis_table(in_size, VDF_DCT_SIZE, t->host)) {
+        delete t;
+        *rc = fail(ctx, VDF_E_BAD_DIMS, "cannot build resize table");
+        return nullptr;
+    }
+    int r = upload(ctx, t->start, t->host.start.data(), t->host.start.size() * 4, stream);
+    if (r == VDF_OK) r = upload(ctx, t->size, t->host.size.data(), t->host.size.size() * 4, stream);
+    if (r == VDF_OK) r = upload(ctx, t->w, t->host.w.data(), t->host.w.size() * 2, stream);
+    if (r == VDF_OK && hipStreamSynchronize(stream) != hipSuccess) r = fail(ctx, VDF_E_HIP, "table upload failed");
+    if (r != VDF_OK) {
+        t->start.release(); t->size.release(); t->w.release();
+        delete t;
+        *rc = r;
+        return nullptr;
+    }
+    ctx->axis_tables[in_size] = t;
+    *rc = VDF_OK;
+    return t;
+}
+
+vdf::ResizeAxisTable dev_view(const DeviceAxisTable *t)
+{
+    vdf::ResizeAxisTable v{};
+    if (t) {
+        v.start = t->start.as<int32_t>();
+        v.size = t->size.as<int32_t>();
+        v.w = t->w.as<int16_t>();
+        v.window = t->host.window;
+        v.precision = t->host.precision;
+    }
+    return v;
+}
+
+int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out, uint32_t *d_dc,
+                       hipStream_t stream)
+{
+    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
+    if (n_clips == 0) return VDF_OK;
+    if (n_clips > 0x7FFFFFFull) return fail(ctx, VDF_E_INVAL, "too many clips in one call");
+    if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->cos_table.p) {
+        double tab[16 * 16];
+        for (int k = 0; k < 16; k++)
+            for (int n = 0; n < 16; n++) tab[k * 16 + n] = std::cos(M_PI * (double)k * ((double)n + 0.5) / 16.0);
+        int rc = upload(ctx, ctx->cos_table, tab, sizeof tab, stream);
+        if (rc) return rc;
+        VDF_HIP(ctx, hipStreamSynchronize(stream));
+    }
+    const bool direct = (w == VDF_DCT_SIZE && h == VDF_DCT_SIZE && ((uintptr_t)d_frames % 16) == 0 &&
+                         frame_stride % 16 == 0 && clip_stride % 16 == 0);
+    if (direct) {
+        VDF_HIP(ctx, vdf::launch_dct_hash(d_frames, clip_stride, frame_stride, n_clips, ctx->cos_table.as<double>(),
+                                          d_out, d_dc, stream));
+        return VDF_OK;
+    }
+    const int need_h = (w != VDF_DCT_SIZE), need_v = (h != VDF_DCT_SIZE);
+    int rc = VDF_OK;
+    DeviceAxisTable *th = need_h ? axis_table(ctx, w, stream, &rc) : nullptr;
+    if (rc) return rc;
+    DeviceAxisTable *tv = need_v ? axis_table(ctx, h, stream, &rc) : nullptr;
+    if (rc) return rc;
+    int32_t y_first = 0, tmp_rows = VDF_DCT_SIZE;
+    if (need_v) {
+        y_first = tv->host.start[0];
+        tmp_rows = tv->host.start[VDF_DCT_SIZE - 1] + tv->host.size[VDF_DCT_SIZE - 1] - y_first;
+    }
+    if ((size_t)tmp_rows * 16 > 64 * 1024) return fail(ctx, VDF_E_BAD_DIMS, "frame height above 4096 is not supported yet");
+    VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+    VDF_HIP(ctx, vdf::launch_resize_generic(d_frames, n_clips, w, h, frame_stride, clip_stride, dev_view(th),
+                                            dev_view(tv), need_h, need_v, y_first, tmp_rows,
+                                            ctx->small.as<uint8_t>(), stream));
+    VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(),
+                                      d_out, d_dc, stream));
+    return VDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdf_ctx_create(int device_id, vdf_ctx **out)
+{
+    if (!out) return VDF_E_INVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+        (void)hipGetLastError();
+        return VDF_E_HIP;
+    }
+    if (device_id < 0 || device_id >= count) { g_create_error = "device id out of range"; return VDF_E_INVAL; }
+    vdf_ctx *ctx = new (std::nothrow) vdf_ctx();
+    if (!ctx) return VDF_E_OOM;
+    ctx->device = device_id;
+    bool ok = hipSetDevice(device_id) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+    if (!ok) {
+        g_create_error = std::string("context setup failed: ") + hipGetErrorString(hipGetLastError());
+        delete ctx;
+        return VDF_E_HIP;
+    }
+    if (const char *s = std::getenv("VDF_ROWS_PER_LANE")) {
+        int r = std::atoi(s);
+        if (r == 1 || r == 2 || r == 4) ctx->tile_rows = 256u * (uint32_t)r;
+    }
+    if (const char *s = std::getenv("VDF_CHUNK_COLS")) {
+        long c = std::atol(s);
+        if (c >= 64 && c <= (1 << 20)) ctx->chunk_cols = (uint32_t)c;
+    }
+    *out = ctx;
+    return VDF_OK;
+}
+
+void vdf_ctx_destroy(vdf_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    delete ctx;
+}
+
+const char *vdf_last_error(const vdf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+int vdf_ctx_device(const vdf_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int vdf_ctx_set_hit_capacity(vdf_ctx *ctx, uint64_t capacity)
+{
+    if (!ctx || capacity == 0 || capacity > (1ull << 32)) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->hit_capacity = capacity;
+    return VDF_OK;
+}
+
+int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
+{
+    if (!ctx || !out) return VDF_E_INVAL;
+    *out = ctx->stats;
+    return VDF_OK;
+}
+
+uint32_t vdf_row_tile_size(void) { return 256u * vdf::kDefaultRowsPerLane; }
+
+int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                              uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,
+                              uint32_t *d_out_dontcare, void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_out_hashes,
+                              d_out_dontcare, s);
+}
+
+int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                       uint32_t *out_dontcare)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
+    if (n_clips == 0) return VDF_OK;
+    if (!frames || !out_hashes) return fail(ctx, VDF_E_INVAL, "null pointer");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // Only the first 16 frames of a clip travel to the device, packed tightly; batches bound the staging buffer.
+    const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, (512ull << 20) / cbytes));
+    VDF_HIP(ctx, ctx->frames.reserve(batch * cbytes));
+    VDF_HIP(ctx, ctx->out_hashes.reserve(batch * VDF_HASH_WORDS * 8));
+    VDF_HIP(ctx, ctx->out_dc.reserve(batch * 4));
+    for (size_t c0 = 0; c0 < n_clips; c0 += batch) {
+        const size_t nb = std::min(batch, n_clips - c0);
+        if (frame_stride == fbytes && clip_stride == cbytes) {
+            VDF_HIP(ctx, hipMemcpyAsync(ctx->frames.p, frames + c0 * clip_stride, nb * cbytes, hipMemcpyHostToDevice, s));
+        } else {
+            for (size_t c = 0; c < nb; c++)
+                VDF_HIP(ctx, hipMemcpy2DAsync(ctx->frames.as<uint8_t>() + c * cbytes, fbytes,
+                                              frames + (c0 + c) * clip_stride, frame_stride, fbytes, VDF_DCT_SIZE,
+                                              hipMemcpyHostToDevice, s));
+        }
+        int rc = hash_device_locked(ctx, ctx->frames.as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
+                                    ctx->out_hashes.as<uint64_t>(), out_dontcare ? ctx->out_dc.as<uint32_t>() : nullptr, s);
+        if (rc) return rc;
+        VDF_HIP(ctx, hipMemcpyAsync(out_hashes + c0 * VDF_HASH_WORDS, ctx->out_hashes.p, nb * VDF_HASH_WORDS * 8,
+                                    hipMemcpyDeviceToHost, s));
+        if (out_dontcare)
+            VDF_HIP(ctx, hipMemcpyAsync(out_dontcare + c0, ctx->out_dc.p, nb * 4, hipMemcpyDeviceToHost, s));
+        VDF_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return VDF_OK;
+}
+
+int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
+                           uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
+                           uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
+                           uint64_t *n_hits, uint32_t *overflow_row, void *stream)
+{
+    if (!ctx || !n_hits || !overflow_row || (capacity && !hits)) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->stats = vdf_search_stats{};
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return search_core(ctx, 0, d_hashes, d_durations, n, d_hashes, d_durations, nullptr, n, tol_int, shard_index,
+                       shard_count, row_begin, row_end, d_matched, 0, hits, capacity, n_hits, overflow_row, s);
+}
+
+static int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
+                                     size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
+                                     size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
+                                     uint64_t capacity, uint64_t *n_hits, hipStream_t s)
+{
+    ctx->stats = vdf_search_stats{};
+    *n_hits = 0;
+    if (n_ref == 0 || n_cand == 0) return VDF_OK;
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    // References arrive in the caller's order; tiles want neighbouring rows to share a duration window, so
+    // rows are visited through a stable duration-sorted permutation (reported indices stay the caller's).
+    std::vector<uint32_t> rdur(n_ref), perm(n_ref);
+    VDF_HIP(ctx, hipMemcpyAsync(rdur.data(), d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
+    VDF_HIP(ctx, hipStreamSynchronize(s));
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rdur[a] < rdur[b]; });
+    int rc = upload(ctx, ctx->perm, perm.data(), n_ref * 4, s);
+    if (rc) return rc;
+    uint32_t overflow_row = 0;
+    rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
+                     ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
+                     capacity, n_hits, &overflow_row, s);
+    if (rc) return rc;
+    if (*n_hits > capacity) return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size");
+    return VDF_OK;
+}
+
+int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
+                           size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations, size_t n_ref,
+                           uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits, uint64_t capacity,
+                           uint64_t *n_hits, void *stream)
+{
+    if (!ctx || !n_hits || (capacity && !hits)) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return search_refs_device_locked(ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
+                                     n_ref, tol_int, ref_index_base, hits, capacity, n_hits,
+                                     stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int vdf_search_self(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, size_t n, uint32_t tol_int,
+                    vdf_groups *out)
+{
+    if (!ctx || !out) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::memset(out, 0, sizeof *out);
+    ctx->stats = vdf_search_stats{};
+    if (n == 0) return vdf_groups_finish_self(out);  // search_algorithm.rs:89-91
+    if (!hashes || !durations) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = upload(ctx, ctx->up_hashes, hashes, n * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK) rc = upload(ctx, ctx->up_dur, durations, n * 4, s);
+    if (rc) return rc;
+
+    uint64_t capacity = ctx->hit_capacity;
+    std::vector<uint8_t> matched(n, 0);
+    std::vector<uint32_t> bitmap;
+    const uint32_t *d_matched = nullptr;
+    uint32_t row_begin = 0;
+    uint64_t span = n;  // rows per launch; shrinks after an overflow, grows back afterwards
+    while (row_begin < n) {
+        const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
+        if (ctx->host_hits.size() < capacity) ctx->host_hits.resize(capacity);
+        uint64_t n_hits = 0;
+        uint32_t overflow_row = 0xFFFFFFFFu;
+        rc = search_core(ctx, 0, ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), n,
+                         ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), nullptr, n, tol_int, 0, 1,
+                         row_begin, row_end, d_matched, 0, ctx->host_hits.data(), capacity, &n_hits, &overflow_row, s);
+        if (rc) { vdf_groups_free(out); return rc; }
+        const uint32_t complete_end = std::min(overflow_row, row_end);
+        rc = vdf_replay_self(n, ctx->host_hits.data(), std::min(n_hits, capacity), row_begin, complete_end,
+                             matched.data(), out);
+        if (rc) { vdf_groups_free(out); return fail(ctx, rc, "replay failed"); }
+        if (overflow_row == 0xFFFFFFFFu) {
+            row_begin = row_end;
+            span = std::min<uint64_t>(n, span * 4);
+        } else {
+            const uint64_t progress = complete_end - row_begin;
+            if (progress == 0) {
+                // Not even one row fit: give a single row the whole buffer (its hits are < n).
+                span = 1;
+                if (capacity < n) capacity = n;
+            } else {
+                span = std::max<uint64_t>(progress * 2, ctx->tile_rows);
+            }
+            row_begin = complete_end;
+        }
+        if (row_begin < n) {  // feed the consumption state back to the device
+            bitmap.assign((n + 31) / 32, 0u);
+            for (size_t i = 0; i < n; i++)
+                if (matched[i]) bitmap[i >> 5] |= 1u << (i & 31);
+            rc = upload(ctx, ctx->matched, bitmap.data(), bitmap.size() * 4, s);
+            if (rc) { vdf_groups_free(out); return rc; }
+            d_matched = ctx->matched.as<uint32_t>();
+        }
+    }
+    return vdf_groups_finish_self(out);
+}
+
+int vdf_search_refs(vdf_ctx *ctx, const uint64_t *cand_hashes, const uint32_t *cand_durations, size_t n_cand,
+                    const uint64_t *ref_hashes, const uint32_t *ref_durations, size_t n_ref, uint32_t tol_int,
+                    vdf_groups *out)
+{
+    if (!ctx || !out) return VDF_E_INVAL;
+    std::memset(out, 0, sizeof *out);
+    if (n_cand == 0 || n_ref == 0) return vdf_groups_from_ref_hits(nullptr, 0, out);
+    if (!cand_hashes || !cand_durations || !ref_hashes || !ref_durations) return fail(ctx, VDF_E_INVAL, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = upload(ctx, ctx->up_hashes, cand_hashes, n_cand * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK) rc = upload(ctx, ctx->up_dur, cand_durations, n_cand * 4, s);
+    if (rc == VDF_OK) rc = upload(ctx, ctx->up_ref_hashes, ref_hashes, n_ref * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK) rc = upload(ctx, ctx->up_ref_dur, ref_durations, n_ref * 4, s);
+    if (rc) return rc;
+    uint64_t capacity = ctx->hit_capacity;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (ctx->host_hits.size() < capacity) ctx->host_hits.resize(capacity);
+        uint64_t n_hits = 0;
+        rc = search_refs_device_locked(ctx, ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), n_cand,
+                                       ctx->up_ref_hashes.as<uint64_t>(), ctx->up_ref_dur.as<uint32_t>(), n_ref,
+                                       tol_int, 0, ctx->host_hits.data(), capacity, &n_hits, s);
+        if (rc == VDF_E_OVERFLOW && attempt == 0) { capacity = n_hits; continue; }  // every hit is output: size exactly
+        if (rc) return rc;
+        return vdf_groups_from_ref_hits(ctx->host_hits.data(), n_hits, out);
+    }
+    return fail(ctx, VDF_E_OVERFLOW, "hit buffer overflow");
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// Tiled XOR + popcount Hamming search for gfx950 (MI355X), wave64.
+//
+// Replaces the O(n^2) loops of the reference:
+//   search_self  hot loop  vid_dup_finder_lib/src/video_hashing/search_algorithm.rs:150-156
+//   search_one   hot loop  vid_dup_finder_lib/src/video_hashing/search_algorithm.rs:67-74
+//   hamming_distance       vid_dup_finder_lib/src/video_hashing/video_hash.rs:311-317
+//
+// Layout of one workgroup (4 waves, 256 threads), R = rows per lane:
+//   - every lane keeps R target hashes (R x 32 dwords) in VGPRs for the whole tile;
+//   - candidate hashes are wave-uniform: they are fetched with scalar loads (s_load_dwordx16 x2
+//     through the scalar cache) and used as the SGPR operand of v_xor_b32; v_bcnt_u32_b32
+//     accumulates the popcount for free.  64 VALU lane-ops per pair, no LDS, no VGPR traffic;
+//   - per candidate one v_min + one v_cmp + one scalar branch guard the rare slow path that
+//     applies the duration window / consumption bitmap and appends (row, col) to the hit buffer.
+// The kernel is VALU-bound (see DESIGN.md "Hamming kernel"): HBM traffic is ~0.25 B per pair.
+#include "vdf_internal.h"
+
+namespace vdf {
+
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;  // forces s_load for uniform addresses
+
+__device__ __forceinline__ uint32_t sat_u32(double x)
+{  // Rust `f64 as u32`: truncating, saturating, NaN -> 0
+    if (!(x == x)) return 0u;
+    if (x <= 0.0) return 0u;
+    if (x >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+
+// first index with !(d[idx] < v)
+__device__ __forceinline__ uint32_t partition_point_lt(const uint32_t *__restrict__ d, uint32_t n, uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (d[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first index with !(d[idx] <= v)
+__device__ __forceinline__ uint32_t partition_point_le(const uint32_t *__restrict__ d, uint32_t n, uint32_t v)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (d[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+// One workgroup per row tile: per-row candidate windows, per-tile candidate range and chunk count.
+//   mode 0 (search_self): row i -> [i + 1, first j with dur[j] > (f64(dur[i]) * 1.1) as u32)
+//                         (search_algorithm.rs:93-117: rhs pointer; candidates are the later entries)
+//   mode 1 (search_one):  ref r -> [partition_point(dur < (d*0.95) as u32), partition_point(dur <= (d*1.05) as u32))
+//                         (search_algorithm.rs:173-185)
+__global__ __launch_bounds__(256) void windows_tiles_kernel(
+    int mode, const uint32_t *__restrict__ col_dur, uint32_t n_cols, const uint32_t *__restrict__ row_dur,
+    const uint32_t *__restrict__ row_perm, uint32_t n_rows, uint32_t row_begin, uint32_t row_end, uint32_t shard_index,
+    uint32_t shard_count, uint32_t tile_rows, uint32_t chunk_cols, uint32_t *__restrict__ row_lo,
+    uint32_t *__restrict__ row_hi, uint32_t *__restrict__ tile_lo, uint32_t *__restrict__ tile_hi,
+    uint32_t *__restrict__ tile_first, uint32_t *__restrict__ tile_count, unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t s_min[4], s_max[4];
+    __shared__ unsigned long long s_pairs[4];
+    const uint32_t t = blockIdx.x;
+    const bool mine = (t % shard_count) == shard_index;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    unsigned long long pairs = 0;
+    for (uint32_t q = threadIdx.x; q < tile_rows; q += 256) {
+        const uint32_t p = t * tile_rows + q;
+        uint32_t lo = 0, hi = 0;
+        if (mine && p < n_rows && p >= row_begin && p < row_end) {
+            const uint32_t r = row_perm ? row_perm[p] : p;
+            const double d = (double)row_dur[r];
+            if (mode == 0) {
+                lo = p + 1;
+                hi = partition_point_le(col_dur, n_cols, sat_u32(d * 1.1));
+            } else {
+                lo = partition_point_lt(col_dur, n_cols, sat_u32(d * 0.95));
+                hi = partition_point_le(col_dur, n_cols, sat_u32(d * 1.05));
+            }
+            if (hi <= lo) { lo = 0; hi = 0; }
+        }
+        row_lo[p] = lo;
+        row_hi[p] = hi;
+        if (hi > lo) {
+            mn = min(mn, lo);
+            mx = max(mx, hi);
+            pairs += hi - lo;
+        }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pairs += __shfl_xor(pairs, o, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = mn; s_max[wave] = mx; s_pairs[wave] = pairs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        pairs = s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3];
+        uint32_t cnt = 0, first = 0;
+        if (mx > mn) {
+            first = mn / chunk_cols;
+            cnt = (mx + chunk_cols - 1) / chunk_cols - first;
+        } else {
+            mn = 0; mx = 0;
+        }
+        tile_lo[t] = mn;
+        tile_hi[t] = mx;
+        tile_first[t] = first;
+        tile_count[t] = cnt;
+        if (pairs) atomicAdd(&counters[2], pairs);
+    }
+}
+
+// Exclusive scan of tile_count[0..n) into tile_offset[0..n]; single workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t n,
+                                                          uint32_t *__restrict__ tile_offset)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t b = min(tid * per, n), e = min(b + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += tile_count[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = (tid >= o) ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (uint32_t i = b; i < e; i++) { tile_offset[i] = run; run += tile_count[i]; }
+    if (tid == 1023) tile_offset[n] = s_part[1023];
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void hamming_tile_kernel(
+    const uint32_t *__restrict__ row_hashes, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
+    uint32_t row_index_base, const uint32_t *__restrict__ col_hashes, const uint32_t *__restrict__ row_lo,
+    const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
+    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_offset, uint32_t n_row_tiles,
+    uint32_t chunk_cols, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
+    vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ overflow_row)
+{
+    constexpr uint32_t TILE_ROWS = 256 * R;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // workgroup -> (row tile, candidate chunk): largest t with tile_offset[t] <= blockIdx.x
+    const_u32_ptr off = (const_u32_ptr)(uintptr_t)tile_offset;
+    uint32_t tl = 0, th = n_row_tiles;
+    while (th - tl > 1) {
+        const uint32_t mid = (tl + th) >> 1;
+        if (off[mid] <= blockIdx.x) tl = mid; else th = mid;
+    }
+    const uint32_t t = tl;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)tile_first)[t] + (blockIdx.x - off[t]);
+    const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
+    const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
+    const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
+    const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
+    if (c_begin >= c_end) return;
+
+    // targets -> VGPRs
+    uint32_t rw[R][32];
+    uint32_t rlo[R], rhi[R], rid[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint32_t p = t * TILE_ROWS + wave * (64 * R) + k * 64 + lane;
+        uint32_t lo = row_lo[p], hi = row_hi[p];  // arrays are padded to whole tiles
+        uint32_t src = p;
+        if (p < n_rows) {
+            if (row_perm) src = row_perm[p];
+            const uint4 *rp = reinterpret_cast<const uint4 *>(row_hashes + (size_t)src * 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint4 v = rp[q];
+                rw[k][4 * q + 0] = v.x; rw[k][4 * q + 1] = v.y; rw[k][4 * q + 2] = v.z; rw[k][4 * q + 3] = v.w;
+            }
+            if (self_mode && matched && ((matched[src >> 5] >> (src & 31)) & 1u)) { lo = 0; hi = 0; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; q++) rw[k][q] = 0u;
+            lo = 0; hi = 0;
+        }
+        rlo[k] = lo; rhi[k] = hi; rid[k] = row_index_base + src;
+    }
+
+    const_u32_ptr cols = (const_u32_ptr)(uintptr_t)col_hashes;
+    for (uint32_t c = c_begin; c < c_end; ++c) {
+        const_u32_ptr cp = cols + (size_t)c * 32;
+        uint32_t d[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) d[k] = 0u;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) {
+            const uint32_t cw = cp[w];  // SGPR
+#pragma unroll
+            for (int k = 0; k < R; k++) d[k] += __builtin_popcount(rw[k][w] ^ cw);
+        }
+        uint32_t m = d[0];
+#pragma unroll
+        for (int k = 1; k < R; k++) m = min(m, d[k]);
+        if (__builtin_amdgcn_ballot_w64(m <= tol) != 0ull) {
+            // rare path: window, consumption bitmap, append
+            bool col_ok = true;
+            if (matched) col_ok = ((((const_u32_ptr)(uintptr_t)matched)[c >> 5] >> (c & 31)) & 1u) == 0u;
+            if (col_ok) {
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    if (d[k] <= tol && c >= rlo[k] && c < rhi[k]) {
+                        const unsigned long long idx = atomicAdd(&counters[0], 1ull);
+                        if (idx < capacity) {
+                            vdf_hit hpair; hpair.row = rid[k]; hpair.col = c;
+                            hits[idx] = hpair;
+                        } else {
+                            atomicMin(overflow_row, rid[k]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * TILE_ROWS);
+}
+
+hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,
+                                const uint32_t *row_perm, uint32_t n_rows, uint32_t row_begin, uint32_t row_end,
+                                uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L, hipStream_t stream)
+{
+    if (L.n_row_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(windows_tiles_kernel, dim3(L.n_row_tiles), dim3(256), 0, stream, mode, col_dur, n_cols, row_dur,
+                       row_perm, n_rows, row_begin, row_end, shard_index, shard_count, (uint32_t)L.tile_rows,
+                       L.chunk_cols, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi, L.tile_first, L.tile_count, L.counters);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, L.tile_count, L.n_row_tiles, L.tile_offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)
+{
+    if (total_tiles == 0) return hipSuccess;
+#define VDF_LAUNCH(RR)                                                                                              \
+    hipLaunchKernelGGL(hamming_tile_kernel<RR>, dim3(total_tiles), dim3(256), 0, stream, L.row_hashes, L.row_perm,   \
+                       L.n_rows, L.row_index_base, L.col_hashes, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,          \
+                       L.tile_first, L.tile_offset, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
+                       L.hits, L.capacity, L.counters, L.overflow_row)
+    switch (L.tile_rows / 256) {
+    case 1: VDF_LAUNCH(1); break;
+    case 2: VDF_LAUNCH(2); break;
+    case 4: VDF_LAUNCH(4); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef VDF_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace vdf

@@ -1,0 +1,78 @@
+// Host-side Lanczos3 coefficient tables for the resize stage (product code; the parity oracle has
+// its own independent restatement in oracle/).
+//
+// Follows what vid_dup_finder_common/src/resize_gray.rs:34-47 asks fast_image_resize 5.1 for:
+// ResizeAlg::Convolution(FilterType::Lanczos3) on PixelType::U8 with the whole image as crop box.
+// The crate's published algorithm: per output pixel a window of f64 weights normalised to 1,
+// quantised to i16 with the largest precision p such that round(max_w * 2^(p+1)) < 2^15.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "resize_tables.h"
+
+namespace vdf {
+
+static double sinc_pi(double x)
+{
+    if (x == 0.0) return 1.0;
+    x *= M_PI;
+    return std::sin(x) / x;
+}
+
+static double lanczos3(double x)
+{
+    if (x >= -3.0 && x < 3.0) return sinc_pi(x) * sinc_pi(x / 3.0);
+    return 0.0;
+}
+
+bool build_axis_table(uint32_t in_size, uint32_t out_size, HostAxisTable &t)
+{
+    t = HostAxisTable();
+    if (in_size == 0 || out_size == 0) return false;
+    const double scale = (double)in_size / (double)out_size;
+    const double fscale = scale > 1.0 ? scale : 1.0;
+    const double radius = 3.0 * fscale;
+    const int window = (int)std::ceil(radius) * 2 + 1;
+    const double recip = 1.0 / fscale;
+    std::vector<double> vals((size_t)window * out_size, 0.0);
+    t.start.assign(out_size, 0);
+    t.size.assign(out_size, 0);
+    t.window = window;
+    for (uint32_t o = 0; o < out_size; o++) {
+        const double in_center = ((double)o + 0.5) * scale;
+        double lo = std::floor(in_center - radius), hi = std::ceil(in_center + radius);
+        if (lo < 0.0) lo = 0.0;
+        if (hi > (double)in_size) hi = (double)in_size;
+        const uint32_t x_min = (uint32_t)lo, x_max = (uint32_t)hi;
+        const double center = in_center - 0.5;
+        double *k = vals.data() + (size_t)o * window;
+        int n = 0;
+        double ww = 0.0;
+        uint32_t b0 = x_min, b1 = x_max;
+        for (uint32_t x = x_min; x < x_max; x++) {
+            const double w = lanczos3(((double)x - center) * recip);
+            if (x == b0 && w == 0.0) b0++;  // leading zero taps are not stored
+            else { k[n++] = w; ww += w; }
+        }
+        for (int i = n - 1; i >= 0 && b1 > b0 && k[i] == 0.0; i--) b1--;  // trailing zero taps
+        if (ww != 0.0)
+            for (int i = 0; i < n; i++) k[i] /= ww;
+        t.start[o] = (int32_t)b0;
+        t.size[o] = (int32_t)(b1 - b0);
+    }
+    double max_w = vals[0];
+    for (double v : vals) max_w = v > max_w ? v : max_w;
+    int precision = 0;
+    for (int p = 0; p < 16; p++) {
+        precision = p;
+        if ((int32_t)std::round(max_w * (double)(1 << (p + 1))) >= (1 << 15)) break;
+    }
+    t.precision = precision;
+    t.w.resize(vals.size());
+    const double q = (double)(1 << precision);
+    for (size_t i = 0; i < vals.size(); i++) t.w[i] = (int16_t)std::round(vals[i] * q);
+    return true;
+}
+
+}  // namespace vdf

@@ -1,0 +1,64 @@
+// Internal declarations shared by the HIP translation units and the C-ABI layer.
+// Nothing here is part of the public boundary (include/vdf.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vdf.h"
+
+namespace vdf {
+
+// ---- Hamming search tiling -------------------------------------------------------------------
+// One workgroup = 4 waves; every lane keeps ROWS_PER_LANE target hashes in VGPRs and streams the
+// candidate hashes through SGPRs (scalar loads), so a workgroup covers TILE_ROWS targets.
+constexpr int kDefaultRowsPerLane = 2;                       // tile = 256 * rows-per-lane targets
+constexpr uint32_t kDefaultChunkCols = 2048;                // candidates per workgroup
+
+struct SearchLaunch {
+    // rows (targets / references)
+    const uint32_t *row_hashes;  // [n_rows][32] dwords
+    const uint32_t *row_perm;    // nullable: row position -> index into row_hashes / reported row
+    uint32_t n_rows;
+    uint32_t row_index_base;     // added to the reported row
+    // columns (candidates)
+    const uint32_t *col_hashes;  // [n_cols][32]
+    uint32_t n_cols;
+    // windows + tiles (device scratch, filled by launch_windows_tiles)
+    uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
+    uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
+    uint32_t n_row_tiles;
+    uint32_t tile_rows;          // 256 * rows-per-lane (256, 512 or 1024)
+    uint32_t chunk_cols;
+    uint32_t tol;
+    const uint32_t *matched;     // nullable bitmap over column indices (self mode: rows too)
+    int self_mode;
+    // output
+    vdf_hit *hits;
+    unsigned long long capacity;
+    unsigned long long *counters;  // [0] hits produced, [1] pairs computed, [2] pairs admitted
+    uint32_t *overflow_row;
+};
+
+// mode 0: self-search windows [i+1, rhs(i));  mode 1: reference windows [lhs(r), rhs(r)).
+hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,
+                                const uint32_t *row_perm, uint32_t n_rows, uint32_t row_begin, uint32_t row_end,
+                                uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L,
+                                hipStream_t stream);
+hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
+
+// ---- hash construction -----------------------------------------------------------------------
+struct ResizeAxisTable {  // device pointers, one axis
+    const int32_t *start;  // [16]
+    const int32_t *size;   // [16]
+    const int16_t *w;      // [16][window]
+    int32_t window;
+    int32_t precision;
+};
+
+hipError_t launch_resize_generic(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                 size_t clip_stride, ResizeAxisTable th, ResizeAxisTable tv, int need_h, int need_v,
+                                 int32_t y_first, int32_t tmp_rows, uint8_t *small, hipStream_t stream);
+hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
+                           const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream);
+
+}  // namespace vdf

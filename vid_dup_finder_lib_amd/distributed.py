@@ -1,0 +1,164 @@
+"""Multi-GPU search: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+How the path shards (DESIGN.md "Multi-GPU"):
+  * hashing: clips are independent -> every rank hashes its own clips, no communication;
+  * search(): every rank holds a shard of the hash database.  ONE all-gather (the only exchange step of the
+    path) replicates the database in every GPU's HBM; row tiles of the upper triangle are dealt round-robin
+    (tile t -> rank t % world) so the triangular work balances; each rank emits the thresholded pairs of its
+    tiles; rank 0 merges the (sparse) hit lists and replays the greedy consumption of
+    Search::search_self (search_algorithm.rs:131-170) once -> MatchGroups identical for every world size;
+  * search_with_references(): candidates replicated the same way, references split contiguously by rank;
+    per-rank results concatenate in rank order (= reference input order).
+
+torch is plumbing here (device buffers, streams, collectives); the arithmetic is in libvdf_hip.so.
+The `engine` argument only needs search_self_device / search_refs_device, so the orchestration is testable on
+CPU with the gloo backend and a stand-in hit producer (tests/test_distributed_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine as _eng
+from ._capi import HASH_WORDS
+
+UINT32_MAX = 0xFFFFFFFF
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def all_gather_database(local_words: torch.Tensor, local_dur: torch.Tensor, group=None):
+    """Replicate the sharded database: local_words [n_local, 16] int64, local_dur [n_local] int32 (same device).
+    Returns (words [n, 16], dur [n]) in rank order.  Shards may have different sizes (padded for the collective)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local_words, local_dur
+    dev = local_words.device
+    n_local = torch.tensor([local_words.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes)
+    pad_w = torch.zeros((m, HASH_WORDS), dtype=torch.int64, device=dev)
+    pad_d = torch.zeros((m,), dtype=torch.int32, device=dev)
+    pad_w[: local_words.shape[0]] = local_words
+    pad_d[: local_dur.shape[0]] = local_dur
+    out_w = torch.empty((world * m, HASH_WORDS), dtype=torch.int64, device=dev)
+    out_d = torch.empty((world * m,), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(out_w, pad_w, group=group)  # X1: (n/G) * 16 x int64 per rank
+    dist.all_gather_into_tensor(out_d, pad_d, group=group)  # X2: n/G x int32 per rank
+    if all(s == m for s in sizes):
+        return out_w, out_d
+    keep = torch.cat([torch.arange(r * m, r * m + s, device=dev) for r, s in enumerate(sizes)])
+    return out_w.index_select(0, keep).contiguous(), out_d.index_select(0, keep).contiguous()
+
+
+def _gather_hits(hits: np.ndarray, group=None) -> Optional[np.ndarray]:
+    """Variable-length gather of [k, 2] uint32 hit lists to rank 0 (merged and sorted by (row, col))."""
+    rank, world = _world(group)
+    if world == 1:
+        return hits
+    bufs = [None] * world if rank == 0 else None
+    dist.gather_object(np.ascontiguousarray(hits), bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    allh = np.concatenate([b.reshape(-1, 2) for b in bufs]) if bufs else hits
+    if len(allh):
+        order = np.lexsort((allh[:, 1], allh[:, 0]))
+        allh = allh[order]
+    return allh
+
+
+def _coll_device(group=None) -> torch.device:
+    backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_int: int, capacity: int = 1 << 22,
+                        group=None, stream: int = 0) -> Optional[List[List[int]]]:
+    """search() over a replicated, sorted database.  Returns the groups (lists of sorted indices, reference
+    order) on rank 0 and None elsewhere.  d_words/d_dur live on this rank's GPU."""
+    rank, world = _world(group)
+    n = int(d_dur.shape[0])
+    if n == 0:
+        return [] if rank == 0 else None
+    matched = np.zeros(n, np.uint8) if rank == 0 else None
+    groups = None
+    d_matched = None
+    row_begin = 0
+    row_end = UINT32_MAX
+    while row_begin < n:
+        hits, n_hits, overflow = engine.search_self_device(
+            d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, shard_index=rank, shard_count=world,
+            row_begin=row_begin, row_end=row_end, d_matched=(d_matched.data_ptr() if d_matched is not None else 0),
+            capacity=capacity, stream=stream)
+        if world > 1:
+            t = torch.tensor([overflow], dtype=torch.int64, device=_coll_device(group))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            overflow = int(t.item())
+        merged = _gather_hits(hits, group)
+        complete_end = min(overflow, n if row_end == UINT32_MAX else min(row_end, n))
+        if rank == 0:
+            groups = _eng.replay_self(n, merged, matched, row_begin, complete_end, groups)
+        if overflow == UINT32_MAX:
+            if row_end == UINT32_MAX or row_end >= n:
+                break
+            row_begin, row_end = row_end, UINT32_MAX
+        else:
+            if complete_end == row_begin:  # not even one row fit: give that row the whole buffer
+                row_end = row_begin + 1
+                capacity = max(capacity, n)
+            else:
+                row_end = UINT32_MAX
+            row_begin = complete_end
+        # feed the consumption bitmap back to every rank
+        words = (n + 31) // 32
+        cdev = _coll_device(group)
+        if rank == 0:
+            bits = np.packbits(matched, bitorder="little")
+            bits = np.concatenate([bits, np.zeros(words * 4 - len(bits), np.uint8)]).view(np.int32)
+            bm = torch.from_numpy(bits.copy()).to(cdev)
+        else:
+            bm = torch.empty(words, dtype=torch.int32, device=cdev)
+        if world > 1:
+            dist.broadcast(bm, src=0, group=group)
+        d_matched = bm.to(d_words.device)
+    if rank != 0:
+        return None
+    if groups is None:
+        groups = _eng.replay_self(n, np.zeros((0, 2), np.uint32), matched, 0, 0, None)
+    return _eng.finish_self(groups)
+
+
+def split_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, order-preserving split of n items."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def search_refs_sharded(engine, d_cand_words: torch.Tensor, d_cand_dur: torch.Tensor, d_ref_words: torch.Tensor,
+                        d_ref_dur: torch.Tensor, ref_index_base: int, tol_int: int, capacity: int = 1 << 22,
+                        group=None, stream: int = 0) -> Optional[List[Tuple[int, List[int]]]]:
+    """search_with_references() with the candidates replicated and THIS rank's slice of the references
+    (global positions ref_index_base ..).  Rank 0 returns [(ref_index, [candidate indices])] in reference order."""
+    rank, world = _world(group)
+    n_ref = int(d_ref_dur.shape[0])
+    n_cand = int(d_cand_dur.shape[0])
+    if n_ref and n_cand:
+        hits, _ = engine.search_refs_device(d_cand_words.data_ptr(), d_cand_dur.data_ptr(), n_cand,
+                                            d_ref_words.data_ptr(), d_ref_dur.data_ptr(), n_ref, tol_int,
+                                            ref_index_base=ref_index_base, capacity=capacity, stream=stream)
+    else:
+        hits = np.zeros((0, 2), np.uint32)
+    merged = _gather_hits(hits, group)
+    if rank != 0:
+        return None
+    return _eng.groups_from_ref_hits(merged)

@@ -1,0 +1,219 @@
+"""Engine: one vdf_ctx (one GPU) behind numpy-friendly methods.
+
+Thin host plumbing over the C ABI (include/vdf.h).  All arithmetic of the hot path runs in
+libvdf_hip.so on the GPU; nothing here computes a hash bit or a Hamming distance on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import HASH_WORDS, VdfError, VdfGroups, VdfHit, VdfSearchStats
+
+UINT32_MAX = 0xFFFFFFFF
+
+
+def _groups_to_lists(g: VdfGroups) -> List[Tuple[int, List[int]]]:
+    out = []
+    n = int(g.n_groups)
+    for i in range(n):
+        a, b = int(g.offsets[i]), int(g.offsets[i + 1])
+        out.append((int(g.ref_index[i]), [int(g.members[k]) for k in range(a, b)]))
+    return out
+
+
+def groups_to_arrays(g: VdfGroups):
+    """(offsets u64[n+1], members u64[m], ref_index i64[n]) copies of a vdf_groups."""
+    n = int(g.n_groups)
+    offsets = np.ctypeslib.as_array(g.offsets, shape=(n + 1,)).copy() if g.offsets else np.zeros(1, np.uint64)
+    m = int(offsets[-1])
+    members = np.ctypeslib.as_array(g.members, shape=(m,)).copy() if m else np.zeros(0, np.uint64)
+    refs = np.ctypeslib.as_array(g.ref_index, shape=(n,)).copy() if n else np.zeros(0, np.int64)
+    return offsets, members, refs
+
+
+class Engine:
+    """One GPU context.  `device` defaults to LOCAL_RANK (one process per GPU) or 0."""
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = _capi.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        ctx = C.c_void_p()
+        rc = self.lib.vdf_ctx_create(int(device), C.byref(ctx))
+        if rc != _capi.VDF_OK:
+            msg = self.lib.vdf_last_error(None)
+            raise VdfError(rc, (msg or b"").decode() or "vdf_ctx_create failed (is a GPU visible?)")
+        self.ctx = ctx
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vdf_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc: int):
+        if rc != _capi.VDF_OK:
+            raise VdfError(rc, (self.lib.vdf_last_error(self.ctx) or b"").decode())
+
+    def set_hit_capacity(self, capacity: int):
+        self._check(self.lib.vdf_ctx_set_hit_capacity(self.ctx, int(capacity)))
+
+    def last_stats(self) -> dict:
+        s = VdfSearchStats()
+        self._check(self.lib.vdf_ctx_last_search_stats(self.ctx, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
+
+    # ------------------------------------------------------------------ hashing
+    def hash_frames(self, frames: np.ndarray, want_dontcare: bool = False):
+        """frames [n_clips, n_frames, H, W] u8 (host) -> hashes [n_clips, 16] u64.
+        Raises VdfError(VDF_E_NOT_ENOUGH_FRAMES) when n_frames < 16 (video_hash.rs:53,61)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim != 4:
+            raise ValueError("frames must be [n_clips, n_frames, H, W]")
+        nc, nf, h, w = frames.shape
+        out = np.zeros((nc, HASH_WORDS), np.uint64)
+        dc = np.zeros(nc, np.uint32) if want_dontcare else None
+        rc = self.lib.vdf_hash_frames_u8(self.ctx, frames.ctypes.data, nc, nf, w, h, w * h, nf * w * h,
+                                         out.ctypes.data, dc.ctypes.data if want_dontcare else None)
+        self._check(rc)
+        return (out, dc) if want_dontcare else out
+
+    def hash_frames_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int, d_out: int,
+                           d_dontcare: int = 0, frame_stride: Optional[int] = None,
+                           clip_stride: Optional[int] = None, stream: int = 0):
+        fs = w * h if frame_stride is None else frame_stride
+        cs = fs * frames_per_clip if clip_stride is None else clip_stride
+        self._check(self.lib.vdf_hash_frames_u8_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, fs, cs,
+                                                       d_out, d_dontcare or None, stream or None))
+
+    # ------------------------------------------------------------------- search
+    def search_self_sorted(self, hashes, durations, tol_int: int) -> List[List[int]]:
+        """search() on SoA input already in Search::sort order; groups of sorted indices."""
+        h = np.ascontiguousarray(hashes, dtype=np.uint64).reshape(-1, HASH_WORDS)
+        d = np.ascontiguousarray(durations, dtype=np.uint32)
+        assert h.shape[0] == d.shape[0]
+        g = VdfGroups()
+        self._check(self.lib.vdf_search_self(self.ctx, h.ctypes.data, d.ctypes.data, len(d), int(tol_int), C.byref(g)))
+        try:
+            return [m for _, m in _groups_to_lists(g)]
+        finally:
+            self.lib.vdf_groups_free(C.byref(g))
+
+    def search_refs_sorted(self, cand_hashes, cand_durations, ref_hashes, ref_durations, tol_int: int):
+        """search_with_references() on sorted candidates; [(ref_input_index, [candidate indices])]."""
+        ch = np.ascontiguousarray(cand_hashes, dtype=np.uint64).reshape(-1, HASH_WORDS)
+        cd = np.ascontiguousarray(cand_durations, dtype=np.uint32)
+        rh = np.ascontiguousarray(ref_hashes, dtype=np.uint64).reshape(-1, HASH_WORDS)
+        rd = np.ascontiguousarray(ref_durations, dtype=np.uint32)
+        g = VdfGroups()
+        self._check(self.lib.vdf_search_refs(self.ctx, ch.ctypes.data, cd.ctypes.data, len(cd), rh.ctypes.data,
+                                             rd.ctypes.data, len(rd), int(tol_int), C.byref(g)))
+        try:
+            return _groups_to_lists(g)
+        finally:
+            self.lib.vdf_groups_free(C.byref(g))
+
+    def search_self_device(self, d_hashes: int, d_durations: int, n: int, tol_int: int, shard_index: int = 0,
+                           shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
+                           capacity: int = 1 << 22, stream: int = 0):
+        """Thresholded adjacency of this shard's row tiles: (hits [k,2] u32 sorted, n_hits, overflow_row)."""
+        hits = np.zeros((max(capacity, 1), 2), np.uint32)
+        n_hits = C.c_uint64(0)
+        overflow = C.c_uint32(0)
+        self._check(self.lib.vdf_search_self_device(self.ctx, d_hashes, d_durations, n, int(tol_int), shard_index,
+                                                    shard_count, row_begin, min(row_end, UINT32_MAX),
+                                                    d_matched or None, hits.ctypes.data, capacity, C.byref(n_hits),
+                                                    C.byref(overflow), stream or None))
+        k = min(int(n_hits.value), capacity)
+        return hits[:k], int(n_hits.value), int(overflow.value)
+
+    def search_refs_device(self, d_cand_hashes: int, d_cand_durations: int, n_cand: int, d_ref_hashes: int,
+                           d_ref_durations: int, n_ref: int, tol_int: int, ref_index_base: int = 0,
+                           capacity: int = 1 << 22, stream: int = 0):
+        """(hits [k,2] u32 sorted by (ref, cand), n_hits).  Grows the buffer once if it was too small."""
+        for _ in range(2):
+            hits = np.zeros((max(capacity, 1), 2), np.uint32)
+            n_hits = C.c_uint64(0)
+            rc = self.lib.vdf_search_refs_device(self.ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes,
+                                                 d_ref_durations, n_ref, int(tol_int), ref_index_base,
+                                                 hits.ctypes.data, capacity, C.byref(n_hits), stream or None)
+            if rc == _capi.VDF_E_OVERFLOW:
+                capacity = int(n_hits.value)
+                continue
+            self._check(rc)
+            return hits[: int(n_hits.value)], int(n_hits.value)
+        raise VdfError(_capi.VDF_E_OVERFLOW, "hit buffer overflow")
+
+
+# ---------------------------------------------------------------- host-only helpers (no GPU needed)
+def hamming_distance_words(a, b) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(HASH_WORDS)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(HASH_WORDS)
+    return int(_capi.load().vdf_hamming_u1024(a.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              b.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+
+def tolerance_int(tolerance: float) -> int:
+    return int(_capi.load().vdf_tolerance_int(float(tolerance)))
+
+
+def count_pairs_self(sorted_durations) -> int:
+    d = np.ascontiguousarray(sorted_durations, dtype=np.uint32)
+    return int(_capi.load().vdf_count_pairs_self(d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d)))
+
+
+def count_pairs_refs(sorted_cand_durations, ref_durations) -> int:
+    c = np.ascontiguousarray(sorted_cand_durations, dtype=np.uint32)
+    r = np.ascontiguousarray(ref_durations, dtype=np.uint32)
+    return int(_capi.load().vdf_count_pairs_refs(c.ctypes.data_as(C.POINTER(C.c_uint32)), len(c),
+                                                 r.ctypes.data_as(C.POINTER(C.c_uint32)), len(r)))
+
+
+def replay_self(n: int, hits: np.ndarray, matched: Optional[np.ndarray] = None, row_begin: int = 0,
+                row_end: int = UINT32_MAX, groups: Optional[VdfGroups] = None) -> VdfGroups:
+    """Host replay of search_self's consumption (search_algorithm.rs:131-170) over hits sorted by (row, col).
+    Appends to `groups` (ascending target order); finish with finish_self()."""
+    lib = _capi.load()
+    hits = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    g = groups if groups is not None else VdfGroups()
+    rc = lib.vdf_replay_self(n, hits.ctypes.data, len(hits), row_begin, min(row_end, UINT32_MAX),
+                             matched.ctypes.data if matched is not None else None, C.byref(g))
+    if rc:
+        raise VdfError(rc, "vdf_replay_self failed")
+    return g
+
+
+def finish_self(groups: VdfGroups) -> List[List[int]]:
+    lib = _capi.load()
+    rc = lib.vdf_groups_finish_self(C.byref(groups))
+    if rc:
+        raise VdfError(rc, "vdf_groups_finish_self failed")
+    try:
+        return [m for _, m in _groups_to_lists(groups)]
+    finally:
+        lib.vdf_groups_free(C.byref(groups))
+
+
+def groups_from_ref_hits(hits: np.ndarray) -> List[Tuple[int, List[int]]]:
+    lib = _capi.load()
+    hits = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    g = VdfGroups()
+    rc = lib.vdf_groups_from_ref_hits(hits.ctypes.data, len(hits), C.byref(g))
+    if rc:
+        raise VdfError(rc, "vdf_groups_from_ref_hits failed")
+    try:
+        return _groups_to_lists(g)
+    finally:
+        lib.vdf_groups_free(C.byref(g))
