@@ -133,7 +133,11 @@ def main():
     shard_w = torch.from_numpy(words[lo:hi].view(np.int64)).to(dev)
     shard_d = torch.zeros(hi - lo, dtype=torch.int32, device=dev)
     pairs = n_total * (n_total - 1) // 2  # all durations equal: one window, the full triangle
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream: the library launches on the stream it is handed, and HIP events must be recorded
+    # on that same stream to see its kernels
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
 
     def barrier():
         torch.cuda.synchronize()

@@ -18,7 +18,8 @@
  *     needs paths and stays on the caller's side; every index this library returns is an index
  *     into the arrays the caller passed.
  *   - Functions with the suffix _device take DEVICE pointers (HIP allocations on the
- *     context's GPU) and a hipStream_t passed as void*; everything else takes host pointers.
+ *     context's GPU) and a hipStream_t passed as void* (NULL = the context's own non-blocking
+ *     stream, NOT the legacy default stream); everything else takes host pointers.
  *   - A context is bound to one GPU.  Multi-GPU runs use one process (and one context) per
  *     GPU; see DESIGN.md "Multi-GPU".
  *   - Thread safety: a context serialises its own calls with an internal mutex, so

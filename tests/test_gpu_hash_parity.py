@@ -84,3 +84,20 @@ def test_batch_consistency(engine):
     allh = engine.hash_frames(frames)
     for i in (0, 17, 299):
         assert np.array_equal(engine.hash_frames(frames[i:i + 1])[0], allh[i])
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("h,w", [(64, 64), (270, 480), (131, 67), (200, 136), (16, 16), (17, 300)])
+def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
+    """Mode 1 = scalar fixed-point kernel, 2 = MFMA per-frame kernel + DCT kernel, 3 = fused MFMA + DCT kernel.
+    Odd widths exercise unaligned 16-byte loads and the end-of-buffer guard."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(1000 + mode + h * 7 + w)
+        frames = rng.integers(0, 256, size=(5, 16, h, w), dtype=np.uint8)
+        _check(eng, frames)
+    finally:
+        eng.close()

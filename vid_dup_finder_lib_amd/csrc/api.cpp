@@ -42,6 +42,11 @@ struct DeviceAxisTable {
     vdf::HostAxisTable host;
 };
 
+struct DeviceMfmaTable {
+    DevBuf operand, bias;
+    vdf::MfmaAxisTable host;
+};
+
 }  // namespace
 
 struct vdf_ctx {
@@ -60,12 +65,18 @@ struct vdf_ctx {
     // hash scratch
     DevBuf small, frames, out_hashes, out_dc, cos_table;
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
+    std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
+    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel
     std::vector<vdf_hit> host_hits;
 
     ~vdf_ctx()
     {
         for (auto &kv : axis_tables) {
             kv.second->start.release(); kv.second->size.release(); kv.second->w.release();
+            delete kv.second;
+        }
+        for (auto &kv : mfma_tables) {
+            kv.second->operand.release(); kv.second->bias.release();
             delete kv.second;
         }
         DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
@@ -221,6 +232,34 @@ DeviceAxisTable *axis_table(vdf_ctx *ctx, uint32_t in_size, hipStream_t stream, 
     return t;
 }
 
+DeviceMfmaTable *mfma_table(vdf_ctx *ctx, uint32_t in_size, bool vertical, hipStream_t stream, int *rc)
+{
+    const uint64_t key = (uint64_t)in_size * 2 + (vertical ? 1 : 0);
+    auto it = ctx->mfma_tables.find(key);
+    if (it != ctx->mfma_tables.end()) { *rc = VDF_OK; return it->second; }
+    DeviceMfmaTable *t = new DeviceMfmaTable();
+    if (!vdf::build_mfma_axis_table(in_size, vertical, t->host)) {
+        delete t;
+        *rc = fail(ctx, VDF_E_BAD_DIMS, "cannot build resize table");
+        return nullptr;
+    }
+    int r = VDF_OK;
+    if (t->host.ok) {
+        r = upload(ctx, t->operand, t->host.operand.data(), t->host.operand.size(), stream);
+        if (r == VDF_OK) r = upload(ctx, t->bias, t->host.bias.data(), t->host.bias.size() * 4, stream);
+        if (r == VDF_OK && hipStreamSynchronize(stream) != hipSuccess) r = fail(ctx, VDF_E_HIP, "table upload failed");
+    }
+    if (r != VDF_OK) {
+        t->operand.release(); t->bias.release();
+        delete t;
+        *rc = r;
+        return nullptr;
+    }
+    ctx->mfma_tables[key] = t;
+    *rc = VDF_OK;
+    return t;
+}
+
 vdf::ResizeAxisTable dev_view(const DeviceAxisTable *t)
 {
     vdf::ResizeAxisTable v{};
@@ -262,6 +301,39 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
     }
     const int need_h = (w != VDF_DCT_SIZE), need_v = (h != VDF_DCT_SIZE);
     int rc = VDF_OK;
+    const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
+    if (ctx->resize_mode != 1) {
+        // Resize on the matrix cores (exact i8 x i8 -> i32): small frames fuse the DCT into the same kernel.
+        DeviceMfmaTable *mh = mfma_table(ctx, w, false, stream, &rc);
+        if (rc) return rc;
+        DeviceMfmaTable *mv = mfma_table(ctx, h, true, stream, &rc);
+        if (rc) return rc;
+        if (mh->host.ok && mv->host.ok) {
+            vdf::MfmaResizeArgs a{};
+            a.bh = mh->operand.p;
+            a.av = mv->operand.p;
+            a.bias_h = mh->bias.as<int32_t>();
+            a.bias_v = mv->bias.as<int32_t>();
+            a.prec_h = mh->host.precision;
+            a.prec_v = mv->host.precision;
+            a.n_kt = mh->host.n_tiles;
+            a.n_rg = mv->host.n_tiles;
+            const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && a.n_rg <= 2);
+            if (fused) {
+                VDF_HIP(ctx, vdf::launch_resize_dct_fused(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
+                                                          ctx->cos_table.as<double>(), d_out, d_dc, stream));
+                return VDF_OK;
+            }
+            VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+            VDF_HIP(ctx, vdf::launch_resize_mfma_frames(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
+                                                        ctx->small.as<uint8_t>(), stream));
+            VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips,
+                                              ctx->cos_table.as<double>(), d_out, d_dc, stream));
+            return VDF_OK;
+        }
+        if (ctx->resize_mode != 0) return fail(ctx, VDF_E_BAD_DIMS, "coefficients do not fit the i8 split");
+    }
+    // scalar fixed-point fallback (any coefficient range)
     DeviceAxisTable *th = need_h ? axis_table(ctx, w, stream, &rc) : nullptr;
     if (rc) return rc;
     DeviceAxisTable *tv = need_v ? axis_table(ctx, h, stream, &rc) : nullptr;
@@ -271,7 +343,7 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         y_first = tv->host.start[0];
         tmp_rows = tv->host.start[VDF_DCT_SIZE - 1] + tv->host.size[VDF_DCT_SIZE - 1] - y_first;
     }
-    if ((size_t)tmp_rows * 16 > 64 * 1024) return fail(ctx, VDF_E_BAD_DIMS, "frame height above 4096 is not supported yet");
+    if ((size_t)tmp_rows * 16 > 64 * 1024) return fail(ctx, VDF_E_BAD_DIMS, "frame height above 4096 is not supported by the scalar resize kernel");
     VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
     VDF_HIP(ctx, vdf::launch_resize_generic(d_frames, n_clips, w, h, frame_stride, clip_stride, dev_view(th),
                                             dev_view(tv), need_h, need_v, y_first, tmp_rows,
@@ -311,6 +383,10 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     if (const char *s = std::getenv("VDF_ROWS_PER_LANE")) {
         int r = std::atoi(s);
         if (r == 1 || r == 2 || r == 4) ctx->tile_rows = 256u * (uint32_t)r;
+    }
+    if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
+        int m = std::atoi(s);
+        if (m >= 0 && m <= 3) ctx->resize_mode = m;
     }
     if (const char *s = std::getenv("VDF_CHUNK_COLS")) {
         long c = std::atol(s);

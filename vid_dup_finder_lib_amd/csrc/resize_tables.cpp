@@ -75,4 +75,48 @@ bool build_axis_table(uint32_t in_size, uint32_t out_size, HostAxisTable &t)
     return true;
 }
 
+bool build_mfma_axis_table(uint32_t in_size, bool vertical, MfmaAxisTable &t)
+{
+    t = MfmaAxisTable();
+    const uint32_t D = 16;
+    const int32_t n_tiles = (int32_t)((in_size + 63) / 64);
+    std::vector<int32_t> full((size_t)D * n_tiles * 64, 0);  // C[o][x], zero padded
+    int precision;
+    if (in_size == D) {
+        precision = 8;  // identity: (256 (p - 128) + 128 * 256 + 128) >> 8 == p
+        for (uint32_t o = 0; o < D; o++) full[(size_t)o * n_tiles * 64 + o] = 256;
+    } else {
+        HostAxisTable h;
+        if (!build_axis_table(in_size, D, h)) return false;
+        precision = h.precision;
+        for (uint32_t o = 0; o < D; o++)
+            for (int32_t k = 0; k < h.size[o]; k++)
+                full[(size_t)o * n_tiles * 64 + h.start[o] + k] = h.w[(size_t)o * h.window + k];
+    }
+    if (precision < 1) return false;
+    t.n_tiles = n_tiles;
+    t.precision = precision;
+    t.bias.assign(D, 0);
+    t.operand.assign((size_t)n_tiles * 2 * 64 * 16, 0);
+    t.ok = true;
+    for (uint32_t o = 0; o < D; o++) {
+        int64_t sum = 0;
+        for (int32_t x = 0; x < n_tiles * 64; x++) sum += full[(size_t)o * n_tiles * 64 + x];
+        t.bias[o] = (int32_t)((1 << (precision - 1)) + 128 * sum);
+    }
+    for (int32_t tile = 0; tile < n_tiles; tile++)
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 16; j++) {
+                const int g = l >> 4, o = l & 15;
+                const int pos = vertical ? 64 * tile + 16 * (j >> 2) + 4 * g + (j & 3) : 64 * tile + 16 * g + j;
+                const int32_t c = full[(size_t)o * n_tiles * 64 + pos];
+                int32_t lo = ((c + 128) & 255) - 128;  // c = 256 hi + lo, lo in [-128, 127]
+                int32_t hi = (c - lo) / 256;
+                if (hi < -128 || hi > 127) t.ok = false;
+                t.operand[(((size_t)tile * 2 + 0) * 64 + l) * 16 + j] = (int8_t)hi;
+                t.operand[(((size_t)tile * 2 + 1) * 64 + l) * 16 + j] = (int8_t)lo;
+            }
+    return true;
+}
+
 }  // namespace vdf

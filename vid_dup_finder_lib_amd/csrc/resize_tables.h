@@ -14,4 +14,21 @@ struct HostAxisTable {
 
 bool build_axis_table(uint32_t in_size, uint32_t out_size, HostAxisTable &t);
 
+// The same coefficients laid out as v_mfma_i32_16x16x64_i8 operands.  Each i16 coefficient c is split
+// c = 256 * hi + lo with lo in [-128, 127]; pixels are centred (p - 128) so both factors are signed i8 and
+// bias = 2^(precision-1) + 128 * sum(c) restores the unsigned sum exactly.
+struct MfmaAxisTable {
+    // n_tiles x {hi, lo} x 64 lanes x 16 bytes.
+    //   horizontal (B operand): byte j of lane l in tile kt  = C[o = l & 15][x = 64 kt + 16 (l >> 4) + j]
+    //   vertical   (A operand): byte j = 4 m + r of lane l in group rg = C[oy = l & 15][y = 64 rg + 16 m + 4 (l >> 4) + r]
+    std::vector<int8_t> operand;
+    std::vector<int32_t> bias;  // [16]
+    int32_t n_tiles = 0;
+    int32_t precision = 0;
+    bool ok = false;            // false if some hi part does not fit i8 (caller falls back to the generic kernel)
+};
+
+// in_size == 16 yields the identity (the reference copies when no resize is needed).
+bool build_mfma_axis_table(uint32_t in_size, bool vertical, MfmaAxisTable &t);
+
 }  // namespace vdf

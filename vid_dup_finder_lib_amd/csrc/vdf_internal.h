@@ -58,6 +58,18 @@ struct ResizeAxisTable {  // device pointers, one axis
 hipError_t launch_resize_generic(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                  size_t clip_stride, ResizeAxisTable th, ResizeAxisTable tv, int need_h, int need_v,
                                  int32_t y_first, int32_t tmp_rows, uint8_t *small, hipStream_t stream);
+struct MfmaResizeArgs {  // device pointers to the MFMA-layout tables (resize_tables.h: MfmaAxisTable)
+    const void *bh, *av;
+    const int32_t *bias_h, *bias_v;
+    int32_t prec_h, prec_v, n_kt, n_rg;
+};
+hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                   size_t clip_stride, const uint8_t *buf_end, const MfmaResizeArgs &a,
+                                   const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare,
+                                   hipStream_t stream);
+hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
+                                     size_t frame_stride, size_t clip_stride, const uint8_t *buf_end,
+                                     const MfmaResizeArgs &a, uint8_t *small, hipStream_t stream);
 hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream);
 
