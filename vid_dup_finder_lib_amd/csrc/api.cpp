@@ -285,9 +285,10 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
     if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->cos_table.p) {
-        double tab[16 * 16];
+        double tab[16 * 16 + 17];  // [k][n] matrix, then the 17 magnitudes cos(m pi / 32)
         for (int k = 0; k < 16; k++)
             for (int n = 0; n < 16; n++) tab[k * 16 + n] = std::cos(M_PI * (double)k * ((double)n + 0.5) / 16.0);
+        for (int m = 0; m < 17; m++) tab[256 + m] = std::cos(M_PI * (double)m / 32.0);
         int rc = upload(ctx, ctx->cos_table, tab, sizeof tab, stream);
         if (rc) return rc;
         VDF_HIP(ctx, hipStreamSynchronize(stream));

@@ -70,85 +70,139 @@ __global__ __launch_bounds__(256) void resize_generic_kernel(
     }
 }
 
-// 16-point unnormalised DCT-II pruned to outputs 0..9:  X[k] = sum_n v[n] cos(pi k (n + 1/2) / 16).
-// One even/odd split: cos(pi k (15-n+1/2)/16) = (-1)^k cos(pi k (n+1/2)/16).
-__device__ __forceinline__ void dct16_pruned(const double (&v)[16], double (&out)[10], const_f64_ptr cosv)
+// 16-point unnormalised DCT-II pruned to outputs 0..9:  X[k] = sum_n v[n] cos(pi k (2n + 1) / 32).
+// One even/odd split: cos(pi k (2(15-n)+1)/32) = (-1)^k cos(pi k (2n+1)/32).  Every matrix entry is
+// +-cos(m pi / 32) for m = 0..16, so the kernel keeps just those 17 magnitudes (wave-uniform, SGPR pairs)
+// and folds the sign into the FMA's negate modifier at compile time; 80 distinct SGPR-pair constants
+// would not fit the scalar register file.
+struct CosRef { int m; int sign; };
+__device__ constexpr CosRef cos_ref(int k, int n)
+{
+    int a = (k * (2 * n + 1)) % 64;  // angle in units of pi/32, period 64
+    int sign = 1;
+    if (a > 32) a = 64 - a;          // cos(2 pi - x) = cos x
+    if (a > 16) { a = 32 - a; sign = -1; }  // cos(pi - x) = -cos x
+    return CosRef{a, sign};
+}
+
+template <int K, int N>
+__device__ __forceinline__ double dct_term(double x, const double (&cm)[17], double acc)
+{
+    constexpr CosRef r = cos_ref(K, N);
+    if constexpr (r.m == 16) return acc;  // cos(pi/2) = 0
+    else if constexpr (r.sign > 0) return fma(x, cm[r.m], acc);
+    else return fma(-x, cm[r.m], acc);
+}
+
+template <int K>
+__device__ __forceinline__ double dct_out(const double (&u)[8], const double (&d)[8], const double (&cm)[17])
+{
+    const double (&x)[8] = (K & 1) ? d : u;
+    double acc = 0.0;
+    acc = dct_term<K, 0>(x[0], cm, acc); acc = dct_term<K, 1>(x[1], cm, acc);
+    acc = dct_term<K, 2>(x[2], cm, acc); acc = dct_term<K, 3>(x[3], cm, acc);
+    acc = dct_term<K, 4>(x[4], cm, acc); acc = dct_term<K, 5>(x[5], cm, acc);
+    acc = dct_term<K, 6>(x[6], cm, acc); acc = dct_term<K, 7>(x[7], cm, acc);
+    return acc;
+}
+
+__device__ __forceinline__ void dct16_pruned(const double (&v)[16], double (&out)[10], const double (&cm)[17])
 {
     double u[8], d[8];
 #pragma unroll
     for (int n = 0; n < 8; n++) { u[n] = v[n] + v[15 - n]; d[n] = v[n] - v[15 - n]; }
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        double acc = 0.0;
-#pragma unroll
-        for (int n = 0; n < 8; n++) acc = fma((k & 1) ? d[n] : u[n], cosv[k * 16 + n], acc);
-        out[k] = acc;
-    }
+    out[0] = dct_out<0>(u, d, cm); out[1] = dct_out<1>(u, d, cm); out[2] = dct_out<2>(u, d, cm);
+    out[3] = dct_out<3>(u, d, cm); out[4] = dct_out<4>(u, d, cm); out[5] = dct_out<5>(u, d, cm);
+    out[6] = dct_out<6>(u, d, cm); out[7] = dct_out<7>(u, d, cm); out[8] = dct_out<8>(u, d, cm);
+    out[9] = dct_out<9>(u, d, cm);
 }
 
 constexpr int kPadY = 17;  // [t][kx][y] rows padded to 17 doubles
 
 struct DctShared {
-    double b[16 * 10 * kPadY];  // pass-x output  [t][kx][y]
-    double c[16 * 100];         // pass-y output  [t][kx][ky]
-    double cosv[10 * 16];       // cos[kt][t] for the per-lane kt of the last pass
+    double b[16 * 10 * kPadY];  // first-pass output [t][k1][n2]; the second pass overwrites row (t, k1) in place with [k2]
+    uint32_t words[32];         // the 1024 hash bits, OR-assembled from per-kt ballots
     uint32_t dc[4];
-    __attribute__((aligned(16))) uint8_t cube[16 * 256];  // resized clip [t][y][x] u8
+    // Resized clip as CENTRED bytes (pix - 128 as i8), one dword per (t, g, x): byte r = pixel (y = 4 g + r, x).
+    // This is exactly what a lane of the vertical resize MFMA holds (C layout), so a frame is stored with one
+    // conflict-free ds_write_b32 per lane, and the thread (t, x) of the first DCT pass finds its 16 y-values
+    // in 4 dwords.
+    __attribute__((aligned(16))) uint32_t cube[16 * 64];
 };
 
-// 256 threads: 3-D DCT-II of the u8 cube in sh.cube (pix - 128, f64), sign test, ballot pack.
-// Caller has filled sh.cube and sh.cosv and synchronised.
+// 256 threads: 3-D DCT-II of the clip in sh.cube (f64), sign test, ballot pack.  Pass order y, x, t (the
+// reference's order, raw_dct_ops.rs:118-132).  Caller has filled sh.cube and sh.cosv and synchronised.
 __device__ __forceinline__ void dct_hash_block(DctShared &sh, const_f64_ptr cosv, size_t clip,
                                                uint64_t *__restrict__ out_hashes, uint32_t *__restrict__ out_dontcare)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // pass x: thread (t, y) owns one 16-pixel row (16 contiguous bytes)
+    double cm[17];  // cos(m pi / 32), wave-uniform (scalar loads)
+#pragma unroll
+    for (int m = 0; m < 17; m++) cm[m] = cosv[256 + m];
+    // pass y: thread (t, x) owns one 16-pixel column
     {
-        const uint32_t t = tid >> 4, y = tid & 15;
-        const uint4 px = *reinterpret_cast<const uint4 *>(sh.cube + tid * 16);
-        const uint32_t wsrc[4] = {px.x, px.y, px.z, px.w};
+        const uint32_t t = tid >> 4, x = tid & 15;
         double v[16], o[10];
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = (double)(int32_t)((wsrc[i >> 2] >> ((i & 3) * 8)) & 255u) - 128.0;
-        dct16_pruned(v, o, cosv);
+        for (int g = 0; g < 4; g++) {
+            const int32_t w = (int32_t)sh.cube[t * 64 + g * 16 + x];
 #pragma unroll
-        for (int kx = 0; kx < 10; kx++) sh.b[(t * 10 + kx) * kPadY + y] = o[kx];
+            for (int r = 0; r < 4; r++) v[4 * g + r] = (double)((w << (24 - 8 * r)) >> 24);  // sign-extending byte extract
+        }
+        dct16_pruned(v, o, cm);
+#pragma unroll
+        for (int ky = 0; ky < 10; ky++) sh.b[(t * 10 + ky) * kPadY + x] = o[ky];
     }
     __syncthreads();
-    // pass y: thread (t, kx), 160 lines
+    // pass x: thread (t, ky), 160 lines
     if (tid < 160) {
         double v[16], o[10];
 #pragma unroll
-        for (int y = 0; y < 16; y++) v[y] = sh.b[tid * kPadY + y];
-        dct16_pruned(v, o, cosv);
+        for (int x = 0; x < 16; x++) v[x] = sh.b[tid * kPadY + x];
+        dct16_pruned(v, o, cm);
 #pragma unroll
-        for (int ky = 0; ky < 10; ky++) sh.c[tid * 10 + ky] = o[ky];
+        for (int kx = 0; kx < 10; kx++) sh.b[tid * kPadY + kx] = o[kx];  // own row: all reads are done
     }
     __syncthreads();
-    // pass t + sign + pack: lane l of wave-word w computes bit i = 64 w + l = 100 kt + 10 kx + ky
+    // pass t + sign + pack: thread rem = 10 kx + ky (100 threads) reads its 16 t-values once and produces the ten
+    // kt outputs; the ballot of output kt over wave w is the 64 (or 36) hash bits starting at bit 100 kt + 64 w
+    // (dct_3d.rs:55-66: bit i = 100 kt + 10 kx + ky), OR-ed into the LDS words by lane kt of the wave.
     uint32_t dc = 0;
+    if (wave < 2) {
+        const uint32_t rem = tid;  // < 128; lanes with rem >= 100 idle
+        const bool live = rem < 100;
+        const uint32_t kx = rem / 10, ky = rem - kx * 10;
+        const uint32_t at = live ? ky * kPadY + kx : 0;
+        double v[16], o[10];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t word = wave + 4 * q;
-        const uint32_t i = word * 64 + lane;
-        double coef = 0.0;
-        if (i < 1000) {
-            const uint32_t kt = i / 100, rem = i - kt * 100;  // rem = 10 kx + ky
+        for (int t = 0; t < 16; t++) v[t] = sh.b[t * 10 * kPadY + at];
+        dct16_pruned(v, o, cm);
+        unsigned long long piece = 0;
 #pragma unroll
-            for (int t = 0; t < 16; t++) coef = fma(sh.c[t * 100 + rem], sh.cosv[kt * 16 + t], coef);
+        for (int kt = 0; kt < 10; kt++) {
+            const unsigned long long bits = __builtin_amdgcn_ballot_w64(live && o[kt] > 0.0);  // 0.0 and NaN -> 0
+            const unsigned long long tiny = __builtin_amdgcn_ballot_w64(live && fabs(o[kt]) < 1e-6);
+            dc += (uint32_t)__builtin_popcountll(tiny);
+            if (lane == (uint32_t)kt) piece = bits;
         }
-        const unsigned long long bits = __builtin_amdgcn_ballot_w64(coef > 0.0);  // 0.0 and NaN -> 0
-        const unsigned long long tiny = __builtin_amdgcn_ballot_w64(i < 1000 && fabs(coef) < 1e-6);
-        dc += (uint32_t)__builtin_popcountll(tiny);
-        if (lane == 0) out_hashes[clip * 16 + word] = bits;
-    }
-    if (out_dontcare) {
+        if (lane < 10) {
+            const uint32_t off = 100u * lane + 64u * wave, wi = off >> 5, sh_l = off & 31u;
+            const uint32_t lo = (uint32_t)piece, hi = (uint32_t)(piece >> 32);
+            atomicOr(&sh.words[wi], lo << sh_l);
+            atomicOr(&sh.words[wi + 1], (hi << sh_l) | (sh_l ? lo >> (32u - sh_l) : 0u));
+            if (sh_l && wi + 2 < 32) atomicOr(&sh.words[wi + 2], hi >> (32u - sh_l));
+        }
         if (lane == 0) sh.dc[wave] = dc;
-        __syncthreads();
-        if (tid == 0) out_dontcare[clip] = sh.dc[0] + sh.dc[1] + sh.dc[2] + sh.dc[3];
     }
+    __syncthreads();
+    if (tid < 16) {
+        const unsigned long long w = (unsigned long long)sh.words[2 * tid] | ((unsigned long long)sh.words[2 * tid + 1] << 32);
+        out_hashes[clip * 16 + tid] = w;
+    }
+    if (out_dontcare && tid == 0) out_dontcare[clip] = sh.dc[0] + sh.dc[1];
 }
 
+// 16 x 16 x 16 u8 cubes (row-major frames) -> hashes.  The cube is re-laid into sh.cube's dword layout.
 __global__ __launch_bounds__(256) void dct_hash_kernel(const uint8_t *__restrict__ small, size_t clip_stride,
                                                        size_t frame_stride, const double *__restrict__ cos_table,
                                                        uint64_t *__restrict__ out_hashes,
@@ -157,11 +211,21 @@ __global__ __launch_bounds__(256) void dct_hash_kernel(const uint8_t *__restrict
     __shared__ DctShared sh;
     const size_t clip = blockIdx.x;
     const uint32_t tid = threadIdx.x;
-    if (tid < 160) sh.cosv[tid] = cos_table[tid];
+    if (tid < 32) sh.words[tid] = 0u;
     {
-        const uint32_t t = tid >> 4, y = tid & 15;
-        *reinterpret_cast<uint4 *>(sh.cube + tid * 16) =
-            *reinterpret_cast<const uint4 *>(small + clip * clip_stride + (size_t)t * frame_stride + y * 16);
+        // thread (t, g, xq): rows 4g..4g+3, columns 4xq..4xq+3 of frame t -> a 4x4 byte transpose in registers
+        const uint32_t t = tid >> 4, g = (tid >> 2) & 3, xq = tid & 3;
+        const uint8_t *src = small + clip * clip_stride + (size_t)t * frame_stride + (4 * g) * 16 + 4 * xq;
+        uint32_t row[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) row[r] = *reinterpret_cast<const uint32_t *>(src + r * 16) ^ 0x80808080u;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) w |= ((row[r] >> (8 * c)) & 255u) << (8 * r);
+            sh.cube[t * 64 + g * 16 + 4 * xq + c] = w;
+        }
     }
     __syncthreads();
     dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
@@ -190,9 +254,10 @@ struct MfmaResizeTables {
     int32_t prec_h, prec_v, n_kt, n_rg;
 };
 
+template <bool CAREFUL>
 __device__ __forceinline__ v4i load_pixels16(const uint8_t *p, const uint8_t *buf_end)
 {
-    if (p + 16 <= buf_end) {
+    if (!CAREFUL || p + 16 <= buf_end) {
         const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(p);
         v4i r = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
         return r;
@@ -217,6 +282,8 @@ __device__ __forceinline__ uint32_t finalize4(v4i hi, v4i lo, int prec)
 }
 
 // Row groups rg_begin, rg_begin + rg_step, ... of one frame; accumulates the vertical partial sums.
+// CAREFUL = this frame's 16-byte loads may reach past the end of the caller's buffer (last frame only).
+template <bool CAREFUL>
 __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
                                                   const uint8_t *buf_end, const MfmaResizeTables &T, int rg_begin,
                                                   int rg_step, v4i &acc_vh, v4i &acc_vl)
@@ -234,7 +301,7 @@ __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ sr
             for (int m = 0; m < 4; m++) {
                 const uint32_t row = 64u * rg + 16u * m + r16;
                 v4i a = {0, 0, 0, 0};
-                if (row < H && x < W) a = load_pixels16(src + (size_t)row * W + x, buf_end);
+                if (row < H && x < W) a = load_pixels16<CAREFUL>(src + (size_t)row * W + x, buf_end);
                 a ^= (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
                 ah[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah[m], 0, 0, 0);
                 al[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al[m], 0, 0, 0);
@@ -250,6 +317,9 @@ __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ sr
 
 // Small frames: one workgroup per clip, one wave per frame (4 frames each), resized frames go to LDS and the
 // DCT runs in the same kernel: HBM traffic = the frames once + 128 B of hash.
+// ONE_TILE (W, H <= 64): the wave's 16 pixel loads (4 frames x 4 row blocks, 16 KB) are all issued before the
+// first MFMA so a workgroup keeps its whole 64 KB clip in flight; tables stay in registers.
+template <bool ONE_TILE>
 __global__ __launch_bounds__(256) void resize_dct_hash_fused_kernel(
     const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
     const uint8_t *buf_end, MfmaResizeTables T, const double *__restrict__ cos_table,
@@ -258,18 +328,55 @@ __global__ __launch_bounds__(256) void resize_dct_hash_fused_kernel(
     __shared__ DctShared sh;
     const size_t clip = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-    if (tid < 160) sh.cosv[tid] = cos_table[tid];
+    if (tid < 32) sh.words[tid] = 0u;
+    const uint8_t *clip_base = frames + clip * clip_stride;
+    // only the last frames of the buffer can see a 16-byte load cross its end (wave-uniform test)
+    const bool careful = clip_base + 15 * frame_stride + (size_t)W * H + 64 > buf_end;
     v4i bias_v;
 #pragma unroll
     for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    if (ONE_TILE && !careful) {
+        const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+        v4i px[4][4];
+        const bool col_ok = 16u * g < W;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t f = wave + 4 * q;
-        v4i vh = {0, 0, 0, 0}, vl = bias_v;
-        resize_row_groups(frames + clip * clip_stride + (size_t)f * frame_stride, W, H, buf_end, T, 0, 1, vh, vl);
-        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;  // back to plain u8: out[oy = 4 g + r][x = r16]
+        for (int q = 0; q < 4; q++) {
+            const uint8_t *src = clip_base + (size_t)(wave + 4 * q) * frame_stride;
 #pragma unroll
-        for (int r = 0; r < 4; r++) sh.cube[f * 256 + (4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+            for (int m = 0; m < 4; m++) {
+                const uint32_t row = 16u * m + r16;
+                px[q][m] = (v4i){0, 0, 0, 0};
+                if (row < H && col_ok) px[q][m] = load_pixels16<false>(src + (size_t)row * W + 16u * g, buf_end);
+            }
+        }
+        const v4i bh = T.bh[lane], bl = T.bh[64 + lane], avh = T.av[lane], avl = T.av[64 + lane];
+        const int32_t bias_h = T.bias_h[r16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4i a = px[q][m] ^ x80;
+                v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al, 0, 0, 0);
+                b[m] = (int)finalize4(ah, al, T.prec_h);
+            }
+            v4i vh = {0, 0, 0, 0}, vl = bias_v;
+            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, vh, 0, 0, 0);
+            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, vl, 0, 0, 0);
+            // centred bytes of out[oy = 4 g + r][x = r16], r = 0..3: one dword per lane
+            sh.cube[(wave + 4 * q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+        }
+    } else {
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const uint32_t f = wave + 4 * q;
+            v4i vh = {0, 0, 0, 0}, vl = bias_v;
+            if (careful) resize_row_groups<true>(clip_base + (size_t)f * frame_stride, W, H, buf_end, T, 0, 1, vh, vl);
+            else resize_row_groups<false>(clip_base + (size_t)f * frame_stride, W, H, buf_end, T, 0, 1, vh, vl);
+            sh.cube[f * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+        }
     }
     __syncthreads();
     dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
@@ -287,7 +394,9 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_kernel(const uint8_t *_
     const uint32_t f = blockIdx.x & 15;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-    resize_row_groups(frames + clip * clip_stride + (size_t)f * frame_stride, W, H, buf_end, T, (int)wave, 4, vh, vl);
+    const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride;
+    if (src + (size_t)W * H + 64 > buf_end) resize_row_groups<true>(src, W, H, buf_end, T, (int)wave, 4, vh, vl);
+    else resize_row_groups<false>(src, W, H, buf_end, T, (int)wave, 4, vh, vl);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
@@ -347,8 +456,13 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
                                    hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_dct_hash_fused_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w, h,
-                       frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes, out_dontcare);
+    if (a.n_kt == 1 && a.n_rg == 1)
+        hipLaunchKernelGGL(resize_dct_hash_fused_kernel<true>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w,
+                           h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes, out_dontcare);
+    else
+        hipLaunchKernelGGL(resize_dct_hash_fused_kernel<false>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames,
+                           w, h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes,
+                           out_dontcare);
     return hipGetLastError();
 }
 
