@@ -1,0 +1,84 @@
+"""BASELINE.json sizes on the GPU, checked through size-independent properties (the oracle would take hours):
+planted-duplicate recovery, idempotence, shard-invariance, and oracle agreement on a window of rows."""
+import numpy as np
+import pytest
+import torch
+
+import hashgen as hg
+from oracle import vdf_oracle as orc
+from vid_dup_finder_lib_amd import engine as ve
+
+pytestmark = pytest.mark.gpu
+
+
+def _planted(n, seed, every=997):
+    rng = np.random.default_rng(seed)
+    words = hg.random_hashes(rng, n)
+    truth = {}
+    for s in range(0, n - 4, every):
+        k = int(rng.integers(0, 300))  # well inside tolerance 350
+        bits = np.unpackbits(words[s].view(np.uint8), bitorder="little")
+        bits[rng.choice(1024, size=k, replace=False)] ^= 1
+        words[s + 1] = np.packbits(bits, bitorder="little").view(np.uint64)
+        truth[s] = s + 1
+    return words, truth
+
+
+def test_one_million_all_pairs_planted_recovery(engine):
+    """configs[1]: 1 M random hashes, all durations 0, tolerance 350."""
+    n = 1_000_000
+    words, truth = _planted(n, 20250613)
+    d_w = torch.from_numpy(words.view(np.int64)).cuda()
+    d_d = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hits, n_hits, overflow = engine.search_self_device(d_w.data_ptr(), d_d.data_ptr(), n, 350)
+    st = engine.last_stats()
+    assert overflow == 0xFFFFFFFF and st["pairs"] == n * (n - 1) // 2 and st["pairs_computed"] >= st["pairs"]
+    got = {(int(a), int(b)) for a, b in hits}
+    assert {(s, t) for s, t in truth.items()} <= got  # every planted pair found
+    # every reported hit really is within tolerance (checked with the oracle's hamming) and i < j
+    for a, b in list(got)[:5000]:
+        assert a < b and orc.hamming(words[a], words[b]) <= 350
+    # random 1000-bit hashes are ~500 +- 16 apart: nothing but the planted pairs should match
+    assert len(got) == len(truth)
+    groups = ve.finish_self(ve.replay_self(n, hits))
+    assert sorted(map(tuple, groups)) == sorted((t, s) for s, t in truth.items())
+    # shard invariance: the union of 3 shards' hits equals the single-shard hit list
+    parts = [engine.search_self_device(d_w.data_ptr(), d_d.data_ptr(), n, 350, shard_index=r, shard_count=3)[0] for r in range(3)]
+    merged = np.concatenate(parts)
+    merged = merged[np.lexsort((merged[:, 1], merged[:, 0]))]
+    assert np.array_equal(merged, hits)
+    # oracle agreement on a band of rows against the whole database (row_begin/row_end restrict the targets)
+    lo, hi = 499_000, 499_064
+    band, _, _ = engine.search_self_device(d_w.data_ptr(), d_d.data_ptr(), n, 470, row_begin=lo, row_end=hi)
+    want = []
+    for i in range(lo, hi):
+        dist = np.unpackbits((words[i + 1:] ^ words[i]).view(np.uint8), axis=1).sum(axis=1)
+        want += [(i, i + 1 + int(j)) for j in np.nonzero(dist <= 470)[0]]
+    assert [tuple(map(int, h)) for h in band] == want and len(want) > 0
+
+
+def test_hundred_thousand_frame_stacks(engine):
+    """configs[2]: 100 k clips of 16 x 64x64: idempotence + oracle agreement on a sample + batch invariance."""
+    n = 100_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20250617)
+    frames = torch.randint(0, 256, (n, 16, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+    out1 = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    out2 = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    dc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    engine.hash_frames_device(frames.data_ptr(), n, 16, 64, 64, out1.data_ptr(), d_dontcare=dc.data_ptr())
+    engine.hash_frames_device(frames.data_ptr(), n, 16, 64, 64, out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2)
+    idx = np.random.default_rng(0).choice(n, size=64, replace=False)
+    sample = frames[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want, coefs = orc.hash_clips_with_coefs(sample)
+    got = out1[torch.from_numpy(idx).cuda()].cpu().numpy().view(np.uint64)
+    care = np.abs(coefs) >= 1e-6
+    gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(64, 1024)[:, :1000]
+    wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(64, 1024)[:, :1000]
+    assert not ((gb != wb) & care).any()
+    assert int(dc.sum().item()) < n // 100  # near-zero coefficients are rare on iid pixels (~7e-4 of clips)
+    # hashes of iid clips are ~uniform: mean popcount close to 500
+    pop = np.unpackbits(out1[:2000].cpu().numpy().view(np.uint8), axis=1).sum(axis=1).mean()
+    assert 480 < pop < 520
