@@ -30,6 +30,7 @@ def test_one_million_all_pairs_planted_recovery(engine):
     words, truth = _planted(n, 20250613)
     d_w = torch.from_numpy(words.view(np.int64)).cuda()
     d_d = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     hits, n_hits, overflow = engine.search_self_device(d_w.data_ptr(), d_d.data_ptr(), n, 350)
     st = engine.last_stats()
     assert overflow == 0xFFFFFFFF and st["pairs"] == n * (n - 1) // 2 and st["pairs_computed"] >= st["pairs"]
@@ -66,6 +67,7 @@ def test_hundred_thousand_frame_stacks(engine):
     out1 = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
     out2 = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
     dc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # inputs/outputs were produced on torch's stream; the library runs on its own
     engine.hash_frames_device(frames.data_ptr(), n, 16, 64, 64, out1.data_ptr(), d_dontcare=dc.data_ptr())
     engine.hash_frames_device(frames.data_ptr(), n, 16, 64, 64, out2.data_ptr())
     torch.cuda.synchronize()

@@ -37,7 +37,11 @@ def groups_to_arrays(g: VdfGroups):
 
 
 class Engine:
-    """One GPU context.  `device` defaults to LOCAL_RANK (one process per GPU) or 0."""
+    """One GPU context.  `device` defaults to LOCAL_RANK (one process per GPU) or 0.
+
+    *_device methods take raw device pointers and a hipStream_t handle.  stream=0 means the context's own
+    non-blocking stream, which does NOT order against work queued elsewhere (e.g. torch's current stream): either
+    pass the stream that produced the buffers, or synchronise before the call."""
 
     def __init__(self, device: Optional[int] = None):
         self.lib = _capi.load()
