@@ -1,0 +1,88 @@
+// Driver for the C++ host mirror (vid_dup_finder_lib_amd/host/vdf.hpp): reads like the reference's own tests.
+//   selftest                      no GPU: Path ordering, MatchGroup contract, Hamming axioms
+//   search <file> <tolerance>     GPU: prints one group per line (duplicate paths, tab separated)
+//   refs <file> <n_ref> <tol>     GPU: first n_ref entries are the references
+// File format: u64 n, then n x {16 x u64 hash, u32 duration, u32 path_len, path bytes}.
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "../../vid_dup_finder_lib_amd/host/vdf.hpp"
+
+static std::vector<vdf::VideoHash> read_file(const char *path)
+{
+    std::ifstream f(path, std::ios::binary);
+    uint64_t n = 0;
+    f.read((char *)&n, 8);
+    std::vector<vdf::VideoHash> out;
+    for (uint64_t i = 0; i < n; i++) {
+        std::array<uint64_t, 16> h;
+        uint32_t d, len;
+        f.read((char *)h.data(), 128);
+        f.read((char *)&d, 4);
+        f.read((char *)&len, 4);
+        std::string p(len, '\0');
+        f.read(p.data(), len);
+        out.emplace_back(h, p, d);
+    }
+    return out;
+}
+
+static void print_groups(const std::vector<vdf::MatchGroup> &gs)
+{
+    for (const auto &g : gs) {
+        std::cout << (g.reference() ? *g.reference() : std::string("-"));
+        for (const auto &p : g.duplicates()) std::cout << '\t' << p;
+        std::cout << '\n';
+    }
+}
+
+static int selftest()
+{
+    using vdf::PathKey;
+    assert(PathKey("a/b") < PathKey("a.b"));               // component-wise, not bytewise
+    assert(PathKey("a//b/") == PathKey("a/b") && PathKey("a/./b") == PathKey("a/b"));
+    assert(PathKey("/a") < PathKey("a") && PathKey("./a") < PathKey("../a") && PathKey("../a") < PathKey("a"));
+    // matches/match_group.rs
+    bool threw = false;
+    try { vdf::MatchGroup::make({"a"}); } catch (const vdf::TooFewEntries &) { threw = true; }
+    assert(threw);
+    threw = false;
+    try { vdf::MatchGroup::make_with_reference("r", {}); } catch (const vdf::TooFewEntries &) { threw = true; }
+    assert(threw);
+    auto g = vdf::MatchGroup::make({"a", "b", "c"});
+    assert(g.len() == 3 && !g.reference() && g.dup_combinations().size() == 3);
+    auto r = vdf::MatchGroup::make_with_reference("ref", {"x", "y"});
+    assert(r.contained_paths() == (std::vector<std::string>{"x", "y", "ref"}) && r.dup_combinations().size() == 2);
+    // video_hash.rs:325-371
+    auto e = vdf::VideoHash::empty_hash(""), f = vdf::VideoHash::full_hash("");
+    assert(e.hamming_distance(e) == 0 && f.hamming_distance(f) == 0 && e.hamming_distance(f) == 1024);
+    assert(vdf::VideoHash() == vdf::VideoHash::empty_hash(""));
+    assert(vdf_tolerance_int(0.35) == 350 && vdf_tolerance_int(0.3) == 300);
+    // too few frames is rejected before any device work (video_hash.rs:53,61)
+    threw = false;
+    try { vdf::VideoHash::from_frames({}, 16, 16, "p", 1); } catch (const vdf::Error &err) { threw = err.kind == vdf::Error::NotEnoughFrames; }
+    assert(threw);
+    std::puts("selftest ok");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 2 && !std::strcmp(argv[1], "selftest")) return selftest();
+    if (argc >= 4 && !std::strcmp(argv[1], "search")) {
+        print_groups(vdf::search(read_file(argv[2]), std::atof(argv[3])));
+        return 0;
+    }
+    if (argc >= 5 && !std::strcmp(argv[1], "refs")) {
+        auto all = read_file(argv[2]);
+        const size_t nr = std::strtoul(argv[3], nullptr, 10);
+        std::vector<vdf::VideoHash> refs(all.begin(), all.begin() + nr), news(all.begin() + nr, all.end());
+        print_groups(vdf::search_with_references(refs, news, std::atof(argv[4])));
+        return 0;
+    }
+    std::fprintf(stderr, "usage: selftest | search <file> <tol> | refs <file> <n_ref> <tol>\n");
+    return 2;
+}

@@ -1,0 +1,246 @@
+// vdf.hpp -- C++ host mirror of the reference crate's public surface for the hot path, over the C ABI
+// (include/vdf.h).  Header-only; link with libvdf_hip.so.
+//
+// The reference is Rust and this image has no Rust toolchain, so this is the compiled-language host side above
+// the boundary: same names, argument meaning and error behaviour as
+//   vid_dup_finder_lib/src/lib.rs:132-140            VideoHash, MatchGroup, search, search_with_references, Error
+//   vid_dup_finder_lib/src/video_hashing/video_hash.rs:26-32,45-73,176-192
+//   vid_dup_finder_lib/src/video_hashing/video_dup_finder.rs:7-46
+//   vid_dup_finder_lib/src/video_hashing/matches/match_group.rs:10-105
+// What stays on the host (it needs paths): Search::sort (search_algorithm.rs:55-61) including Rust's
+// component-wise PathBuf ordering; MatchGroup assembly from the index lists the library returns.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <numeric>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vdf.h"
+
+namespace vdf {
+
+// ---- Error (video_hashing/mod.rs:17-28) -------------------------------------------------------------------
+struct Error : std::runtime_error {
+    enum Kind { NotVideo, VidProc, NotEnoughFrames, Device } kind;
+    Error(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+    static Error not_enough_frames() { return Error(NotEnoughFrames, "Could not extract enough frames"); }
+    static Error vid_proc(const std::string &m) { return Error(VidProc, "Video processing error: " + m); }
+};
+struct TooFewEntries : std::runtime_error {  // match_group.rs:15-16
+    TooFewEntries() : std::runtime_error("too few entries") {}
+};
+
+// ---- one GPU context -------------------------------------------------------------------------------------
+class Context {
+public:
+    explicit Context(int device = 0)
+    {
+        vdf_ctx *c = nullptr;
+        if (vdf_ctx_create(device, &c) != VDF_OK) throw Error(Error::Device, vdf_last_error(nullptr));
+        ctx_.reset(c, vdf_ctx_destroy);
+    }
+    vdf_ctx *get() const { return ctx_.get(); }
+    static Context &default_context()
+    {
+        static Context c(0);
+        return c;
+    }
+
+private:
+    std::shared_ptr<vdf_ctx> ctx_;
+};
+
+// ---- Rust `PathBuf: Ord`: std::path compares Components, not bytes ------------------------------------------
+// RootDir < CurDir < ParentDir < Normal(bytes); repeated '/' and inner "." are not components.
+struct PathKey {
+    std::vector<std::pair<int, std::string>> comps;
+    explicit PathKey(const std::string &p)
+    {
+        if (!p.empty() && p[0] == '/') comps.emplace_back(1, "");
+        else if (p == "." || p.rfind("./", 0) == 0) comps.emplace_back(2, "");
+        size_t i = 0;
+        while (i <= p.size()) {
+            size_t j = p.find('/', i);
+            if (j == std::string::npos) j = p.size();
+            const std::string part = p.substr(i, j - i);
+            if (!part.empty() && part != ".") comps.emplace_back(part == ".." ? 3 : 4, part == ".." ? "" : part);
+            i = j + 1;
+        }
+    }
+    bool operator<(const PathKey &o) const { return comps < o.comps; }
+    bool operator==(const PathKey &o) const { return comps == o.comps; }
+};
+
+// ---- VideoHash (video_hash.rs:26-32) ----------------------------------------------------------------------
+class VideoHash {
+public:
+    VideoHash() : hash_{}, duration_(0) {}  // Default, video_hash.rs:34-42
+    VideoHash(const std::array<uint64_t, VDF_HASH_WORDS> &h, std::string src_path, uint32_t duration)
+        : hash_(h), src_path_(std::move(src_path)), duration_(duration) {}
+
+    // video_hash.rs:45-73.  frames: equal-size gray u8 frames (row-major, w x h); fewer than 16 (or none) ->
+    // NotEnoughFrames; only the first 16 are used (dct_3d.rs:25).
+    static VideoHash from_frames(const std::vector<const uint8_t *> &frames, uint32_t w, uint32_t h,
+                                 const std::string &src_path, uint32_t duration, Context *ctx_opt = nullptr)
+    {
+        if (frames.size() < VDF_DCT_SIZE) throw Error::not_enough_frames();
+        Context &ctx = ctx_opt ? *ctx_opt : Context::default_context();
+        std::vector<uint8_t> packed((size_t)VDF_DCT_SIZE * w * h);
+        for (size_t f = 0; f < VDF_DCT_SIZE; f++) std::copy(frames[f], frames[f] + (size_t)w * h, packed.begin() + f * (size_t)w * h);
+        std::array<uint64_t, VDF_HASH_WORDS> words{};
+        const int rc = vdf_hash_frames_u8(ctx.get(), packed.data(), 1, VDF_DCT_SIZE, w, h, (size_t)w * h,
+                                          (size_t)w * h * VDF_DCT_SIZE, words.data(), nullptr);
+        if (rc == VDF_E_NOT_ENOUGH_FRAMES) throw Error::not_enough_frames();
+        if (rc == VDF_E_BAD_DIMS) throw Error::vid_proc(vdf_last_error(ctx.get()));
+        if (rc != VDF_OK) throw Error(Error::Device, vdf_last_error(ctx.get()));
+        return VideoHash(words, src_path, duration);
+    }
+
+    const std::string &src_path() const { return src_path_; }
+    uint32_t duration() const { return duration_; }
+    uint32_t hamming_distance(const VideoHash &o) const { return vdf_hamming_u1024(hash_.data(), o.hash_.data()); }
+    double normalized_hamming_distance(const VideoHash &o) const { return hamming_distance(o) / 1000.0; }
+    const std::array<uint64_t, VDF_HASH_WORDS> &words() const { return hash_; }
+
+    VideoHash with_duration(uint32_t d) const { return VideoHash(hash_, src_path_, d); }
+    VideoHash with_src_path(const std::string &p) const { return VideoHash(hash_, p, duration_); }
+    static VideoHash empty_hash(const std::string &p) { return VideoHash({}, p, 0); }
+    static VideoHash full_hash(const std::string &p)
+    {
+        std::array<uint64_t, VDF_HASH_WORDS> h;
+        h.fill(~0ull);
+        return VideoHash(h, p, 0);
+    }
+    bool operator==(const VideoHash &o) const { return hash_ == o.hash_ && PathKey(src_path_) == PathKey(o.src_path_) && duration_ == o.duration_; }
+
+private:
+    std::array<uint64_t, VDF_HASH_WORDS> hash_;
+    std::string src_path_;
+    uint32_t duration_;
+};
+
+// ---- MatchGroup (matches/match_group.rs) ---------------------------------------------------------------------
+class MatchGroup {
+public:
+    static MatchGroup make(std::vector<std::string> entries)
+    {
+        if (entries.size() < 2) throw TooFewEntries();
+        return MatchGroup(std::nullopt, std::move(entries));
+    }
+    static MatchGroup make_with_reference(std::string reference, std::vector<std::string> entries)
+    {
+        if (entries.empty()) throw TooFewEntries();
+        return MatchGroup(std::move(reference), std::move(entries));
+    }
+    size_t len() const { return duplicates_.size(); }
+    const std::optional<std::string> &reference() const { return reference_; }
+    const std::vector<std::string> &duplicates() const { return duplicates_; }
+    std::vector<std::string> contained_paths() const
+    {  // duplicates, then the reference (match_group.rs:68-81)
+        std::vector<std::string> v = duplicates_;
+        if (reference_) v.push_back(*reference_);
+        return v;
+    }
+    std::vector<MatchGroup> dup_combinations() const
+    {  // match_group.rs:87-105
+        std::vector<MatchGroup> out;
+        if (reference_) {
+            for (const auto &d : duplicates_) out.push_back(make_with_reference(*reference_, {d}));
+        } else {
+            for (size_t i = 0; i < duplicates_.size(); i++)
+                for (size_t j = i + 1; j < duplicates_.size(); j++) out.push_back(make({duplicates_[i], duplicates_[j]}));
+        }
+        return out;
+    }
+
+private:
+    MatchGroup(std::optional<std::string> r, std::vector<std::string> d) : reference_(std::move(r)), duplicates_(std::move(d)) {}
+    std::optional<std::string> reference_;
+    std::vector<std::string> duplicates_;
+};
+
+namespace detail {
+// Search::sort, search_algorithm.rs:55-61: stable by (duration, src_path) with Path ordering.
+inline std::vector<size_t> sort_order(const std::vector<VideoHash> &h)
+{
+    std::vector<PathKey> keys;
+    keys.reserve(h.size());
+    for (const auto &x : h) keys.emplace_back(x.src_path());
+    std::vector<size_t> idx(h.size());
+    std::iota(idx.begin(), idx.end(), size_t{0});
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+        if (h[a].duration() != h[b].duration()) return h[a].duration() < h[b].duration();
+        return keys[a] < keys[b];
+    });
+    return idx;
+}
+inline void to_soa(const std::vector<VideoHash> &h, const std::vector<size_t> &order, std::vector<uint64_t> &words,
+                   std::vector<uint32_t> &dur)
+{
+    words.resize(order.size() * VDF_HASH_WORDS);
+    dur.resize(order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        std::copy(h[order[k]].words().begin(), h[order[k]].words().end(), words.begin() + k * VDF_HASH_WORDS);
+        dur[k] = h[order[k]].duration();
+    }
+}
+struct Groups {
+    vdf_groups g{};
+    ~Groups() { vdf_groups_free(&g); }
+};
+}  // namespace detail
+
+// video_dup_finder.rs:7-13
+inline std::vector<MatchGroup> search(const std::vector<VideoHash> &hashes, double tolerance,
+                                      Context &ctx = Context::default_context())
+{
+    std::vector<MatchGroup> out;
+    if (hashes.empty()) return out;  // search_algorithm.rs:89-91
+    const auto order = detail::sort_order(hashes);
+    std::vector<uint64_t> words;
+    std::vector<uint32_t> dur;
+    detail::to_soa(hashes, order, words, dur);
+    detail::Groups gr;
+    if (vdf_search_self(ctx.get(), words.data(), dur.data(), dur.size(), vdf_tolerance_int(tolerance), &gr.g) != VDF_OK)
+        throw Error(Error::Device, vdf_last_error(ctx.get()));
+    for (uint64_t g = 0; g < gr.g.n_groups; g++) {
+        std::vector<std::string> paths;
+        for (uint64_t k = gr.g.offsets[g]; k < gr.g.offsets[g + 1]; k++) paths.push_back(hashes[order[gr.g.members[k]]].src_path());
+        if (paths.size() >= 2) out.push_back(MatchGroup::make(std::move(paths)));  // filter_map(.. .ok())
+    }
+    return out;
+}
+
+// video_dup_finder.rs:19-46
+inline std::vector<MatchGroup> search_with_references(const std::vector<VideoHash> &ref_hashes,
+                                                      const std::vector<VideoHash> &new_hashes, double tolerance,
+                                                      Context &ctx = Context::default_context())
+{
+    std::vector<MatchGroup> out;
+    if (ref_hashes.empty() || new_hashes.empty()) return out;
+    const auto order = detail::sort_order(new_hashes);
+    std::vector<uint64_t> words, rwords;
+    std::vector<uint32_t> dur, rdur;
+    detail::to_soa(new_hashes, order, words, dur);
+    std::vector<size_t> ident(ref_hashes.size());
+    std::iota(ident.begin(), ident.end(), size_t{0});
+    detail::to_soa(ref_hashes, ident, rwords, rdur);
+    detail::Groups gr;
+    if (vdf_search_refs(ctx.get(), words.data(), dur.data(), dur.size(), rwords.data(), rdur.data(), rdur.size(),
+                        vdf_tolerance_int(tolerance), &gr.g) != VDF_OK)
+        throw Error(Error::Device, vdf_last_error(ctx.get()));
+    for (uint64_t g = 0; g < gr.g.n_groups; g++) {
+        std::vector<std::string> paths;
+        for (uint64_t k = gr.g.offsets[g]; k < gr.g.offsets[g + 1]; k++) paths.push_back(new_hashes[order[gr.g.members[k]]].src_path());
+        out.push_back(MatchGroup::make_with_reference(ref_hashes[(size_t)gr.g.ref_index[g]].src_path(), std::move(paths)));
+    }
+    return out;
+}
+
+}  // namespace vdf
