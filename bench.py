@@ -22,7 +22,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-ops/s
+# VALU issue ceiling: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz.  tools/ubench_valu.hip measures 1.76 ns per
+# wave64 instruction per SIMD for every VALU opcode tried (profiles/r01_ubench_valu_issue_rates.txt), i.e. 16
+# lanes/clk/SIMD -- the rate behind the 78.6 TF f64 / 157 TF packed-f32 spec figures.
+VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9
 BYTES_PER_PAIR = 128  # one 128-B candidate streamed per comparison
 LANEOPS_PER_PAIR = 64  # 32 dwords x (v_xor_b32 + v_bcnt_u32_b32)
 BYTES_PER_FRAME = 4104  # 4096 B read + 8 B written per 64x64 frame
@@ -66,18 +69,20 @@ def cpu_baseline(words, tol_int, target_seconds=12.0):
             "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
 
 
-def cpu_baseline_hash(n_clips=1500):
+def cpu_baseline_hash(clips_per_thread=96):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import vdf_oracle as orc
 
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_clips = cores * clips_per_thread
     rng = np.random.default_rng(20250617)
     frames = rng.integers(0, 256, size=(n_clips, 16, 64, 64), dtype=np.uint8)
-    cores = os.cpu_count() or 1
-    chunks = np.array_split(np.arange(n_clips), cores * 4)
+    orc.hash_clips(frames[:2])  # build/load outside the timed region
+    chunks = [frames[i * clips_per_thread:(i + 1) * clips_per_thread] for i in range(cores)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: the analogue of the app's rayon par_bridge
-        list(ex.map(lambda idx: orc.hash_clips(frames[idx]) if len(idx) else None, chunks))
+        list(ex.map(orc.hash_clips, chunks))
     dt = time.perf_counter() - t0
     return {"value": n_clips * 16 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle from_frames over a {cores}-thread pool, {n_clips} clips of 16x64x64"}
@@ -88,7 +93,7 @@ def read_traffic(name):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(name)
+            return json.load(f).get(name, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -218,9 +223,9 @@ def main():
         h_gbs = fps * BYTES_PER_FRAME / 1e9
         out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": fps,
                        "unit": "frames/s", "clips": nc, "ms_per_step": ms, "dtype": "u8 -> i32 fixed point -> f64",
-                       "roofline": {"bound": "hbm", "kernel": "resize + dct_hash", "achieved": h_gbs,
+                       "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_fused_kernel", "achieved": h_gbs,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS,
-                                    "traffic": read_traffic("dct_hash")}}
+                                    "traffic": read_traffic("resize_dct_hash_fused_kernel")}}
         del frames, out_h
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:

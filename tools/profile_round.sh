@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root: rocprofv3 kernel stats + PMC passes for bench.py and the
+# hash micro-bench.  Every profiler call has its own timeout (a TA_* counter pass once hung a whole call).
+# Usage: tools/profile_round.sh <out_dir under gpurun_out>
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-prof}
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/bench_under_profiler.json 2> /dev/null
+B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0"
+H1="python3 $R/tools/bench_hash.py --steps 1"
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search -- $B1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hash -- $H1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_hash -- $H1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq_search -- $B1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq_hash -- $H1 > /dev/null 2>&1
+ls $O

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output directory into the files committed under profiles/:
+   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (vdf kernels only)
+   <tag>_pmc_summary.json   per-kernel counter sums per launch
+   pmc_traffic.json         HBM bytes per launch for the dominant kernels (read by bench.py: roofline.traffic)
+Usage: python tools/summarize_profiles.py gpurun_out/<dir> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if "vdf::" in r[0]]
+    with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
+bj = os.path.join(src, "bench_under_profiler.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    open(os.path.join(out, f"{tag}_bench_under_profiler.json"), "w").write(open(bj).read())
+
+summary = {}
+for d in sorted(glob.glob(os.path.join(src, "*"))):
+    fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"]
+        if "vdf::" not in k:
+            continue
+        k = k.split("(")[0].replace("void ", "").replace("vdf::", "")
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k].add(r["Dispatch_Id"])
+    summary[os.path.basename(d)] = {k: {"launches": len(launches[k]), **{c: v / len(launches[k]) for c, v in cs.items()}}
+                                    for k, cs in agg.items()}
+json.dump(summary, open(os.path.join(out, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+
+
+def traffic(fetch_dir, write_dir, kernel, fetch_factor, note):
+    f = summary.get(fetch_dir, {}).get(kernel, {}).get("FETCH_SIZE")
+    w = summary.get(write_dir, {}).get(kernel, {}).get("WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    # rocprofv3 reports KB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 128-B requests at 64 B, i.e. half the
+    # bytes of a wide (16 B/lane) coalesced read -> factor 2 where the kernel streams with dwordx4 loads.
+    return {"hbm_bytes_per_launch": f * 1024 * fetch_factor + w * 1024, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+            "fetch_factor": fetch_factor, "note": note}
+
+
+t = {}
+for k in summary.get("fetch_search", {}):
+    if k.startswith("hamming_tile_kernel"):
+        t["hamming_tile_kernel"] = traffic("fetch_search", "write_search", k, 1,
+                                           "candidates arrive through scalar-cache line fills (64-B requests): no x2 correction applied")
+for k in summary.get("fetch_hash", {}):
+    if k.startswith("resize_dct_hash_fused_kernel"):
+        t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
+                                                    "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
+json.dump(t, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(t, indent=1))
