@@ -66,6 +66,7 @@ struct vdf_ctx {
     DevBuf small, frames, out_hashes, out_dc, cos_table;
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
+    int hash_no_persistent = 0, hash_wgs_per_cu = 3;
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel
     std::vector<vdf_hit> host_hits;
 
@@ -319,6 +320,8 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             a.prec_v = mv->host.precision;
             a.n_kt = mh->host.n_tiles;
             a.n_rg = mv->host.n_tiles;
+            a.no_persistent = ctx->hash_no_persistent;
+            a.persistent_wgs_per_cu = ctx->hash_wgs_per_cu;
             const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && a.n_rg <= 2);
             if (fused) {
                 VDF_HIP(ctx, vdf::launch_resize_dct_fused(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
@@ -388,6 +391,11 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
         if (m >= 0 && m <= 3) ctx->resize_mode = m;
+    }
+    if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
+    if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {
+        int v = std::atoi(s);
+        if (v >= 1 && v <= 8) ctx->hash_wgs_per_cu = v;
     }
     if (const char *s = std::getenv("VDF_CHUNK_COLS")) {
         long c = std::atol(s);

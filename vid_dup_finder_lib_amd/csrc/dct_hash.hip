@@ -10,6 +10,8 @@
 // Two kernels: resize (one workgroup per frame, W x H -> 16 x 16 u8 into a small cube buffer) and
 // dct_hash (one workgroup per clip: f64 DCT-II along x, y, t through LDS, pruned to the 10 outputs
 // per axis that are consumed, sign test, __ballot pack: ballot of wave-word w IS hash word w).
+#include <algorithm>
+
 #include "vdf_internal.h"
 
 namespace vdf {
@@ -162,6 +164,8 @@ __device__ __forceinline__ void dct_hash_block(DctShared &sh, const_f64_ptr cosv
         dct16_pruned(v, o, cm);
 #pragma unroll
         for (int kx = 0; kx < 10; kx++) sh.b[tid * kPadY + kx] = o[kx];  // own row: all reads are done
+    } else if (tid >= 192 && tid < 224) {
+        sh.words[tid - 192] = 0u;  // idle lanes clear the ballot words (previous clip's words were read two barriers ago)
     }
     __syncthreads();
     // pass t + sign + pack: thread rem = 10 kx + ky (100 threads) reads its 16 t-values once and produces the ten
@@ -382,6 +386,66 @@ __global__ __launch_bounds__(256) void resize_dct_hash_fused_kernel(
     dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
 }
 
+// Persistent form of the ONE_TILE fused kernel (W, H <= 64, W % 16 == 0 so no load crosses the buffer end):
+// a workgroup loops over clips and issues the NEXT clip's 16 loads per lane (64 KB per workgroup) as soon as the
+// resize has consumed the current pixels, so HBM streams underneath the DCT instead of after it.
+__global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
+    const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
+    MfmaResizeTables T, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
+    uint32_t *__restrict__ out_dontcare, uint32_t n_clips)
+{
+    __shared__ DctShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    if (tid < 32) sh.words[tid] = 0u;
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    const v4i bh = T.bh[lane], bl = T.bh[64 + lane], avh = T.av[lane], avl = T.av[64 + lane];
+    const int32_t bias_h = T.bias_h[r16];
+    const bool col_ok = 16u * g < W;
+    const size_t lane_off = (size_t)r16 * W + 16u * g;  // row r16 of row block m is at + 16 m W
+
+    v4i px[4][4];
+    auto issue_loads = [&](size_t clip) {
+        const uint8_t *base = frames + clip * clip_stride + (size_t)wave * frame_stride + lane_off;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                px[q][m] = (v4i){0, 0, 0, 0};
+                if (16u * m + r16 < H && col_ok)
+                    px[q][m] = load_pixels16<false>(base + (size_t)(4 * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
+            }
+        }
+    };
+    uint32_t clip = blockIdx.x;
+    if (clip < n_clips) issue_loads(clip);
+    while (clip < n_clips) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4i a = px[q][m] ^ x80;
+                v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al, 0, 0, 0);
+                b[m] = (int)finalize4(ah, al, T.prec_h);
+            }
+            v4i vh = {0, 0, 0, 0}, vl = bias_v;
+            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, vh, 0, 0, 0);
+            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, vl, 0, 0, 0);
+            sh.cube[(wave + 4 * q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+        }
+        const uint32_t next = clip + gridDim.x;
+        if (next < n_clips) issue_loads(next);  // in flight during the whole DCT below
+        __syncthreads();
+        dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
+        clip = next;
+    }
+}
+
 // Large frames: one workgroup per frame, the four waves take alternate 64-row groups and their vertical
 // partial sums (exact i32) are added through LDS.  Writes the 16 x 16 u8 frame to `small`.
 __global__ __launch_bounds__(256) void resize_mfma_frame_kernel(const uint8_t *__restrict__ frames, uint32_t W,
@@ -456,7 +520,15 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
                                    hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    if (a.n_kt == 1 && a.n_rg == 1)
+    if (a.n_kt == 1 && a.n_rg == 1 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t grid = (uint32_t)std::min<size_t>(n_clips, (size_t)cus * a.persistent_wgs_per_cu);
+        hipLaunchKernelGGL(resize_dct_hash_persistent_kernel, dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
+                           (uint32_t)n_clips);
+    } else if (a.n_kt == 1 && a.n_rg == 1)
         hipLaunchKernelGGL(resize_dct_hash_fused_kernel<true>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w,
                            h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes, out_dontcare);
     else

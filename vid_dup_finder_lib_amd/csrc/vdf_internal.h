@@ -62,6 +62,8 @@ struct MfmaResizeArgs {  // device pointers to the MFMA-layout tables (resize_ta
     const void *bh, *av;
     const int32_t *bias_h, *bias_v;
     int32_t prec_h, prec_v, n_kt, n_rg;
+    int32_t no_persistent = 0;         // debugging: force the one-clip-per-workgroup fused kernel
+    int32_t persistent_wgs_per_cu = 3; // resident workgroups per CU for the persistent kernel
 };
 hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                    size_t clip_stride, const uint8_t *buf_end, const MfmaResizeArgs &a,
