@@ -13,11 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def engine():
-    """The HIP engine.  No fallback: on a box without a GPU (or without libvdf_hip.so) this raises."""
+@pytest.fixture(scope="session", params=["mfma", "valu"])
+def engine(request):
+    """The HIP engine, once per Hamming backend (fp4 Gram matrix on the matrix cores / XOR + popcount on the
+    VALU: both exact).  No fallback: on a box without a GPU (or without libvdf_hip.so) this raises."""
     import vid_dup_finder_lib_amd as vdf
 
-    eng = vdf.Engine(0)
+    old = os.environ.get("VDF_SEARCH_BACKEND")
+    os.environ["VDF_SEARCH_BACKEND"] = request.param
+    try:
+        eng = vdf.Engine(0)
+    finally:
+        if old is None:
+            os.environ.pop("VDF_SEARCH_BACKEND", None)
+        else:
+            os.environ["VDF_SEARCH_BACKEND"] = old
+    eng.backend = request.param
     yield eng
     eng.close()

@@ -67,6 +67,8 @@ struct vdf_ctx {
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
+    int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
+    DevBuf exp_cols, exp_rows;
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel
     std::vector<vdf_hit> host_hits;
 
@@ -81,7 +83,7 @@ struct vdf_ctx {
             delete kv.second;
         }
         DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
-                         &hits, &perm, &matched, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
+                         &hits, &perm, &matched, &exp_cols, &exp_rows, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
                          &out_hashes, &out_dc, &cos_table};
         for (DevBuf *b : all) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -128,7 +130,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, hipSetDevice(ctx->device));
 
     vdf::SearchLaunch L{};
-    L.tile_rows = ctx->tile_rows;
+    const bool mfma = ctx->search_backend == 1;
+    L.tile_rows = mfma ? 256u : ctx->tile_rows;
     L.chunk_cols = ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     const size_t padded_rows = (size_t)L.n_row_tiles * L.tile_rows;
@@ -164,6 +167,21 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.counters = ctx->counters.as<unsigned long long>();
     L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
 
+    if (mfma) {
+        // expand both operands to +-1 fp4 (512 B per hash); rows share the column copy in self mode
+        const uint32_t col_pad = (uint32_t)((n_cols + vdf::kMfmaRowPad - 1) / vdf::kMfmaRowPad * vdf::kMfmaRowPad) + vdf::kMfmaColPad;
+        VDF_HIP(ctx, ctx->exp_cols.reserve((size_t)col_pad * 512));
+        VDF_HIP(ctx, vdf::launch_expand_fp4(L.col_hashes, (uint32_t)n_cols, col_pad, ctx->exp_cols.p, stream));
+        L.col_exp = ctx->exp_cols.p;
+        if (d_row_hashes == d_col_hashes) {
+            L.row_exp = ctx->exp_cols.p;
+        } else {
+            const uint32_t row_pad = (uint32_t)padded_rows;
+            VDF_HIP(ctx, ctx->exp_rows.reserve((size_t)row_pad * 512));
+            VDF_HIP(ctx, vdf::launch_expand_fp4(L.row_hashes, (uint32_t)n_rows, row_pad, ctx->exp_rows.p, stream));
+            L.row_exp = ctx->exp_rows.p;
+        }
+    }
     // counters[0..2] = 0, overflow_row = UINT32_MAX
     unsigned long long init[8] = {0, 0, 0, 0, 0xFFFFFFFFull, 0, 0, 0};
     VDF_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, sizeof init, hipMemcpyHostToDevice, stream));
@@ -175,7 +193,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
 
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
+    if (mfma) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma(L, total_tiles, stream));
+    else VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
     VDF_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     unsigned long long fin[8];
     VDF_HIP(ctx, hipMemcpyAsync(fin, ctx->counters.p, sizeof fin, hipMemcpyDeviceToHost, stream));
@@ -391,6 +410,10 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
         if (m >= 0 && m <= 3) ctx->resize_mode = m;
+    }
+    if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
+        if (!std::strcmp(s, "valu")) ctx->search_backend = 0;
+        else if (!std::strcmp(s, "mfma")) ctx->search_backend = 1;
     }
     if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {

@@ -242,6 +242,163 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
     if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * TILE_ROWS);
 }
 
+// ---- exact Hamming distances on the matrix cores ---------------------------------------------------------
+// With every hash bit encoded as a +-1 fp4 value (e2m1: 0x2 = +1.0, 0xA = -1.0) the dot product of two hashes is
+// (#equal bits) - (#different bits) = 1024 - 2 * hamming, an integer <= 1024 that f32 accumulation represents
+// exactly, so  hamming <= tol  <=>  dot >= 1024 - 2 tol  bit for bit.  v_mfma_scale_f32_32x32x64_f8f6f4 (both
+// operands fp4, unit E8M0 scales) evaluates 32 x 32 pairs x 64 bit positions per instruction; measured
+// 15 ns per instruction per SIMD (tools/ubench_mfma.hip) = 4.4e12 pairs/s chip-wide, 7x the VALU issue ceiling
+// of the XOR + popcount formulation (tools/ubench_valu.hip).  Layout probed with exact data
+// (tools/probe_mfma_fp4.hip): A row / B col = lane & 31, k-group = lane >> 5 (32 nibbles = 16 B per lane),
+// C row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), C col = lane & 31.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// packed [n][32] u32  ->  expanded [n_pad][32 chunks][16 B]: chunk d = the 32 nibbles of packed dword d
+// (nibble q <-> bit q).  Rows n .. n_pad are zero (fp4 +0.0: dot 0, never inside a window).
+__global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ packed, uint32_t n,
+                                                        uint32_t n_pad, uint4 *__restrict__ expanded)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (hash, dword)
+    if (idx >= (size_t)n_pad * 32) return;
+    const uint32_t hsh = (uint32_t)(idx >> 5);
+    uint4 out = {0u, 0u, 0u, 0u};
+    if (hsh < n) {
+        const uint32_t w = packed[idx];
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t x = (w >> (8 * j)) & 0xFFu;          // 8 bits -> 8 nibbles
+            x = (x | (x << 12)) & 0x000F000Fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;
+            o[j] = (x << 3) | 0x22222222u;                // bit 0 -> 0x2 (+1.0), bit 1 -> 0xA (-1.0)
+        }
+        out = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    expanded[idx] = out;
+}
+
+constexpr uint32_t kMfmaTileRows = 256;  // 4 waves x 64 rows
+constexpr uint32_t kMfmaColStep = 32;    // candidates per LDS stage
+
+__global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
+    const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
+    uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
+    const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
+    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_offset, uint32_t n_row_tiles,
+    uint32_t chunk_cols, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
+    vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ overflow_row)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_b[2][kMfmaColStep * 32];  // 2 x 16 KB: [col][chunk ^ col] swizzled
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c31 = lane & 31;
+
+    const_u32_ptr off = (const_u32_ptr)(uintptr_t)tile_offset;
+    uint32_t tl = 0, th = n_row_tiles;
+    while (th - tl > 1) {
+        const uint32_t mid = (tl + th) >> 1;
+        if (off[mid] <= blockIdx.x) tl = mid; else th = mid;
+    }
+    const uint32_t t = tl;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)tile_first)[t] + (blockIdx.x - off[t]);
+    const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
+    const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
+    const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
+    const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
+    if (c_begin >= c_end) return;
+
+    // targets: 2 row tiles of 32 per wave, all 16 k-steps (32 chunks of 16 B per hash: lane group g takes chunks 16 g ..)
+    const uint32_t row0 = t * kMfmaTileRows + wave * 64;
+    v4i a[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        const uint32_t p = row0 + 32 * rt + c31;
+        uint32_t src = p;
+        if (p < n_rows && row_perm) src = row_perm[p];
+        const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;  // rows >= n_rows read the zero padding
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const uint4 v = rp[s];
+            a[rt][s] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
+    }
+    const float thresh = 1024.0f - 2.0f * (float)min(tol, 1024u);
+
+    // stage loader: 1024 chunks of 16 B per 32-column stage, 4 per thread; LDS slot L = (col << 5 | q) holds chunk q ^ col
+    const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
+    uint4 stage[4];
+    auto load_stage = [&](uint32_t cb) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t L = tid + 256 * i, c = L >> 5, q = L & 31;
+            stage[i] = col_exp[(size_t)(cb + c) * 32 + (q ^ c)];
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) s_b[buf][tid + 256 * i] = stage[i];
+    };
+    load_stage(cb0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (uint32_t cb = cb0; cb < c_end; cb += kMfmaColStep, buf ^= 1) {
+        const bool more = cb + kMfmaColStep < c_end;
+        if (more) load_stage(cb + kMfmaColStep);  // in flight under the MFMAs below
+        v16f acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const uint4 bv = s_b[buf][(c31 << 5) | ((uint32_t)(s + 16 * g) ^ c31)];
+            const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
+            const v8i a0 = {a[0][s].x, a[0][s].y, a[0][s].z, a[0][s].w, 0, 0, 0, 0};
+            const v8i a1 = {a[1][s].x, a[1][s].y, a[1][s].z, a[1][s].w, 0, 0, 0, 0};
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b, acc0, 4, 4, 0, 127, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b, acc1, 4, 4, 0, 127, 0, 127);
+        }
+        float m = acc0[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) m = fmaxf(m, acc0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) m = fmaxf(m, acc1[r]);
+        if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
+            // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
+            const uint32_t j = cb + c31;
+            bool col_ok = j >= c_begin && j < c_end;
+            if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float d = rt ? acc1[r] : acc0[r];
+                    if (col_ok && d >= thresh) {
+                        const uint32_t p = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        const uint32_t lo = row_lo[p], hi = row_hi[p];
+                        if (j >= lo && j < hi) {
+                            const uint32_t src = row_perm ? row_perm[p] : p;
+                            bool ok = true;
+                            if (self_mode && matched) ok = ((matched[src >> 5] >> (src & 31)) & 1u) == 0u;
+                            if (ok) {
+                                const unsigned long long idx = atomicAdd(&counters[0], 1ull);
+                                if (idx < capacity) {
+                                    vdf_hit hp; hp.row = row_index_base + src; hp.col = j;
+                                    hits[idx] = hp;
+                                } else {
+                                    atomicMin(overflow_row, row_index_base + src);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
+}
+
 hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,
                                 const uint32_t *row_perm, uint32_t n_rows, uint32_t row_begin, uint32_t row_end,
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L, hipStream_t stream)
@@ -269,6 +426,27 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
     default: return hipErrorInvalidValue;
     }
 #undef VDF_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream)
+{
+    if (n_pad == 0) return hipSuccess;
+    const size_t total = (size_t)n_pad * 32;
+    hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, packed, n, n_pad,
+                       reinterpret_cast<uint4 *>(expanded));
+    return hipGetLastError();
+}
+
+hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)
+{
+    if (total_tiles == 0) return hipSuccess;
+    if (L.tile_rows != kMfmaTileRows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(hamming_mfma_kernel, dim3(total_tiles), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,
+                       reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,
+                       L.tile_first, L.tile_offset, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits,
+                       L.capacity, L.counters, L.overflow_row);
     return hipGetLastError();
 }
 

@@ -23,6 +23,8 @@ struct SearchLaunch {
     // columns (candidates)
     const uint32_t *col_hashes;  // [n_cols][32]
     uint32_t n_cols;
+    // fp4-expanded copies for the MFMA backend ([n_pad][512 B], zero padded); null for the VALU backend
+    const void *row_exp, *col_exp;
     // windows + tiles (device scratch, filled by launch_windows_tiles)
     uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
@@ -45,6 +47,10 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L,
                                 hipStream_t stream);
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
+// MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of 256, columns to a multiple of 32 (+32).
+constexpr uint32_t kMfmaRowPad = 256, kMfmaColPad = 32;
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
+hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 
 // ---- hash construction -----------------------------------------------------------------------
 struct ResizeAxisTable {  // device pointers, one axis
