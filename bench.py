@@ -29,6 +29,10 @@ VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9
 BYTES_PER_PAIR = 128  # one 128-B candidate streamed per comparison
 LANEOPS_PER_PAIR = 64  # 32 dwords x (v_xor_b32 + v_bcnt_u32_b32)
 BYTES_PER_FRAME = 4104  # 4096 B read + 8 B written per 64x64 frame
+# fp4 MFMA backend: a pair is a 1024-long +-1 dot product = 1024 MACs = 2048 FLOP on the f8f6f4 matrix path.
+FLOP_PER_PAIR = 2048
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: ~10 PF dense FP4/FP6 (spec).  tools/ubench_mfma.hip sustains
+#                                  4.4e12 pairs/s = 9.0 PFLOP/s with operands held in registers.
 
 
 def make_hashes(n, seed, planted_every=1000):
@@ -119,7 +123,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also at world size 1)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -146,7 +151,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +160,7 @@ def main():
 
     def step():
         nonlocal n_groups
-        full_w, full_d = vd.all_gather_database(shard_w, shard_d)
+        full_w, full_d = vd.all_gather_database(shard_w, shard_d, force=use_dist)
         groups = vd.search_self_sharded(eng, full_w, full_d, tol_int, stream=stream)
         st = eng.last_stats()
         kernel_ms.append((st["kernel_ms"], st["n_launches"], st["pairs"], st["pairs_computed"], st["n_hits"]))
@@ -172,35 +177,51 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # ---- dominant kernel: hamming_tile_kernel, HIP-event time on its own stream --------------------------
+    # ---- dominant kernel (HIP-event time recorded by the library on the kernel's own stream) ---------------
+    backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
     k_ms = float(np.mean([k[0] / max(k[1], 1) for k in kernel_ms]))
     k_pairs = float(np.mean([k[2] for k in kernel_ms]))  # pairs admitted on THIS rank per launch
-    k_comp = float(np.mean([k[3] for k in kernel_ms]))
-    achieved_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "hamming_tile_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": read_traffic("hamming_tile_kernel"),
-                "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
-                "note": "operand-stream model of the reference loop (128 B per pair, SURVEY 8d); tiles keep targets in "
-                        "VGPRs and candidates in SGPRs so real HBM traffic is ~0.25 B/pair and the true ceiling is VALU"}
-    valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
-    valu["frac"] = valu["achieved"] / valu["peak"]
-
+    k_comp = float(np.mean([k[3] for k in kernel_ms]))   # pairs the tiles evaluated (>= admitted)
+    stream_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
+    hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": stream_gbs / HBM_PEAK_GBS,
+                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream model of the reference loop: 128 B per pair "
+                         "against 8 TB/s (north_star target frac >= 0.5).  Tiles keep targets in registers and share "
+                         "candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per pair (see traffic)"}
+    if backend == "valu":
+        kname = "hamming_tile_kernel"
+        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname), kernel_ms=k_ms, pairs_per_launch=k_pairs)
+        valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        extra = {"valu": valu}
+        dtype = "u32 (xor + popcount over 32 dwords per hash)"
+    else:
+        kname = "hamming_mfma_kernel"
+        tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, "traffic": read_traffic(kname),
+                    "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
+                    "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
+                            "2048 FLOP per pair; integer results, bit-identical to XOR + popcount"}
+        extra = {"hbm_operand_stream_model": hbm_model}
+        dtype = "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)"
     out = {
         "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
         "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32 (xor + popcount over 32 dwords per hash)", "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, all durations 0, all-pairs "
                                "search_self at tolerance 350, planted near-duplicates every 1000th hash",
                    "n_hashes": n_total, "hashes_per_gpu_shard": hi - lo, "pairs": pairs, "tolerance_int": tol_int,
                    "parallelism": f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1
                    else "single GPU"},
-        "roofline": roofline, "valu": valu, "match_groups": n_groups,
+        "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
     }
+    out.update(extra)
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM ------------------------------------------
     if args.hash_clips > 0 and rank == 0:
@@ -234,7 +255,7 @@ def main():
             out["hash"]["cpu_baseline"] = cpu_baseline_hash()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -61,8 +61,11 @@ for k in summary.get("fetch_search", {}):
     if k.startswith("hamming_tile_kernel"):
         t["hamming_tile_kernel"] = traffic("fetch_search", "write_search", k, 1,
                                            "candidates arrive through scalar-cache line fills (64-B requests): no x2 correction applied")
+    if k.startswith("hamming_mfma_kernel"):
+        t["hamming_mfma_kernel"] = traffic("fetch_search", "write_search", k, 2,
+                                           "candidate tiles stream through global_load_lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
 for k in summary.get("fetch_hash", {}):
-    if k.startswith("resize_dct_hash_fused_kernel"):
+    if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
         t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
                                                     "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
 json.dump(t, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)

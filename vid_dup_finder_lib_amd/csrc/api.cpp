@@ -67,6 +67,8 @@ struct vdf_ctx {
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
+    uint32_t mfma_chunk_cols = 4096, mfma_group = 8192;
+    DevBuf group_cmin, group_offset, group_blocks;
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel
@@ -83,7 +85,7 @@ struct vdf_ctx {
             delete kv.second;
         }
         DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
-                         &hits, &perm, &matched, &exp_cols, &exp_rows, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
+                         &hits, &perm, &matched, &exp_cols, &exp_rows, &group_cmin, &group_offset, &group_blocks, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
                          &out_hashes, &out_dc, &cos_table};
         for (DevBuf *b : all) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
@@ -132,7 +134,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     vdf::SearchLaunch L{};
     const bool mfma = ctx->search_backend == 1;
     L.tile_rows = mfma ? 256u : ctx->tile_rows;
-    L.chunk_cols = ctx->chunk_cols;
+    L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     const size_t padded_rows = (size_t)L.n_row_tiles * L.tile_rows;
     VDF_HIP(ctx, ctx->row_lo.reserve(padded_rows * 4));
@@ -168,6 +170,15 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
 
     if (mfma) {
+        L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
+        L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
+        if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
+        VDF_HIP(ctx, ctx->group_cmin.reserve((size_t)L.n_groups * 4));
+        VDF_HIP(ctx, ctx->group_offset.reserve(((size_t)L.n_groups + 1) * 4));
+        VDF_HIP(ctx, ctx->group_blocks.reserve((size_t)L.n_groups * 4));
+        L.group_blocks = ctx->group_blocks.as<uint32_t>();
+        L.group_cmin = ctx->group_cmin.as<uint32_t>();
+        L.group_offset = ctx->group_offset.as<uint32_t>();
         // expand both operands to +-1 fp4 (512 B per hash); rows share the column copy in self mode
         const uint32_t col_pad = (uint32_t)((n_cols + vdf::kMfmaRowPad - 1) / vdf::kMfmaRowPad * vdf::kMfmaRowPad) + vdf::kMfmaColPad;
         VDF_HIP(ctx, ctx->exp_cols.reserve((size_t)col_pad * 512));
@@ -188,7 +199,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
                                            row_begin, row_end, shard_index, shard_count, L, stream));
     uint32_t total_tiles = 0;
-    VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, L.tile_offset + L.n_row_tiles, 4, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
+                                hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
 
@@ -414,6 +426,14 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
         if (!std::strcmp(s, "valu")) ctx->search_backend = 0;
         else if (!std::strcmp(s, "mfma")) ctx->search_backend = 1;
+    }
+    if (const char *s = std::getenv("VDF_MFMA_CHUNK_COLS")) {
+        long c = std::atol(s);
+        if (c >= 32 && c <= (1 << 22)) ctx->mfma_chunk_cols = (uint32_t)c;
+    }
+    if (const char *s = std::getenv("VDF_MFMA_GROUP")) {
+        long c = std::atol(s);
+        if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;
     }
     if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {

@@ -151,6 +151,48 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__rest
     if (tid == 1023) tile_offset[n] = s_part[1023];
 }
 
+// Grouped, chunk-major work order for the MFMA kernel: G consecutive row tiles form a group; inside a group
+// the workgroups walk candidate chunk by candidate chunk, so the ~2 x 256 workgroups resident at any time all
+// stream the SAME few MB of candidates and find them in their XCD's L2 instead of HBM.  Workgroups whose
+// (row tile, chunk) is outside the tile's range exit at once (a few % of the grid near the diagonal).
+__global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__restrict__ tile_first,
+                                                          const uint32_t *__restrict__ tile_count, uint32_t n_row_tiles,
+                                                          uint32_t group_size, uint32_t *__restrict__ group_cmin,
+                                                          uint32_t *__restrict__ group_blocks)
+{  // one workgroup per group: chunk range covered by its row tiles
+    __shared__ uint32_t s_min[4], s_max[4];
+    const uint32_t g = blockIdx.x;
+    uint32_t cmin = 0xFFFFFFFFu, cmax = 0;
+    const uint32_t t1 = min((g + 1) * group_size, n_row_tiles);
+    for (uint32_t t = g * group_size + threadIdx.x; t < t1; t += 256) {
+        if (tile_count[t]) {
+            cmin = min(cmin, tile_first[t]);
+            cmax = max(cmax, tile_first[t] + tile_count[t]);
+        }
+    }
+    cmin = wave_min(cmin);
+    cmax = wave_max(cmax);
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = cmin; s_max[threadIdx.x >> 6] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (cmax <= cmin) { cmin = 0; cmax = 0; }
+        group_cmin[g] = cmin;
+        group_blocks[g] = (cmax - cmin) * group_size;
+    }
+}
+
+__global__ void group_scan_kernel(const uint32_t *__restrict__ group_blocks, uint32_t n_groups,
+                                  uint32_t *__restrict__ group_offset)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < n_groups; g++) { group_offset[g] = run; run += group_blocks[g]; }
+        group_offset[n_groups] = run;
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void hamming_tile_kernel(
     const uint32_t *__restrict__ row_hashes, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
@@ -281,28 +323,37 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
 }
 
 constexpr uint32_t kMfmaTileRows = 256;  // 4 waves x 64 rows
-constexpr uint32_t kMfmaColStep = 32;    // candidates per LDS stage
+constexpr uint32_t kMfmaSub = 2;                     // 32-column sub-tiles per LDS stage
+constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
 
 __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
     const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
-    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_offset, uint32_t n_row_tiles,
-    uint32_t chunk_cols, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
-    vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ overflow_row)
+    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ group_offset, const uint32_t *__restrict__ group_cmin, uint32_t n_groups,
+    uint32_t group_size, uint32_t n_row_tiles, uint32_t chunk_cols, uint32_t tol,
+    const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
+    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_b[2][kMfmaColStep * 32];  // 2 x 16 KB: [col][chunk ^ col] swizzled
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c31 = lane & 31;
 
-    const_u32_ptr off = (const_u32_ptr)(uintptr_t)tile_offset;
-    uint32_t tl = 0, th = n_row_tiles;
-    while (th - tl > 1) {
-        const uint32_t mid = (tl + th) >> 1;
-        if (off[mid] <= blockIdx.x) tl = mid; else th = mid;
+    // workgroup -> (group, chunk, row tile in group): chunk-major inside a group
+    const_u32_ptr goff = (const_u32_ptr)(uintptr_t)group_offset;
+    uint32_t gl = 0, gh = n_groups;
+    while (gh - gl > 1) {
+        const uint32_t mid = (gl + gh) >> 1;
+        if (goff[mid] <= blockIdx.x) gl = mid; else gh = mid;
     }
-    const uint32_t t = tl;
-    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)tile_first)[t] + (blockIdx.x - off[t]);
+    const uint32_t idx = blockIdx.x - goff[gl];
+    const uint32_t t = gl * group_size + idx % group_size;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / group_size;
+    if (t >= n_row_tiles) return;
+    {
+        const uint32_t f = ((const_u32_ptr)(uintptr_t)tile_first)[t], cnt = ((const_u32_ptr)(uintptr_t)tile_count)[t];
+        if (chunk < f || chunk >= f + cnt) return;
+    }
     const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
     const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
     const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
@@ -326,36 +377,50 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     }
     const float thresh = 1024.0f - 2.0f * (float)min(tol, 1024u);
 
-    // stage loader: 1024 chunks of 16 B per 32-column stage, 4 per thread; LDS slot L = (col << 5 | q) holds chunk q ^ col
+    // stage loader: a 32-column stage is 1024 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col of that
+    // column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged with
+    // global_load_lds: the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane SOURCE
+    // address; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
     const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
-    uint4 stage[4];
-    auto load_stage = [&](uint32_t cb) {
+    uint32_t lane_off[4 * kMfmaSub];  // loop-invariant byte offset of this lane's source chunk inside a stage
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t L = tid + 256 * i, c = L >> 5, q = L & 31;
-            stage[i] = col_exp[(size_t)(cb + c) * 32 + (q ^ c)];
-        }
-    };
-    auto store_stage = [&](int buf) {
+    for (int i = 0; i < (int)(4 * kMfmaSub); i++) {
+        const uint32_t L = 256 * i + 64 * wave + lane, c = L >> 5, q = L & 31;
+        lane_off[i] = c * 512u + ((q ^ (c & 31)) << 4);
+    }
+    auto load_stage = [&](uint32_t cb, int buf) {
+        const char *base = reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512;  // wave-uniform (SGPR pair)
 #pragma unroll
-        for (int i = 0; i < 4; i++) s_b[buf][tid + 256 * i] = stage[i];
+        for (int i = 0; i < (int)(4 * kMfmaSub); i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off[i]),
+                                             (__attribute__((address_space(3))) void *)&s_b[buf][256 * i + 64 * wave],
+                                             16, 0, 0);
     };
-    load_stage(cb0);
-    store_stage(0);
+    load_stage(cb0, 0);
     __syncthreads();
     int buf = 0;
     for (uint32_t cb = cb0; cb < c_end; cb += kMfmaColStep, buf ^= 1) {
         const bool more = cb + kMfmaColStep < c_end;
-        if (more) load_stage(cb + kMfmaColStep);  // in flight under the MFMAs below
+        if (more) load_stage(cb + kMfmaColStep, buf ^ 1);  // lands under the MFMAs below
+#pragma unroll
+        for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
+        if (cb + 32u * sub >= c_end) break;
         v16f acc0 = {}, acc1 = {};
+        // LDS fragment reads run 8 steps ahead of the MFMAs that consume them (bounded so that 128 A + 32 C + 32 B
+        // registers stay under the 256-VGPR budget of 2 waves per SIMD without spills)
+        const uint32_t lds_row = (32u * sub + c31) << 5;
+        uint4 bq[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[s] = s_b[buf][lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
 #pragma unroll
         for (int s = 0; s < 16; s++) {
-            const uint4 bv = s_b[buf][(c31 << 5) | ((uint32_t)(s + 16 * g) ^ c31)];
+            const uint4 bv = bq[s & 7];
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
             const v8i a0 = {a[0][s].x, a[0][s].y, a[0][s].z, a[0][s].w, 0, 0, 0, 0};
             const v8i a1 = {a[1][s].x, a[1][s].y, a[1][s].z, a[1][s].w, 0, 0, 0, 0};
             acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b, acc0, 4, 4, 0, 127, 0, 127);
             acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b, acc1, 4, 4, 0, 127, 0, 127);
+            if (s + 8 < 16) bq[s & 7] = s_b[buf][lds_row | ((uint32_t)(s + 8 + 16 * g) ^ c31)];
         }
         float m = acc0[0];
 #pragma unroll
@@ -364,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
         for (int r = 0; r < 16; r++) m = fmaxf(m, acc1[r]);
         if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
             // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
-            const uint32_t j = cb + c31;
+            const uint32_t j = cb + 32u * sub + c31;
             bool col_ok = j >= c_begin && j < c_end;
             if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
 #pragma unroll
@@ -393,8 +458,8 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
                 }
             }
         }
-        if (more) store_stage(buf ^ 1);
-        __syncthreads();
+        }
+        __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with s_b[buf]
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
 }
@@ -408,6 +473,11 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                        row_perm, n_rows, row_begin, row_end, shard_index, shard_count, (uint32_t)L.tile_rows,
                        L.chunk_cols, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi, L.tile_first, L.tile_count, L.counters);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, L.tile_count, L.n_row_tiles, L.tile_offset);
+    if (L.n_groups) {
+        hipLaunchKernelGGL(group_tiles_kernel, dim3(L.n_groups), dim3(256), 0, stream, L.tile_first, L.tile_count,
+                           L.n_row_tiles, L.group_size, L.group_cmin, L.group_blocks);
+        hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(64), 0, stream, L.group_blocks, L.n_groups, L.group_offset);
+    }
     return hipGetLastError();
 }
 
@@ -445,8 +515,9 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
     hipLaunchKernelGGL(hamming_mfma_kernel, dim3(total_tiles), dim3(256), 0, stream,
                        reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,
                        reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,
-                       L.tile_first, L.tile_offset, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits,
-                       L.capacity, L.counters, L.overflow_row);
+                       L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,
+                       L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,
+                       L.overflow_row);
     return hipGetLastError();
 }
 

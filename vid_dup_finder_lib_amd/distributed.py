@@ -34,11 +34,12 @@ def _world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
-def all_gather_database(local_words: torch.Tensor, local_dur: torch.Tensor, group=None):
+def all_gather_database(local_words: torch.Tensor, local_dur: torch.Tensor, group=None, force: bool = False):
     """Replicate the sharded database: local_words [n_local, 16] int64, local_dur [n_local] int32 (same device).
-    Returns (words [n, 16], dur [n]) in rank order.  Shards may have different sizes (padded for the collective)."""
+    Returns (words [n, 16], dur [n]) in rank order.  Shards may have different sizes (padded for the collective).
+    force=True runs the collective even at world size 1 (bench.py under torchrun: exercises the RCCL path)."""
     rank, world = _world(group)
-    if world == 1:
+    if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return local_words, local_dur
     dev = local_words.device
     n_local = torch.tensor([local_words.shape[0]], dtype=torch.int64, device=dev)

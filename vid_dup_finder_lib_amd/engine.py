@@ -133,7 +133,7 @@ class Engine:
                            shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
         """Thresholded adjacency of this shard's row tiles: (hits [k,2] u32 sorted, n_hits, overflow_row)."""
-        hits = np.zeros((max(capacity, 1), 2), np.uint32)
+        hits = np.empty((max(capacity, 1), 2), np.uint32)  # filled by the library up to n_hits
         n_hits = C.c_uint64(0)
         overflow = C.c_uint32(0)
         self._check(self.lib.vdf_search_self_device(self.ctx, d_hashes, d_durations, n, int(tol_int), shard_index,
@@ -141,14 +141,14 @@ class Engine:
                                                     d_matched or None, hits.ctypes.data, capacity, C.byref(n_hits),
                                                     C.byref(overflow), stream or None))
         k = min(int(n_hits.value), capacity)
-        return hits[:k], int(n_hits.value), int(overflow.value)
+        return hits[:k].copy(), int(n_hits.value), int(overflow.value)
 
     def search_refs_device(self, d_cand_hashes: int, d_cand_durations: int, n_cand: int, d_ref_hashes: int,
                            d_ref_durations: int, n_ref: int, tol_int: int, ref_index_base: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
         """(hits [k,2] u32 sorted by (ref, cand), n_hits).  Grows the buffer once if it was too small."""
         for _ in range(2):
-            hits = np.zeros((max(capacity, 1), 2), np.uint32)
+            hits = np.empty((max(capacity, 1), 2), np.uint32)
             n_hits = C.c_uint64(0)
             rc = self.lib.vdf_search_refs_device(self.ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes,
                                                  d_ref_durations, n_ref, int(tol_int), ref_index_base,
@@ -157,7 +157,7 @@ class Engine:
                 capacity = int(n_hits.value)
                 continue
             self._check(rc)
-            return hits[: int(n_hits.value)], int(n_hits.value)
+            return hits[: int(n_hits.value)].copy(), int(n_hits.value)
         raise VdfError(_capi.VDF_E_OVERFLOW, "hit buffer overflow")
 
 
