@@ -84,3 +84,41 @@ def test_hundred_thousand_frame_stacks(engine):
     # hashes of iid clips are ~uniform: mean popcount close to 500
     pop = np.unpackbits(out1[:2000].cpu().numpy().view(np.uint8), axis=1).sum(axis=1).mean()
     assert 480 < pop < 520
+
+
+def test_refs_one_million_by_hundred_thousand(engine):
+    """configs[4] shape: 1 M candidates x 100 k references, log-uniform durations (+-5 % windows), tolerance 350.
+    Half of the references are near-copies of candidates (<= 300 flipped bits, same duration): each must find its
+    source; a sample of references is checked against the oracle exactly."""
+    n_cand, n_ref = 1_000_000, 100_000
+    rng = np.random.default_rng(20250615)
+    cw = hg.random_hashes(rng, n_cand)
+    cd = np.sort(np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n_cand))).astype(np.uint32))
+    src = rng.choice(n_cand, size=n_ref // 2, replace=False)
+    rw = np.concatenate([cw[src].copy(), hg.random_hashes(rng, n_ref - n_ref // 2)])
+    rd = np.concatenate([cd[src], np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n_ref - n_ref // 2))).astype(np.uint32)])
+    flips = rng.integers(0, 301, size=n_ref // 2)
+    for i in range(n_ref // 2):  # flip `flips[i]` distinct bits
+        pos = rng.choice(1024, size=int(flips[i]), replace=False)
+        np.bitwise_xor.at(rw[i], pos >> 6, np.uint64(1) << (pos & 63).astype(np.uint64))
+    perm = rng.permutation(n_ref)
+    rw, rd, origin = rw[perm], rd[perm], np.concatenate([src, np.full(n_ref - n_ref // 2, -1)])[perm]
+    t = [torch.from_numpy(a).cuda() for a in (cw.view(np.int64), cd.view(np.int32), rw.view(np.int64), rd.view(np.int32))]
+    torch.cuda.synchronize()
+    hits, n_hits = engine.search_refs_device(t[0].data_ptr(), t[1].data_ptr(), n_cand, t[2].data_ptr(), t[3].data_ptr(),
+                                             n_ref, 350)
+    st = engine.last_stats()
+    assert st["pairs"] == ve.count_pairs_refs(cd, rd)
+    assert n_hits == len(hits) and np.all(np.diff(hits[:, 0].astype(np.int64)) >= 0)  # sorted by reference
+    found = set(map(tuple, hits.tolist()))
+    planted = [(int(r), int(origin[r])) for r in range(n_ref) if origin[r] >= 0]
+    assert all(p in found for p in planted)
+    assert len(found) == len(planted)  # random 1000-bit hashes never come within 350 of each other
+    groups = ve.groups_from_ref_hits(hits)
+    assert [g[0] for g in groups] == sorted(r for r, _ in planted)
+    sample = rng.choice(n_ref, size=200, replace=False)
+    want = orc.search_refs_sorted(cw, cd, rw[sample], rd[sample], 350)
+    got = {r: m for r, m in groups}
+    assert [(int(sample[k]), m) for k, m in want] == [(int(sample[k]), got[int(sample[k])]) for k, _ in want]
+    print(f"refs: {st['pairs']:.3g} admitted pairs, kernel {st['kernel_ms']:.2f} ms, "
+          f"{st['pairs'] / st['kernel_ms'] * 1e3:.3g} pairs/s in-kernel ({engine.backend})")

@@ -174,3 +174,18 @@ def test_public_api_matches_oracle(engine):
     want_r = orc.search_with_references(words[:40], dur[:40], paths[:40], words[20:], dur[20:], paths[20:], 0.2)
     assert [(g.reference(), list(g.duplicates())) for g in got_r] == want_r
     assert vdf.search([], 1.0, engine=engine) == []
+
+
+@pytest.mark.parametrize("n", [1, 31, 257, 700])
+def test_large_tolerances_match_everything(engine, n):
+    """tolerance >= 0.5: the fp4 backend's threshold 1024 - 2 tol goes <= 0, so even its zero padding rows/columns
+    pass the fast test; the window checks must still reject them.  tolerance 1.0 matches every pair."""
+    rng = np.random.default_rng(900 + n)
+    w = hg.random_hashes(rng, n)
+    d = np.sort(rng.integers(100, 140, size=n).astype(np.uint32))
+    for tol in (512, 700, 1024, 5000):
+        _both_self(engine, w, d, tol)
+    rw = hg.random_hashes(rng, 9)
+    rd = rng.integers(90, 150, size=9).astype(np.uint32)
+    for tol in (600, 1024):
+        _both_refs(engine, w, d, rw, rd, tol)

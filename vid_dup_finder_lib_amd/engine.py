@@ -18,12 +18,10 @@ UINT32_MAX = 0xFFFFFFFF
 
 
 def _groups_to_lists(g: VdfGroups) -> List[Tuple[int, List[int]]]:
-    out = []
-    n = int(g.n_groups)
-    for i in range(n):
-        a, b = int(g.offsets[i]), int(g.offsets[i + 1])
-        out.append((int(g.ref_index[i]), [int(g.members[k]) for k in range(a, b)]))
-    return out
+    offsets, members, refs = groups_to_arrays(g)
+    offs = offsets.tolist()
+    mem = members.tolist()
+    return [(int(refs[i]), mem[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
 
 
 def groups_to_arrays(g: VdfGroups):
