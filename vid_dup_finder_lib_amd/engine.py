@@ -65,6 +65,14 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------ helpers
+    def _hit_buffer(self, capacity: int) -> np.ndarray:
+        """Reusable host staging buffer for hit lists (a fresh 32 MB allocation per call costs ~10 ms)."""
+        buf = getattr(self, "_hits", None)
+        if buf is None or buf.shape[0] < max(capacity, 1):
+            buf = np.empty((max(capacity, 1), 2), np.uint32)
+            self._hits = buf
+        return buf
+
     def _check(self, rc: int):
         if rc != _capi.VDF_OK:
             raise VdfError(rc, (self.lib.vdf_last_error(self.ctx) or b"").decode())
@@ -131,7 +139,7 @@ class Engine:
                            shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
         """Thresholded adjacency of this shard's row tiles: (hits [k,2] u32 sorted, n_hits, overflow_row)."""
-        hits = np.empty((max(capacity, 1), 2), np.uint32)  # filled by the library up to n_hits
+        hits = self._hit_buffer(capacity)  # filled by the library up to n_hits
         n_hits = C.c_uint64(0)
         overflow = C.c_uint32(0)
         self._check(self.lib.vdf_search_self_device(self.ctx, d_hashes, d_durations, n, int(tol_int), shard_index,
@@ -146,7 +154,7 @@ class Engine:
                            capacity: int = 1 << 22, stream: int = 0):
         """(hits [k,2] u32 sorted by (ref, cand), n_hits).  Grows the buffer once if it was too small."""
         for _ in range(2):
-            hits = np.empty((max(capacity, 1), 2), np.uint32)
+            hits = self._hit_buffer(capacity)
             n_hits = C.c_uint64(0)
             rc = self.lib.vdf_search_refs_device(self.ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes,
                                                  d_ref_durations, n_ref, int(tol_int), ref_index_base,
