@@ -119,6 +119,30 @@ int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_cl
                               uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,
                               uint32_t *d_out_dontcare, void *stream);
 
+/* ---- letterbox crop detection + cropped hashing (the step right before from_frames) -------------
+ * Replaces crop_video_frames with Cropdetect::Letterbox, the builder's default
+ * (src/video_hashing/video_hash_builder.rs:188-212,59): cropdetect_letterbox
+ * (vid_dup_finder_common/src/video_frames_gray.rs:201-210: frames 0 and 8, letterbox_crop with
+ * AnyColour(16), :38-128, crops united by per-edge minimum, crop.rs:53-68), then every frame is
+ * cropped and handed to from_frames.  Here the crop box is read in place: no cropped copies.
+ * Crops are 4 x uint32 per clip: left, right, top, bottom edge offsets (crop.rs:3-10). */
+int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                    uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                    uint32_t *d_crops /* DEVICE [n_clips][4] */, void *stream);
+/* crops: HOST [n_clips][4] (NULL or all zero = no crop).  l + r >= w or t + b >= h -> VDF_E_INVAL. */
+int vdf_hash_frames_u8_cropped_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                      uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                      const uint32_t *crops, uint64_t *d_out_hashes, uint32_t *d_out_dontcare,
+                                      void *stream);
+/* detect + crop + hash in one call; out_crops (HOST, nullable) receives the detected boxes. */
+int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                        uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                        uint64_t *d_out_hashes, uint32_t *d_out_dontcare, uint32_t *out_crops,
+                                        void *stream);
+int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip,
+                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                                 uint32_t *out_crops, uint32_t *out_dontcare);
+
 /* ---- search(): replaces Search::search_self, search_algorithm.rs:81-171 (hot loop :150-156) --
  * hashes: n x 16 words, durations: n, both in sorted order.  tol_int from vdf_tolerance_int().
  * Groups come back exactly as search() builds them (video_dup_finder.rs:7-13): members = hits in

@@ -12,6 +12,9 @@
  *     134-315, src/video_hashing/video_hash.rs:325-371,
  *     src/video_hashing/search_algorithm.rs:203-208), restated in
  *     tests/test_oracle_reference_scenarios.py.
+ *   letterbox crop detection: pinned by the reference's known-answer tests
+ *     (vid_dup_finder_common/src/video_frames_gray.rs:216-459), restated in
+ *     tests/test_oracle_letterbox.py.
  *   hash bits (resize + 3-D DCT): PARITY UNPINNED.  The reference is Rust
  *     (no cargo/rustc here), its tests hold no known-answer hash vector, and
  *     the arithmetic lives in un-vendored crates (rustdct "0.7",
@@ -475,4 +478,77 @@ uint64_t vdf_oracle_pairs_self(const uint32_t *dur, size_t n)
         pairs += rhs - (i + 1);
     }
     return pairs;
+}
+
+/* ------------------------------------------------------------------------
+ * Letterbox crop detection (the step right before the path).
+ * vid_dup_finder_common/src/video_frames_gray.rs:38-128 (letterbox_crop with
+ * LetterboxColour::AnyColour(tol)) and :201-210 (cropdetect_letterbox: frames
+ * 0, 8, 16, .. at most 8 of them, crops united = per-edge minimum,
+ * crop.rs:53-68).  Pinned by the reference's own known-answer tests
+ * (video_frames_gray.rs:216-459), restated in tests/test_oracle_letterbox.py.
+ * ---------------------------------------------------------------------- */
+static int strip_is_letterbox(const uint8_t *p, size_t step, uint32_t len, uint32_t tol)
+{
+    uint32_t hist[256];
+    memset(hist, 0, sizeof hist);
+    for (uint32_t i = 0; i < len; i++) hist[p[(size_t)i * step]]++;
+    uint32_t mode = 0, best = 0;
+    for (uint32_t v = 0; v < 256; v++) /* Iterator::max_by_key keeps the LAST maximum */
+        if (hist[v] >= best) { best = hist[v]; mode = v; }
+    uint32_t lo = mode > tol ? mode - tol : 0, hi = mode + tol > 255 ? 255 : mode + tol, count = 0;
+    for (uint32_t v = lo; v <= hi; v++) count += hist[v];
+    return (double)count / (double)len > 0.9; /* min_proportion, :66,95-98 */
+}
+
+/* out = {left, right, top, bottom}; pitch in bytes. */
+void vdf_oracle_letterbox_crop(const uint8_t *frame, uint32_t w, uint32_t h, size_t pitch, uint32_t tol, uint32_t *out)
+{
+    uint32_t l = 0, r = 0, t = 0, b = 0;
+    while (l < w && strip_is_letterbox(frame + l, pitch, h, tol)) l++;
+    while (r < w && strip_is_letterbox(frame + (w - r - 1), pitch, h, tol)) r++;
+    while (t < h && strip_is_letterbox(frame + (size_t)t * pitch, 1, w, tol)) t++;
+    while (b < h && strip_is_letterbox(frame + (size_t)(h - b - 1) * pitch, 1, w, tol)) b++;
+    if ((int64_t)w - l - r >= 1 && (int64_t)h - t - b >= 1) { /* :119-127 */
+        out[0] = l; out[1] = r; out[2] = t; out[3] = b;
+    } else {
+        out[0] = out[1] = out[2] = out[3] = 0;
+    }
+}
+
+/* cropdetect_letterbox over a clip: frames 0, 8, ... (step_by(8).take(8)), tol 16.  Returns 0, or
+ * ORACLE_E_NOT_ENOUGH_FRAMES for an empty clip (detect_crop -> None, video_hash_builder.rs:195). */
+int vdf_oracle_cropdetect_letterbox(const uint8_t *frames, uint32_t n_frames, uint32_t w, uint32_t h,
+                                    size_t frame_stride, uint32_t *out)
+{
+    if (n_frames == 0) return ORACLE_E_NOT_ENOUGH_FRAMES;
+    uint32_t acc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t used = 0;
+    for (uint32_t f = 0; f < n_frames && used < 8; f += 8, used++) {
+        uint32_t c[4];
+        vdf_oracle_letterbox_crop(frames + (size_t)f * frame_stride, w, h, w, 16, c);
+        for (int k = 0; k < 4; k++) acc[k] = c[k] < acc[k] ? c[k] : acc[k];
+    }
+    memcpy(out, acc, sizeof acc);
+    return ORACLE_OK;
+}
+
+/* crop_video_frames + from_frames (video_hash_builder.rs:188-204,222): detect, copy the crop box out of every
+ * frame, hash the cropped frames. */
+int vdf_oracle_hash_clip_letterbox(const uint8_t *frames, uint32_t n_frames, uint32_t w, uint32_t h, size_t frame_stride,
+                                   uint64_t *out_hash, double *out_coefs, uint32_t *out_crop)
+{
+    uint32_t c[4];
+    int rc = vdf_oracle_cropdetect_letterbox(frames, n_frames, w, h, frame_stride, c);
+    if (rc) return rc;
+    if (out_crop) memcpy(out_crop, c, sizeof c);
+    const uint32_t cw = w - c[0] - c[1], ch = h - c[2] - c[3];
+    const uint32_t nf = n_frames < DCT_SIZE ? n_frames : DCT_SIZE;
+    uint8_t *buf = (uint8_t *)malloc((size_t)cw * ch * (nf ? nf : 1));
+    for (uint32_t f = 0; f < nf; f++)
+        for (uint32_t y = 0; y < ch; y++)
+            memcpy(buf + ((size_t)f * ch + y) * cw, frames + (size_t)f * frame_stride + (size_t)(y + c[2]) * w + c[0], cw);
+    rc = vdf_oracle_hash_clip(buf, nf, cw, ch, (size_t)cw * ch, out_hash, out_coefs);
+    free(buf);
+    return rc;
 }

@@ -71,6 +71,13 @@ def lib() -> C.CDLL:
                                              i64p, u64p]
         L.vdf_oracle_pairs_self.restype = C.c_uint64
         L.vdf_oracle_pairs_self.argtypes = [u32p, C.c_size_t]
+        L.vdf_oracle_letterbox_crop.restype = None
+        L.vdf_oracle_letterbox_crop.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, u32p]
+        L.vdf_oracle_cropdetect_letterbox.restype = C.c_int
+        L.vdf_oracle_cropdetect_letterbox.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, u32p]
+        L.vdf_oracle_hash_clip_letterbox.restype = C.c_int
+        L.vdf_oracle_hash_clip_letterbox.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t, u64p,
+                                                     C.POINTER(C.c_double), u32p]
         _lib = L
     return _lib
 
@@ -162,6 +169,40 @@ def hash_clips_with_coefs(frames: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         hs.append(h)
         cs.append(c)
     return np.stack(hs), np.stack(cs)
+
+
+# ------------------------------------------------------------ letterbox crop
+def letterbox_crop(frame: np.ndarray, tol: int = 16):
+    """(left, right, top, bottom) of one HxW u8 frame, LetterboxColour::AnyColour(tol)
+    (vid_dup_finder_common/src/video_frames_gray.rs:38-128)."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w = frame.shape
+    out = np.zeros(4, np.uint32)
+    lib().vdf_oracle_letterbox_crop(_p(frame, C.c_uint8), w, h, w, int(tol), _p(out, C.c_uint32))
+    return tuple(int(x) for x in out)
+
+
+def cropdetect_letterbox(frames: np.ndarray):
+    """Clip-level crop (video_frames_gray.rs:201-210): frames 0, 8, .. united.  frames [n, H, W] u8."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w = frames.shape
+    out = np.zeros(4, np.uint32)
+    rc = lib().vdf_oracle_cropdetect_letterbox(_p(frames, C.c_uint8), n, w, h, w * h, _p(out, C.c_uint32))
+    if rc:
+        raise ValueError(f"cropdetect failed: {rc}")
+    return tuple(int(x) for x in out)
+
+
+def hash_clip_letterbox(frames: np.ndarray, want_coefs: bool = False):
+    """crop_video_frames + from_frames (video_hash_builder.rs:188-204,222) -> (rc, hash, coefs|None, crop)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w = frames.shape
+    out = np.zeros(HASH_WORDS, np.uint64)
+    crop = np.zeros(4, np.uint32)
+    coefs = np.zeros(HASH_BITS, np.float64) if want_coefs else None
+    rc = lib().vdf_oracle_hash_clip_letterbox(_p(frames, C.c_uint8), n, w, h, w * h, _p(out, C.c_uint64),
+                                              _p(coefs, C.c_double) if want_coefs else None, _p(crop, C.c_uint32))
+    return rc, out, coefs, tuple(int(x) for x in crop)
 
 
 # -------------------------------------------------------------------- search

@@ -55,3 +55,9 @@ def test_errors_mirror_the_reference_enum():
     with pytest.raises(vdf.NotEnoughFrames):
         vdf.VideoHash.from_frames([], "p", 1)
     assert vdf.search([], 0.3) == [] and vdf.search_with_references([], [], 0.3) == []
+
+
+def test_gen_hashes_option_mapping():
+    assert vdf.Cropdetect.LETTERBOX.value == "letterbox"
+    with pytest.raises(vdf.VidProc):
+        vdf.gen_hashes(np.zeros((1, 16, 8, 8), np.uint8), ["p"], [1], cropdetect=vdf.Cropdetect.MOTION)

@@ -9,6 +9,7 @@ seconds) is exactly the input of VideoHash.from_frames below.
 """
 from __future__ import annotations
 
+import enum
 import itertools
 import os
 from typing import Iterable, Iterator, List, Optional, Sequence
@@ -19,7 +20,7 @@ from . import _capi
 from ._capi import DEFAULT_SEARCH_TOLERANCE, HASH_BITS, HASH_WORDS, TOLERANCE_SCALING_FACTOR, VdfError
 from .engine import Engine, hamming_distance_words, tolerance_int
 
-__all__ = ["VideoHash", "MatchGroup", "Error", "NotEnoughFrames", "NotVideo", "VidProc", "TooFewEntries", "search",
+__all__ = ["Cropdetect", "gen_hashes", "VideoHash", "MatchGroup", "Error", "NotEnoughFrames", "NotVideo", "VidProc", "TooFewEntries", "search",
            "search_with_references", "default_engine", "hash_frame_stacks", "rust_path_key", "sort_order",
            "DEFAULT_SEARCH_TOLERANCE", "TOLERANCE_SCALING_FACTOR"]
 
@@ -42,6 +43,14 @@ class VidProc(Error):
 class NotEnoughFrames(Error):
     def __init__(self):
         super().__init__("Could not extract enough frames")
+
+
+class Cropdetect(enum.Enum):
+    """vid_dup_finder_lib/src/definitions.rs:47-54.  Motion-based detection (vid_dup_finder_common/src/motioncrop/)
+    is not on the accelerated path."""
+    NONE = "none"
+    LETTERBOX = "letterbox"
+    MOTION = "motion"
 
 
 class TooFewEntries(Exception):
@@ -275,5 +284,26 @@ def hash_frame_stacks(frames: np.ndarray, src_paths: Sequence, durations: Sequen
     except VdfError as e:
         if e.code == _capi.VDF_E_NOT_ENOUGH_FRAMES:
             raise NotEnoughFrames() from e
+        raise
+    return [VideoHash(words[i], src_paths[i], durations[i]) for i in range(len(words))]
+
+
+def gen_hashes(frames: np.ndarray, src_paths: Sequence, durations: Sequence[int],
+               cropdetect: Cropdetect = Cropdetect.LETTERBOX, engine: Optional[Engine] = None) -> List[VideoHash]:
+    """The part of `gen_hash` after decode (video_hash_builder.rs:214-223) for a batch of clips:
+    crop_video_frames(cropdetect) -- default Letterbox, like CreationOptions::default (:55-63) -- then
+    VideoHash::from_frames.  frames [n_clips, n_frames >= 16, H, W] u8.  Detection (frames 0 and 8,
+    video_frames_gray.rs:201-210) and the cropped resize both run on the GPU; no cropped copies are made."""
+    if cropdetect == Cropdetect.NONE:
+        return hash_frame_stacks(frames, src_paths, durations, engine)
+    if cropdetect != Cropdetect.LETTERBOX:
+        raise VidProc("Cropdetect::Motion is not supported by the accelerated path")
+    try:
+        words, _crops = (engine or default_engine()).hash_frames_letterbox(frames)
+    except VdfError as e:
+        if e.code == _capi.VDF_E_NOT_ENOUGH_FRAMES:
+            raise NotEnoughFrames() from e
+        if e.code == _capi.VDF_E_BAD_DIMS:
+            raise VidProc(str(e)) from e
         raise
     return [VideoHash(words[i], src_paths[i], durations[i]) for i in range(len(words))]

@@ -63,7 +63,7 @@ struct vdf_ctx {
     DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
     DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
     // hash scratch
-    DevBuf small, frames, out_hashes, out_dc, cos_table;
+    DevBuf small, frames, out_hashes, out_dc, cos_table, crops, crop_desc, crop_tables;
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
@@ -86,7 +86,7 @@ struct vdf_ctx {
         }
         DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                          &hits, &perm, &matched, &exp_cols, &exp_rows, &group_cmin, &group_offset, &group_blocks, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
-                         &out_hashes, &out_dc, &cos_table};
+                         &out_hashes, &out_dc, &cos_table, &crops, &crop_desc, &crop_tables};
         for (DevBuf *b : all) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -305,6 +305,19 @@ vdf::ResizeAxisTable dev_view(const DeviceAxisTable *t)
     return v;
 }
 
+int ensure_cos_table(vdf_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->cos_table.p) return VDF_OK;
+    double tab[16 * 16 + 17];  // [k][n] matrix, then the 17 magnitudes cos(m pi / 32)
+    for (int k = 0; k < 16; k++)
+        for (int n = 0; n < 16; n++) tab[k * 16 + n] = std::cos(M_PI * (double)k * ((double)n + 0.5) / 16.0);
+    for (int m = 0; m < 17; m++) tab[256 + m] = std::cos(M_PI * (double)m / 32.0);
+    int rc = upload(ctx, ctx->cos_table, tab, sizeof tab, stream);
+    if (rc) return rc;
+    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    return VDF_OK;
+}
+
 int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
                        uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out, uint32_t *d_dc,
                        hipStream_t stream)
@@ -316,14 +329,9 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
     if (n_clips > 0x7FFFFFFull) return fail(ctx, VDF_E_INVAL, "too many clips in one call");
     if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->cos_table.p) {
-        double tab[16 * 16 + 17];  // [k][n] matrix, then the 17 magnitudes cos(m pi / 32)
-        for (int k = 0; k < 16; k++)
-            for (int n = 0; n < 16; n++) tab[k * 16 + n] = std::cos(M_PI * (double)k * ((double)n + 0.5) / 16.0);
-        for (int m = 0; m < 17; m++) tab[256 + m] = std::cos(M_PI * (double)m / 32.0);
-        int rc = upload(ctx, ctx->cos_table, tab, sizeof tab, stream);
-        if (rc) return rc;
-        VDF_HIP(ctx, hipStreamSynchronize(stream));
+    {
+        int rc0 = ensure_cos_table(ctx, stream);
+        if (rc0) return rc0;
     }
     const bool direct = (w == VDF_DCT_SIZE && h == VDF_DCT_SIZE && ((uintptr_t)d_frames % 16) == 0 &&
                          frame_stride % 16 == 0 && clip_stride % 16 == 0);
@@ -386,6 +394,86 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
     VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(),
                                       d_out, d_dc, stream));
     return VDF_OK;
+}
+
+// Hash clips whose crop boxes (HOST array [n_clips][4] = left, right, top, bottom; null = no crop) are read in place.
+int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                        uint32_t h, size_t frame_stride, size_t clip_stride, const uint32_t *crops, uint64_t *d_out,
+                        uint32_t *d_dc, hipStream_t stream)
+{
+    bool any = false;
+    if (crops)
+        for (size_t i = 0; i < n_clips * 4 && !any; i++) any = crops[i] != 0;
+    if (!any)  // the common case: the fused / persistent kernels
+        return hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_out, d_dc, stream);
+    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
+    if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n_clips > 0x7FFFFFFull) return fail(ctx, VDF_E_INVAL, "too many clips in one call");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        int rc0 = ensure_cos_table(ctx, stream);
+        if (rc0) return rc0;
+    }
+    std::vector<vdf::CropClipDesc> desc(n_clips);
+    std::vector<vdf::CropTableEntry> entries;
+    std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
+    auto entry_for = [&](uint32_t size, bool vertical, int *rc) -> uint32_t {
+        const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        DeviceMfmaTable *t = mfma_table(ctx, size, vertical, stream, rc);
+        if (*rc) return 0;
+        if (!t->host.ok) { *rc = fail(ctx, VDF_E_BAD_DIMS, "crop box size whose coefficients do not fit the i8 split"); return 0; }
+        vdf::CropTableEntry e{t->operand.p, t->bias.as<int32_t>(), t->host.n_tiles, t->host.precision};
+        entries.push_back(e);
+        index[key] = (uint32_t)entries.size() - 1;
+        return (uint32_t)entries.size() - 1;
+    };
+    for (size_t c = 0; c < n_clips; c++) {
+        const uint32_t l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
+        if ((uint64_t)l + r >= w || (uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
+        int rc = VDF_OK;
+        desc[c].x0 = l; desc[c].y0 = t; desc[c].w = w - l - r; desc[c].h = h - t - b;
+        desc[c].h_table = entry_for(desc[c].w, false, &rc);
+        if (rc) return rc;
+        desc[c].v_table = entry_for(desc[c].h, true, &rc);
+        if (rc) return rc;
+    }
+    int rc = upload(ctx, ctx->crop_desc, desc.data(), desc.size() * sizeof(vdf::CropClipDesc), stream);
+    if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, entries.data(), entries.size() * sizeof(vdf::CropTableEntry), stream);
+    if (rc) return rc;
+    VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
+    const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
+    VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+    VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_clips, w, frame_stride, clip_stride, buf_end,
+                                                 ctx->crop_desc.as<vdf::CropClipDesc>(),
+                                                 ctx->crop_tables.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), stream));
+    VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out,
+                                      d_dc, stream));
+    return VDF_OK;
+}
+
+int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out,
+                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream)
+{
+    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
+    if (n_clips == 0) return VDF_OK;
+    if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
+    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
+                                       ctx->crops.as<uint32_t>(), stream));
+    std::vector<uint32_t> crops(n_clips * 4);
+    VDF_HIP(ctx, hipMemcpyAsync(crops.data(), ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    if (out_crops) std::memcpy(out_crops, crops.data(), n_clips * 16);
+    return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops.data(),
+                               d_out, d_dc, stream);
 }
 
 }  // namespace
@@ -523,6 +611,81 @@ int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint
                                     hipMemcpyDeviceToHost, s));
         if (out_dontcare)
             VDF_HIP(ctx, hipMemcpyAsync(out_dontcare + c0, ctx->out_dc.p, nb * 4, hipMemcpyDeviceToHost, s));
+        VDF_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return VDF_OK;
+}
+
+int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                    uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint32_t *d_crops,
+                                    void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (frames_per_clip == 0) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "no frames to detect a crop on");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (n_clips == 0) return VDF_OK;
+    if (!d_frames || !d_crops) return fail(ctx, VDF_E_INVAL, "null pointer");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_crops,
+                                       stream ? (hipStream_t)stream : ctx->stream));
+    return VDF_OK;
+}
+
+int vdf_hash_frames_u8_cropped_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                      uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                      const uint32_t *crops, uint64_t *d_out_hashes, uint32_t *d_out_dontcare,
+                                      void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops,
+                               d_out_hashes, d_out_dontcare, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                        uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                        uint64_t *d_out_hashes, uint32_t *d_out_dontcare, uint32_t *out_crops,
+                                        void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return letterbox_hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
+                                        d_out_hashes, d_out_dontcare, out_crops,
+                                        stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip,
+                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                                 uint32_t *out_crops, uint32_t *out_dontcare)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
+    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
+    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
+    if (n_clips == 0) return VDF_OK;
+    if (!frames || !out_hashes) return fail(ctx, VDF_E_INVAL, "null pointer");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, (512ull << 20) / cbytes));
+    VDF_HIP(ctx, ctx->frames.reserve(batch * cbytes));
+    VDF_HIP(ctx, ctx->out_hashes.reserve(batch * VDF_HASH_WORDS * 8));
+    VDF_HIP(ctx, ctx->out_dc.reserve(batch * 4));
+    for (size_t c0 = 0; c0 < n_clips; c0 += batch) {
+        const size_t nb = std::min(batch, n_clips - c0);
+        for (size_t c = 0; c < nb; c++)
+            VDF_HIP(ctx, hipMemcpy2DAsync(ctx->frames.as<uint8_t>() + c * cbytes, fbytes, frames + (c0 + c) * clip_stride,
+                                          frame_stride, fbytes, VDF_DCT_SIZE, hipMemcpyHostToDevice, s));
+        int rc = letterbox_hash_device_locked(ctx, ctx->frames.as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
+                                              ctx->out_hashes.as<uint64_t>(),
+                                              out_dontcare ? ctx->out_dc.as<uint32_t>() : nullptr,
+                                              out_crops ? out_crops + 4 * c0 : nullptr, s);
+        if (rc) return rc;
+        VDF_HIP(ctx, hipMemcpyAsync(out_hashes + c0 * VDF_HASH_WORDS, ctx->out_hashes.p, nb * VDF_HASH_WORDS * 8,
+                                    hipMemcpyDeviceToHost, s));
+        if (out_dontcare) VDF_HIP(ctx, hipMemcpyAsync(out_dontcare + c0, ctx->out_dc.p, nb * 4, hipMemcpyDeviceToHost, s));
         VDF_HIP(ctx, hipStreamSynchronize(s));
     }
     return VDF_OK;

@@ -1,0 +1,103 @@
+// Letterbox crop detection on the device (the step right before the hot path).
+//
+// Replaces vid_dup_finder_common/src/video_frames_gray.rs:38-128 (letterbox_crop, LetterboxColour::AnyColour(16))
+// and :201-210 (cropdetect_letterbox: frames 0 and 8 of the 16 a clip contributes, crops united by per-edge
+// minimum, crop.rs:53-68), as driven by vid_dup_finder_lib/src/video_hashing/video_hash_builder.rs:188-212.
+//
+// One workgroup per probed frame; wave 0/1/2/3 walks in from the left/right/top/bottom edge and stops at the
+// first strip that is not letterbox, exactly like the reference's take_while.  A strip is letterbox when more
+// than 90 % of its pixels are within +-tol of the strip's mode (ties: the LAST maximum, Iterator::max_by_key).
+// Integer histogram per strip in LDS, one f64 compare: bit-exact with the oracle.
+#include "vdf_internal.h"
+
+namespace vdf {
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+// hist: this wave's 256-bin LDS histogram.  All 64 lanes must call.
+__device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p, size_t step, uint32_t len,
+                                                   uint32_t tol, uint32_t *hist)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; k++) hist[lane + 64 * k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < len; i += 64) atomicAdd(&hist[p[(size_t)i * step]], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t h[4], key = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        h[k] = hist[lane + 64 * k];
+        key = max(key, (h[k] << 8) | (lane + 64 * k));  // max count, ties -> the larger value (the LAST maximum)
+    }
+    const uint32_t mode = wave_max_u32(key) & 255u;
+    const uint32_t lo = mode > tol ? mode - tol : 0u, hi = min(mode + tol, 255u);
+    uint32_t count = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v = lane + 64 * k;
+        if (v >= lo && v <= hi) count += h[k];
+    }
+    count = wave_sum_u32(count);
+    __builtin_amdgcn_wave_barrier();
+    return (double)count / (double)len > 0.9;
+}
+
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
+                                                        size_t frame_stride, size_t clip_stride, uint32_t n_probe,
+                                                        uint32_t tol, uint32_t *__restrict__ crops)
+{
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_edge[4];
+    const size_t clip = blockIdx.x / n_probe;
+    const uint32_t probe = blockIdx.x % n_probe;  // frame 8 * probe
+    const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * probe) * frame_stride;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t *hist = s_hist[wave];
+    uint32_t n = 0;
+    if (wave == 0) {
+        while (n < W && strip_is_letterbox(f + n, W, H, tol, hist)) n++;
+    } else if (wave == 1) {
+        while (n < W && strip_is_letterbox(f + (W - n - 1), W, H, tol, hist)) n++;
+    } else if (wave == 2) {
+        while (n < H && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) n++;
+    } else {
+        while (n < H && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) n++;
+    }
+    if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t l = s_edge[0], r = s_edge[1], t = s_edge[2], b = s_edge[3];
+        // video_frames_gray.rs:119-127: converging edges (e.g. a uniform frame) mean "no crop"
+        const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
+        atomicMin(&crops[clip * 4 + threadIdx.x], ok ? s_edge[threadIdx.x] : 0u);  // union = per-edge minimum
+    }
+}
+
+hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    const uint32_t nf = frames_per_clip < VDF_DCT_SIZE ? frames_per_clip : VDF_DCT_SIZE;  // the builder keeps 16 frames
+    const uint32_t n_probe = (nf + 7) / 8;                                                // frames 0, 8
+    hipError_t e = hipMemsetAsync(crops, 0xFF, n_clips * 4 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(letterbox_kernel, dim3((uint32_t)(n_clips * n_probe)), dim3(256), 0, stream, frames, w, h,
+                       frame_stride, clip_stride, n_probe, 16u, crops);
+    return hipGetLastError();
+}
+
+}  // namespace vdf

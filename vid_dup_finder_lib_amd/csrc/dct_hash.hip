@@ -290,8 +290,9 @@ __device__ __forceinline__ uint32_t finalize4(v4i hi, v4i lo, int prec)
 template <bool CAREFUL>
 __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
                                                   const uint8_t *buf_end, const MfmaResizeTables &T, int rg_begin,
-                                                  int rg_step, v4i &acc_vh, v4i &acc_vl)
+                                                  int rg_step, v4i &acc_vh, v4i &acc_vl, size_t pitch = 0)
 {
+    if (pitch == 0) pitch = W;  // tightly packed rows unless a crop box is read in place
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
     const int32_t bias_h = T.bias_h[r16];
     for (int rg = rg_begin; rg < T.n_rg; rg += rg_step) {
@@ -305,7 +306,7 @@ __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ sr
             for (int m = 0; m < 4; m++) {
                 const uint32_t row = 64u * rg + 16u * m + r16;
                 v4i a = {0, 0, 0, 0};
-                if (row < H && x < W) a = load_pixels16<CAREFUL>(src + (size_t)row * W + x, buf_end);
+                if (row < H && x < W) a = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
                 a ^= (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
                 ah[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah[m], 0, 0, 0);
                 al[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al[m], 0, 0, 0);
@@ -497,6 +498,65 @@ hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_
     if (n_clips == 0) return hipSuccess;
     hipLaunchKernelGGL(dct_hash_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, small, small_clip_stride,
                        small_frame_stride, cos_table, out_hashes, out_dontcare);
+    return hipGetLastError();
+}
+
+// Cropped clips (letterbox crop box read in place: no cropped copy of the frames is ever made).  Every clip may have
+// its own box, hence its own coefficient tables: a per-clip descriptor names the box and the two table entries.
+__global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
+                                                                  size_t frame_stride, size_t clip_stride,
+                                                                  const uint8_t *buf_end,
+                                                                  const CropClipDesc *__restrict__ desc,
+                                                                  const CropTableEntry *__restrict__ tables,
+                                                                  uint8_t *__restrict__ small)
+{
+    __shared__ int32_t s_part[3][2][64][4];
+    const size_t clip = blockIdx.x >> 4;
+    const uint32_t f = blockIdx.x & 15;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const CropClipDesc d = desc[clip];
+    const CropTableEntry th = tables[d.h_table], tv = tables[d.v_table];
+    MfmaResizeTables T;
+    T.bh = reinterpret_cast<const v4i *>(th.operand);
+    T.av = reinterpret_cast<const v4i *>(tv.operand);
+    T.bias_h = th.bias;
+    T.bias_v = tv.bias;
+    T.prec_h = th.precision;
+    T.prec_v = tv.precision;
+    T.n_kt = th.n_tiles;
+    T.n_rg = tv.n_tiles;
+    v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+    const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
+    // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very
+    // end of the buffer needs the careful loader
+    if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_groups<true>(src, d.w, d.h, buf_end, T, (int)wave, 4, vh, vl, pitch);
+    else resize_row_groups<false>(src, d.w, d.h, buf_end, T, (int)wave, 4, vh, vl, pitch);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            vl[r] += T.bias_v[4 * g + r];
+#pragma unroll
+            for (int w = 0; w < 3; w++) { vh[r] += s_part[w][0][lane][r]; vl[r] += s_part[w][1][lane][r]; }
+        }
+        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+        uint8_t *dst = small + (clip * 16 + f) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+    }
+}
+
+hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
+                                      size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
+                                      const CropTableEntry *tables, uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    hipLaunchKernelGGL(resize_mfma_cropped_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, pitch,
+                       frame_stride, clip_stride, buf_end, desc, tables, small);
     return hipGetLastError();
 }
 

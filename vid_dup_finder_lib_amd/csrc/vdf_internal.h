@@ -80,6 +80,21 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
 hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                      size_t frame_stride, size_t clip_stride, const uint8_t *buf_end,
                                      const MfmaResizeArgs &a, uint8_t *small, hipStream_t stream);
+// ---- letterbox crop detection + cropped resize -------------------------------------------
+struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
+    uint32_t x0, y0, w, h;
+    uint32_t h_table, v_table;
+};
+struct CropTableEntry {  // one MFMA-layout axis table (device pointers)
+    const void *operand;
+    const int32_t *bias;
+    int32_t n_tiles, precision;
+};
+hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
+hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
+                                      size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
+                                      const CropTableEntry *tables, uint8_t *small, hipStream_t stream);
 hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream);
 

@@ -108,6 +108,43 @@ class Engine:
         self._check(self.lib.vdf_hash_frames_u8_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, fs, cs,
                                                        d_out, d_dontcare or None, stream or None))
 
+    def hash_frames_letterbox(self, frames: np.ndarray, want_dontcare: bool = False):
+        """crop_video_frames(Cropdetect::Letterbox) + from_frames (video_hash_builder.rs:188-223) for a batch:
+        frames [n_clips, n_frames >= 16, H, W] u8 -> (hashes [n_clips, 16] u64, crops [n_clips, 4] u32 = l, r, t, b
+        [, dontcare])."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim != 4:
+            raise ValueError("frames must be [n_clips, n_frames, H, W]")
+        nc, nf, h, w = frames.shape
+        out = np.zeros((nc, HASH_WORDS), np.uint64)
+        crops = np.zeros((nc, 4), np.uint32)
+        dc = np.zeros(nc, np.uint32) if want_dontcare else None
+        self._check(self.lib.vdf_hash_frames_u8_letterbox(self.ctx, frames.ctypes.data, nc, nf, w, h, w * h, nf * w * h,
+                                                          out.ctypes.data, crops.ctypes.data,
+                                                          dc.ctypes.data if want_dontcare else None))
+        return (out, crops, dc) if want_dontcare else (out, crops)
+
+    def cropdetect_letterbox_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
+                                    d_crops: int, stream: int = 0):
+        self._check(self.lib.vdf_cropdetect_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, w * h,
+                                                             w * h * frames_per_clip, d_crops, stream or None))
+
+    def hash_frames_cropped_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
+                                   crops: Optional[np.ndarray], d_out: int, d_dontcare: int = 0, stream: int = 0):
+        c = None if crops is None else np.ascontiguousarray(crops, dtype=np.uint32).reshape(n_clips, 4)
+        self._check(self.lib.vdf_hash_frames_u8_cropped_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, w * h,
+                                                               w * h * frames_per_clip,
+                                                               c.ctypes.data if c is not None else None, d_out,
+                                                               d_dontcare or None, stream or None))
+
+    def hash_frames_letterbox_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
+                                     d_out: int, d_dontcare: int = 0, stream: int = 0) -> np.ndarray:
+        crops = np.zeros((n_clips, 4), np.uint32)
+        self._check(self.lib.vdf_hash_frames_u8_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h,
+                                                                 w * h, w * h * frames_per_clip, d_out,
+                                                                 d_dontcare or None, crops.ctypes.data, stream or None))
+        return crops
+
     # ------------------------------------------------------------------- search
     def search_self_sorted(self, hashes, durations, tol_int: int) -> List[List[int]]:
         """search() on SoA input already in Search::sort order; groups of sorted indices."""
