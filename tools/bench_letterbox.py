@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Timing of detect + crop + hash (vdf_hash_frames_u8_letterbox_device) on HBM-resident clips."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vid_dup_finder_lib_amd as vdf
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--clips", type=int, default=20000)
+ap.add_argument("--w", type=int, default=64)
+ap.add_argument("--h", type=int, default=64)
+ap.add_argument("--bars", type=float, default=0.12, help="letterbox bar height as a fraction of H (0 = none)")
+ap.add_argument("--steps", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+eng = vdf.Engine(0)
+st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
+g = torch.Generator(device=dev); g.manual_seed(1)
+frames = torch.randint(0, 256, (a.clips, 16, a.h, a.w), dtype=torch.uint8, device=dev, generator=g)
+bar = int(a.h * a.bars)
+if bar:
+    frames[:, :, :bar, :] = 16
+    frames[:, :, a.h - bar:, :] = 16
+out = torch.zeros((a.clips, 16), dtype=torch.int64, device=dev)
+crops_d = torch.zeros((a.clips, 4), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for name, fn in (("detect only", lambda: eng.cropdetect_letterbox_device(frames.data_ptr(), a.clips, 16, a.w, a.h, crops_d.data_ptr(), stream=st.cuda_stream)),
+                 ("detect+crop+hash", lambda: eng.hash_frames_letterbox_device(frames.data_ptr(), a.clips, 16, a.w, a.h, out.data_ptr(), stream=st.cuda_stream))):
+    fn(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(a.steps): r = fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.steps
+    print(f"{name}: {a.clips} clips 16x{a.h}x{a.w} bars={bar}: {ms:.3f} ms, {a.clips*16/ms*1e3:.4g} frames/s, {a.clips*16*a.w*a.h/ms/1e6:.1f} GB/s of frames")
+print("crop[0] =", r[0] if r is not None else None)

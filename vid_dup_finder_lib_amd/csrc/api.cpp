@@ -318,10 +318,21 @@ int ensure_cos_table(vdf_ctx *ctx, hipStream_t stream)
     return VDF_OK;
 }
 
+constexpr size_t kMaxClipsPerLaunch = 256 * 1024;  // x 16 frames x 256 threads stays under HIP's 2^32 work-item grid limit
+
 int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
                        uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out, uint32_t *d_dc,
                        hipStream_t stream)
 {
+    if (n_clips > kMaxClipsPerLaunch) {
+        for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch) {
+            const size_t nb = std::min(kMaxClipsPerLaunch, n_clips - c0);
+            int rc = hash_device_locked(ctx, d_frames + c0 * clip_stride, nb, frames_per_clip, w, h, frame_stride,
+                                        clip_stride, d_out + c0 * VDF_HASH_WORDS, d_dc ? d_dc + c0 : nullptr, stream);
+            if (rc) return rc;
+        }
+        return VDF_OK;
+    }
     if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
     if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
     if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
@@ -401,6 +412,16 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
                         uint32_t h, size_t frame_stride, size_t clip_stride, const uint32_t *crops, uint64_t *d_out,
                         uint32_t *d_dc, hipStream_t stream)
 {
+    if (n_clips > kMaxClipsPerLaunch) {
+        for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch) {
+            const size_t nb = std::min(kMaxClipsPerLaunch, n_clips - c0);
+            int rc = hash_cropped_locked(ctx, d_frames + c0 * clip_stride, nb, frames_per_clip, w, h, frame_stride,
+                                         clip_stride, crops ? crops + 4 * c0 : nullptr, d_out + c0 * VDF_HASH_WORDS,
+                                         d_dc ? d_dc + c0 : nullptr, stream);
+            if (rc) return rc;
+        }
+        return VDF_OK;
+    }
     bool any = false;
     if (crops)
         for (size_t i = 0; i < n_clips * 4 && !any; i++) any = crops[i] != 0;
@@ -464,6 +485,17 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
     if (n_clips == 0) return VDF_OK;
     if (!d_frames || !d_out) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n_clips > kMaxClipsPerLaunch) {
+        for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch) {
+            const size_t nb = std::min(kMaxClipsPerLaunch, n_clips - c0);
+            int rc = letterbox_hash_device_locked(ctx, d_frames + c0 * clip_stride, nb, frames_per_clip, w, h,
+                                                  frame_stride, clip_stride, d_out + c0 * VDF_HASH_WORDS,
+                                                  d_dc ? d_dc + c0 : nullptr, out_crops ? out_crops + 4 * c0 : nullptr,
+                                                  stream);
+            if (rc) return rc;
+        }
+        return VDF_OK;
+    }
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
     VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
@@ -627,8 +659,10 @@ int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_
     if (n_clips == 0) return VDF_OK;
     if (!d_frames || !d_crops) return fail(ctx, VDF_E_INVAL, "null pointer");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
-    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_crops,
-                                       stream ? (hipStream_t)stream : ctx->stream));
+    for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch)
+        VDF_HIP(ctx, vdf::launch_letterbox(d_frames + c0 * clip_stride, std::min(kMaxClipsPerLaunch, n_clips - c0),
+                                           frames_per_clip, w, h, frame_stride, clip_stride, d_crops + 4 * c0,
+                                           stream ? (hipStream_t)stream : ctx->stream));
     return VDF_OK;
 }
 

@@ -13,9 +13,13 @@
 //   - per candidate one v_min + one v_cmp + one scalar branch guard the rare slow path that
 //     applies the duration window / consumption bitmap and appends (row, col) to the hit buffer.
 // The kernel is VALU-bound (see DESIGN.md "Hamming kernel"): HBM traffic is ~0.25 B per pair.
+#include <algorithm>
+
 #include "vdf_internal.h"
 
 namespace vdf {
+
+constexpr uint32_t kMaxBlocksPerLaunch = 8u << 20;  // x 256 threads = 2^31 work-items, under HIP's 2^32 grid limit
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;  // forces s_load for uniform addresses
 
@@ -201,20 +205,21 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
     const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_offset, uint32_t n_row_tiles,
     uint32_t chunk_cols, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
     vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ overflow_row)
+    uint32_t *__restrict__ overflow_row, uint32_t block_base)
 {
     constexpr uint32_t TILE_ROWS = 256 * R;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
 
     // workgroup -> (row tile, candidate chunk): largest t with tile_offset[t] <= blockIdx.x
     const_u32_ptr off = (const_u32_ptr)(uintptr_t)tile_offset;
     uint32_t tl = 0, th = n_row_tiles;
     while (th - tl > 1) {
         const uint32_t mid = (tl + th) >> 1;
-        if (off[mid] <= blockIdx.x) tl = mid; else th = mid;
+        if (off[mid] <= bid) tl = mid; else th = mid;
     }
     const uint32_t t = tl;
-    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)tile_first)[t] + (blockIdx.x - off[t]);
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)tile_first)[t] + (bid - off[t]);
     const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
     const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
     const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
@@ -302,8 +307,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ packed, uint32_t n,
                                                         uint32_t n_pad, uint4 *__restrict__ expanded)
 {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // (hash, dword)
-    if (idx >= (size_t)n_pad * 32) return;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)n_pad * 32;
+         idx += (size_t)gridDim.x * 256) {  // (hash, dword), grid-stride: the grid is capped under HIP's 2^32 limit
     const uint32_t hsh = (uint32_t)(idx >> 5);
     uint4 out = {0u, 0u, 0u, 0u};
     if (hsh < n) {
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
         out = make_uint4(o[0], o[1], o[2], o[3]);
     }
     expanded[idx] = out;
+    }
 }
 
 constexpr uint32_t kMfmaTileRows = 256;  // 4 waves x 64 rows
@@ -334,8 +340,9 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     const uint32_t *__restrict__ group_offset, const uint32_t *__restrict__ group_cmin, uint32_t n_groups,
     uint32_t group_size, uint32_t n_row_tiles, uint32_t chunk_cols, uint32_t tol,
     const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
-    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row)
+    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base)
 {
+    const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
     __shared__ __attribute__((aligned(16))) uint4 s_b[2][kMfmaColStep * 32];  // 2 x 16 KB: [col][chunk ^ col] swizzled
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c31 = lane & 31;
 
@@ -344,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     uint32_t gl = 0, gh = n_groups;
     while (gh - gl > 1) {
         const uint32_t mid = (gl + gh) >> 1;
-        if (goff[mid] <= blockIdx.x) gl = mid; else gh = mid;
+        if (goff[mid] <= bid) gl = mid; else gh = mid;
     }
-    const uint32_t idx = blockIdx.x - goff[gl];
+    const uint32_t idx = bid - goff[gl];
     const uint32_t t = gl * group_size + idx % group_size;
     const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / group_size;
     if (t >= n_row_tiles) return;
@@ -485,25 +492,31 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
 {
     if (total_tiles == 0) return hipSuccess;
 #define VDF_LAUNCH(RR)                                                                                              \
-    hipLaunchKernelGGL(hamming_tile_kernel<RR>, dim3(total_tiles), dim3(256), 0, stream, L.row_hashes, L.row_perm,   \
+    hipLaunchKernelGGL(hamming_tile_kernel<RR>, dim3(nb), dim3(256), 0, stream, L.row_hashes, L.row_perm,            \
                        L.n_rows, L.row_index_base, L.col_hashes, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,          \
                        L.tile_first, L.tile_offset, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
-                       L.hits, L.capacity, L.counters, L.overflow_row)
-    switch (L.tile_rows / 256) {
-    case 1: VDF_LAUNCH(1); break;
-    case 2: VDF_LAUNCH(2); break;
-    case 4: VDF_LAUNCH(4); break;
-    default: return hipErrorInvalidValue;
+                       L.hits, L.capacity, L.counters, L.overflow_row, base)
+    // HIP limits a grid to 2^32 work-items in x: slices of at most kMaxBlocksPerLaunch workgroups
+    for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
+        const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
+        switch (L.tile_rows / 256) {
+        case 1: VDF_LAUNCH(1); break;
+        case 2: VDF_LAUNCH(2); break;
+        case 4: VDF_LAUNCH(4); break;
+        default: return hipErrorInvalidValue;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
 #undef VDF_LAUNCH
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream)
 {
     if (n_pad == 0) return hipSuccess;
     const size_t total = (size_t)n_pad * 32;
-    hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, packed, n, n_pad,
+    hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, kMaxBlocksPerLaunch)), dim3(256), 0, stream, packed, n, n_pad,
                        reinterpret_cast<uint4 *>(expanded));
     return hipGetLastError();
 }
@@ -512,13 +525,18 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
 {
     if (total_tiles == 0) return hipSuccess;
     if (L.tile_rows != kMfmaTileRows) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(hamming_mfma_kernel, dim3(total_tiles), dim3(256), 0, stream,
-                       reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,
-                       reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,
-                       L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,
-                       L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,
-                       L.overflow_row);
-    return hipGetLastError();
+    for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
+        const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
+        hipLaunchKernelGGL(hamming_mfma_kernel, dim3(nb), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,
+                           reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,
+                           L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,
+                           L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,
+                           L.overflow_row, base);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace vdf
