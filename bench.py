@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--hash-clips", type=int, default=100_000, help="clips for the DCT-hash leg (0 = skip)")
     ap.add_argument("--tolerance", type=float, default=0.35)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-windowed", dest="windowed", action="store_false", help="skip the windowed-durations leg")
     args = ap.parse_args()
 
     import torch
@@ -227,6 +228,24 @@ def main():
         "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
     }
     out.update(extra)
+
+    # ---- windowed-durations variant: same hashes, durations = floor(exp(U(ln 5, ln 7200))) sorted, so the
+    # one-sided x1.1 window admits ~1 % of the triangle; shows what the window/tile culling costs.  rank 0 only.
+    if rank == 0 and args.windowed:
+        rng = np.random.default_rng(20250613)
+        dur = np.sort(np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=args.n_hashes))).astype(np.uint32))
+        wd = torch.from_numpy(dur.view(np.int32)).to(dev)
+        ww = torch.from_numpy(words[: args.n_hashes].view(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+        t1 = time.perf_counter()
+        hits_w, _, _ = eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+        dtw = time.perf_counter() - t1
+        st = eng.last_stats()
+        out["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"], "kernel_ms": st["kernel_ms"],
+                           "ms": dtw * 1e3, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
+                           "note": "log-uniform durations, one-sided x1.1 window (search_algorithm.rs:99)"}
+        del ww, wd
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM ------------------------------------------
     if args.hash_clips > 0 and rank == 0:

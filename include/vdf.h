@@ -187,7 +187,7 @@ int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const ui
                            size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
                            uint64_t capacity, uint64_t *n_hits, void *stream);
 
-uint32_t vdf_row_tile_size(void);
+uint32_t vdf_row_tile_size(void); /* rows per tile of the default backend (informational: any shard_count works) */
 
 /* Host replay of search_self's consumption order (search_algorithm.rs:131-170) over hits sorted
  * by (row, col).  matched (nullable, n bytes, in/out) carries consumption state between partial

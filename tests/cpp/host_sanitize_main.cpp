@@ -1,0 +1,61 @@
+// AddressSanitizer/UBSan driver for the host-only parts of the library (no GPU, no HIP runtime): the greedy
+// replay, group assembly, pair counting and the resize coefficient tables.  Built by tests/test_host_sanitizers.py
+// with -fsanitize=address,undefined straight from the sources.
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/vdf.h"
+#include "../../vid_dup_finder_lib_amd/csrc/resize_tables.h"
+
+int main()
+{
+    std::mt19937 rng(1);
+    // replay over random hit lists, in one go and in pieces with carried state
+    for (int rep = 0; rep < 200; rep++) {
+        const size_t n = 1 + rng() % 300;
+        std::vector<vdf_hit> hits;
+        for (uint32_t i = 0; i + 1 < n; i++)
+            for (uint32_t j = i + 1; j < n; j++)
+                if (rng() % 17 == 0) hits.push_back(vdf_hit{i, j});
+        vdf_groups a{}, b{};
+        assert(vdf_replay_self(n, hits.data(), hits.size(), 0, 0xFFFFFFFFu, nullptr, &a) == VDF_OK);
+        assert(vdf_groups_finish_self(&a) == VDF_OK);
+        std::vector<uint8_t> matched(n, 0);
+        const uint32_t cut = (uint32_t)(rng() % n);
+        assert(vdf_replay_self(n, hits.data(), hits.size(), 0, cut, matched.data(), &b) == VDF_OK);
+        assert(vdf_replay_self(n, hits.data(), hits.size(), cut, (uint32_t)n, matched.data(), &b) == VDF_OK);
+        assert(vdf_groups_finish_self(&b) == VDF_OK);
+        assert(a.n_groups == b.n_groups);
+        if (a.n_groups) {
+            assert(std::memcmp(a.offsets, b.offsets, (a.n_groups + 1) * 8) == 0);
+            assert(std::memcmp(a.members, b.members, a.offsets[a.n_groups] * 8) == 0);
+        }
+        vdf_groups r{};
+        assert(vdf_groups_from_ref_hits(hits.data(), hits.size(), &r) == VDF_OK);
+        vdf_groups_free(&a); vdf_groups_free(&b); vdf_groups_free(&r);
+    }
+    vdf_groups e{};
+    assert(vdf_replay_self(0, nullptr, 0, 0, 0, nullptr, &e) == VDF_OK && vdf_groups_finish_self(&e) == VDF_OK && e.n_groups == 0);
+    vdf_groups_free(&e);
+    // pair counting at the u32 boundary
+    std::vector<uint32_t> d = {0, 1, 10, 11, 12, 4000000000u, 4294967295u, 4294967295u};
+    assert(vdf_count_pairs_self(d.data(), d.size()) > 0);
+    assert(vdf_count_pairs_refs(d.data(), d.size(), d.data(), d.size()) > 0);
+    assert(vdf_tolerance_int(0.35) == 350 && vdf_tolerance_int(-3.0) == 0 && vdf_tolerance_int(1e300) == 0xFFFFFFFFu);
+    // coefficient tables for every size up to 300 and a few large ones
+    for (uint32_t sz : std::vector<uint32_t>{1, 2, 3, 15, 16, 17, 31, 33, 63, 64, 65, 127, 270, 1080, 1920, 4320}) {
+        vdf::HostAxisTable t;
+        assert(vdf::build_axis_table(sz, 16, t));
+        for (int o = 0; o < 16; o++) assert(t.start[o] >= 0 && t.start[o] + t.size[o] <= (int32_t)sz);
+        for (int v = 0; v < 2; v++) {
+            vdf::MfmaAxisTable m;
+            assert(vdf::build_mfma_axis_table(sz, v == 1, m));
+            assert(m.operand.size() == (size_t)m.n_tiles * 2 * 64 * 16 && m.bias.size() == 16);
+        }
+    }
+    std::puts("sanitize ok");
+    return 0;
+}

@@ -594,7 +594,7 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
     return VDF_OK;
 }
 
-uint32_t vdf_row_tile_size(void) { return 256u * vdf::kDefaultRowsPerLane; }
+uint32_t vdf_row_tile_size(void) { return 256u; }  // MFMA backend (default); the VALU backend uses 256 x rows-per-lane
 
 int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                               uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,
