@@ -133,7 +133,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     vdf::SearchLaunch L{};
     const bool mfma = ctx->search_backend == 1;
-    L.tile_rows = mfma ? 256u : ctx->tile_rows;
+    L.tile_rows = mfma ? vdf::kMfmaRowPad : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     const size_t padded_rows = (size_t)L.n_row_tiles * L.tile_rows;
@@ -170,6 +170,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
 
     if (mfma) {
+        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
         if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
@@ -594,7 +595,7 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
     return VDF_OK;
 }
 
-uint32_t vdf_row_tile_size(void) { return 256u; }  // MFMA backend (default); the VALU backend uses 256 x rows-per-lane
+uint32_t vdf_row_tile_size(void) { return vdf::kMfmaRowPad; }  // MFMA backend (default); the VALU backend uses 256 x rows-per-lane
 
 int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                               uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,

@@ -19,7 +19,7 @@
 
 namespace vdf {
 
-constexpr uint32_t kMaxBlocksPerLaunch = 8u << 20;  // x 256 threads = 2^31 work-items, under HIP's 2^32 grid limit
+constexpr uint32_t kMaxBlocksPerLaunch = 4u << 20;  // x <= 512 threads <= 2^31 work-items, under HIP's 2^32 grid limit
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;  // forces s_load for uniform addresses
 
@@ -328,11 +328,15 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
     }
 }
 
-constexpr uint32_t kMfmaTileRows = 256;  // 4 waves x 64 rows
+constexpr uint32_t kMfmaWaves = 4;                          // waves per workgroup sharing one staged candidate tile
+constexpr uint32_t kMfmaTileRows = 64 * kMfmaWaves;         // 64 target rows per wave
 constexpr uint32_t kMfmaSub = 2;                     // 32-column sub-tiles per LDS stage
 constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
 
-__global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
+// ABLATE (timing experiments only, results are wrong when != 0): 1 = no epilogue test, 2 = no DMA after the first
+// stage, 3 = no DMA and no barrier.
+template <int ABLATE>
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
     const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
@@ -389,18 +393,19 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     // global_load_lds: the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane SOURCE
     // address; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
     const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
-    uint32_t lane_off[4 * kMfmaSub];  // loop-invariant byte offset of this lane's source chunk inside a stage
+    constexpr int kDmaPerWave = (int)(kMfmaColStep * 32 / (64 * kMfmaWaves));  // 1 KB DMA instructions per wave per stage
+    uint32_t lane_off[kDmaPerWave];  // loop-invariant byte offset of this lane's source chunk inside a stage
 #pragma unroll
-    for (int i = 0; i < (int)(4 * kMfmaSub); i++) {
-        const uint32_t L = 256 * i + 64 * wave + lane, c = L >> 5, q = L & 31;
+    for (int i = 0; i < kDmaPerWave; i++) {
+        const uint32_t L = 64 * kMfmaWaves * i + 64 * wave + lane, c = L >> 5, q = L & 31;
         lane_off[i] = c * 512u + ((q ^ (c & 31)) << 4);
     }
     auto load_stage = [&](uint32_t cb, int buf) {
         const char *base = reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512;  // wave-uniform (SGPR pair)
 #pragma unroll
-        for (int i = 0; i < (int)(4 * kMfmaSub); i++)
+        for (int i = 0; i < kDmaPerWave; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off[i]),
-                                             (__attribute__((address_space(3))) void *)&s_b[buf][256 * i + 64 * wave],
+                                             (__attribute__((address_space(3))) void *)&s_b[buf][64 * kMfmaWaves * i + 64 * wave],
                                              16, 0, 0);
     };
     load_stage(cb0, 0);
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     int buf = 0;
     for (uint32_t cb = cb0; cb < c_end; cb += kMfmaColStep, buf ^= 1) {
         const bool more = cb + kMfmaColStep < c_end;
-        if (more) load_stage(cb + kMfmaColStep, buf ^ 1);  // lands under the MFMAs below
+        if (more && ABLATE < 2) load_stage(cb + kMfmaColStep, buf ^ 1);  // lands under the MFMAs below
 #pragma unroll
         for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
         if (cb + 32u * sub >= c_end) break;
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
         for (int r = 1; r < 16; r++) m = fmaxf(m, acc0[r]);
 #pragma unroll
         for (int r = 0; r < 16; r++) m = fmaxf(m, acc1[r]);
+        if (ABLATE == 1) { asm volatile("" ::"v"(m)); m = -2048.0f; }
         if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
             // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
             const uint32_t j = cb + 32u * sub + c31;
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
             }
         }
         }
-        __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with s_b[buf]
+        if (ABLATE < 3) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with s_b[buf]
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
 }
@@ -527,12 +533,20 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
     if (L.tile_rows != kMfmaTileRows) return hipErrorInvalidValue;
     for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
         const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
-        hipLaunchKernelGGL(hamming_mfma_kernel, dim3(nb), dim3(256), 0, stream,
-                           reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,
-                           reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,
-                           L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,
-                           L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,
-                           L.overflow_row, base);
+#define VDF_MFMA_LAUNCH(AB)                                                                                         \
+    hipLaunchKernelGGL(hamming_mfma_kernel<AB>, dim3(nb), dim3(64 * kMfmaWaves), 0, stream,                                      \
+                       reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,           \
+                       reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
+                       L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
+                       L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,    \
+                       L.overflow_row, base)
+        switch (L.ablate) {
+        case 1: VDF_MFMA_LAUNCH(1); break;
+        case 2: VDF_MFMA_LAUNCH(2); break;
+        case 3: VDF_MFMA_LAUNCH(3); break;
+        default: VDF_MFMA_LAUNCH(0); break;
+        }
+#undef VDF_MFMA_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -29,6 +29,7 @@ struct SearchLaunch {
     uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
     uint32_t *group_cmin, *group_offset, *group_blocks;  // [n_groups (+1)]: chunk-major grouped order (MFMA backend), else null
+    int ablate = 0;                       // timing experiments only (VDF_MFMA_ABLATE), wrong results when != 0
     uint32_t n_groups, group_size;        // n_groups = 0 for the VALU backend (compact tile list)
     uint32_t n_row_tiles;
     uint32_t tile_rows;          // 256 * rows-per-lane (256, 512 or 1024)
@@ -49,8 +50,8 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L,
                                 hipStream_t stream);
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
-// MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of 256, columns to a multiple of 32 (+32).
-constexpr uint32_t kMfmaRowPad = 256, kMfmaColPad = 128;
+// MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of the tile, columns by a further 128.
+constexpr uint32_t kMfmaRowPad = 256, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile (4 waves x 64; 8 waves measured slower)
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 
