@@ -200,6 +200,34 @@ int vdf_groups_finish_self(vdf_groups *g);
 /* Groups for search_with_references from hits sorted by (row, col). */
 int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
 
+/* ---- the app's on-disk hash cache <-> SoA (host only) ---------------------------------------------
+ * Format: bincode 2 `config::standard()` (little endian, varint) of
+ * HashMap<PathBuf, MtimeCacheEntry { cache_mtime: SystemTime, value: Result<VideoHash, Error> }>
+ * (vid_dup_finder_app/src/video_hash_filesystem_cache/generic_filesystem_cache/base_fs_cache.rs:26,
+ * 106-118,192-204; processing_fs_cache.rs:23-27; generic_cache_if.rs:23; video_hash.rs:26-32).
+ * Decoding yields the arrays the search ABI takes; entries whose value is Err(..) are counted, not
+ * returned.  Entry order is the file's (a HashMap's: arbitrary); sort before searching. */
+typedef struct vdf_cache_soa {
+    uint64_t n_entries;      /* map length */
+    uint64_t n_ok;           /* entries with Ok(VideoHash): length of the arrays below */
+    uint64_t n_err;          /* entries with Err(..) */
+    uint64_t n_key_differs;  /* Ok entries whose map key != VideoHash.src_path (0 for caches the app wrote) */
+    uint64_t *hashes;        /* n_ok x 16 */
+    uint32_t *durations;     /* n_ok */
+    uint64_t *path_offsets;  /* n_ok + 1 byte offsets into paths (VideoHash.src_path, UTF-8, not NUL terminated) */
+    char *paths;
+    uint64_t *mtime_secs;    /* n_ok: cache_mtime.secs_since_epoch */
+    uint32_t *mtime_nanos;   /* n_ok */
+} vdf_cache_soa;
+int vdf_cache_decode(const uint8_t *data, size_t len, vdf_cache_soa *out); /* malformed input -> VDF_E_INVAL */
+void vdf_cache_free(vdf_cache_soa *c);
+/* Writes a cache the app can load: every entry Ok(VideoHash), key = src_path.  mtime arrays may be NULL (0).
+ * *out_data is library-allocated; release with vdf_buffer_free(). */
+int vdf_cache_encode(uint64_t n, const uint64_t *hashes, const uint32_t *durations, const uint64_t *path_offsets,
+                     const char *paths, const uint64_t *mtime_secs, const uint32_t *mtime_nanos, uint8_t **out_data,
+                     size_t *out_len);
+void vdf_buffer_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,15 @@ class VdfSearchStats(C.Structure):
     ]
 
 
+class VdfCacheSoa(C.Structure):
+    _fields_ = [
+        ("n_entries", C.c_uint64), ("n_ok", C.c_uint64), ("n_err", C.c_uint64), ("n_key_differs", C.c_uint64),
+        ("hashes", C.POINTER(C.c_uint64)), ("durations", C.POINTER(C.c_uint32)),
+        ("path_offsets", C.POINTER(C.c_uint64)), ("paths", C.POINTER(C.c_char)),
+        ("mtime_secs", C.POINTER(C.c_uint64)), ("mtime_nanos", C.POINTER(C.c_uint32)),
+    ]
+
+
 _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
@@ -99,6 +108,11 @@ SIGNATURES = {
                                   C.POINTER(VdfGroups)]),
     "vdf_groups_finish_self": (C.c_int, [C.POINTER(VdfGroups)]),
     "vdf_groups_from_ref_hits": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(VdfGroups)]),
+    "vdf_cache_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VdfCacheSoa)]),
+    "vdf_cache_free": (None, [C.POINTER(VdfCacheSoa)]),
+    "vdf_cache_encode": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "vdf_buffer_free": (None, [C.c_void_p]),
 }
 
 _lib = None
