@@ -200,6 +200,13 @@ int vdf_groups_finish_self(vdf_groups *g);
 /* Groups for search_with_references from hits sorted by (row, col). */
 int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
 
+/* ---- the app's Sorting::Distance key (vid_dup_finder_app/src/app/search_output.rs:43-60) ----------
+ * out_max[g] = max hamming distance over all pairs of group g's contained paths: its members (indices
+ * into hashes, n x 16, host) and, when ref_hashes and groups->ref_index are given and ref_index[g] >= 0,
+ * the group's reference ref_hashes[ref_index[g]].  Every group has >= 2 contained paths in the reference. */
+int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, const uint64_t *ref_hashes, size_t n_ref,
+                            const vdf_groups *groups, uint32_t *out_max);
+
 /* ---- the app's on-disk hash cache <-> SoA (host only) ---------------------------------------------
  * Format: bincode 2 `config::standard()` (little endian, varint) of
  * HashMap<PathBuf, MtimeCacheEntry { cache_mtime: SystemTime, value: Result<VideoHash, Error> }>

@@ -189,3 +189,27 @@ def test_large_tolerances_match_everything(engine, n):
     rd = rng.integers(90, 150, size=9).astype(np.uint32)
     for tol in (600, 1024):
         _both_refs(engine, w, d, rw, rd, tol)
+
+
+def test_groups_max_distance_matches_bruteforce(engine):
+    """SURVEY 8f N4: the app's Sorting::Distance key (search_output.rs:43-60)."""
+    rng = np.random.default_rng(77)
+    words, dur = hg.planted_set(rng, 3000, n_clusters=60, max_copies=40, max_flips=300)
+    w, d, _ = hg.sort_by_duration(words, dur)
+    groups = engine.search_self_sorted(w, d, 350)
+    assert len(groups) > 10
+    got = engine.groups_max_distance(w, groups)
+    want = [max(orc.hamming(w[a], w[b]) for i, a in enumerate(g) for b in g[i + 1:]) for g in groups]
+    assert got.tolist() == want
+    # with references: contained_paths = duplicates then the reference
+    pick = [g[0] for g in groups[:20]]
+    rw = w[pick].copy()
+    rw[:, 0] ^= np.uint64(0xFFFF)
+    res = engine.search_refs_sorted(w, d, rw, d[pick], 350)
+    got_r = engine.groups_max_distance(w, [m for _, m in res], ref_hashes=rw, ref_index=[r for r, _ in res])
+    want_r = []
+    for r, m in res:
+        hs = [w[x] for x in m] + [rw[r]]
+        want_r.append(max(orc.hamming(hs[i], hs[j]) for i in range(len(hs)) for j in range(i + 1, len(hs))))
+    assert got_r.tolist() == want_r
+    assert engine.groups_max_distance(w, []).tolist() == []

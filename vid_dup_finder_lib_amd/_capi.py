@@ -108,6 +108,8 @@ SIGNATURES = {
                                   C.POINTER(VdfGroups)]),
     "vdf_groups_finish_self": (C.c_int, [C.POINTER(VdfGroups)]),
     "vdf_groups_from_ref_hits": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(VdfGroups)]),
+    "vdf_groups_max_distance": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(VdfGroups),
+                                          C.c_void_p]),
     "vdf_cache_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VdfCacheSoa)]),
     "vdf_cache_free": (None, [C.POINTER(VdfCacheSoa)]),
     "vdf_cache_encode": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -726,6 +726,44 @@ int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_c
     return VDF_OK;
 }
 
+int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, const uint64_t *ref_hashes, size_t n_ref,
+                            const vdf_groups *groups, uint32_t *out_max)
+{
+    if (!ctx || !groups) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t ng = groups->n_groups;
+    if (ng == 0) return VDF_OK;
+    if (!hashes || !out_max || !groups->offsets || !groups->members) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (ng > 0x7FFFFFFFull) return fail(ctx, VDF_E_INVAL, "too many groups");
+    const uint64_t nm = groups->offsets[ng];
+    for (uint64_t i = 0; i < nm; i++)
+        if (groups->members[i] >= n) return fail(ctx, VDF_E_INVAL, "group member index out of range");
+    const bool refs = ref_hashes && groups->ref_index;
+    if (refs)
+        for (uint64_t g = 0; g < ng; g++)
+            if (groups->ref_index[g] >= (int64_t)n_ref) return fail(ctx, VDF_E_INVAL, "reference index out of range");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf d_off, d_mem, d_ref, d_out;
+    int rc = upload(ctx, ctx->up_hashes, hashes, n * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK && refs) rc = upload(ctx, ctx->up_ref_hashes, ref_hashes, n_ref * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK) rc = upload(ctx, d_off, groups->offsets, (ng + 1) * 8, s);
+    if (rc == VDF_OK) rc = upload(ctx, d_mem, groups->members, std::max<uint64_t>(nm, 1) * 8, s);
+    if (rc == VDF_OK && refs) rc = upload(ctx, d_ref, groups->ref_index, ng * 8, s);
+    hipError_t e = rc == VDF_OK ? d_out.reserve(ng * 4) : hipSuccess;
+    if (rc == VDF_OK && e == hipSuccess)
+        e = vdf::launch_group_max_distance(ctx->up_hashes.as<uint32_t>(), d_off.as<unsigned long long>(),
+                                           d_mem.as<unsigned long long>(),
+                                           refs ? ctx->up_ref_hashes.as<uint32_t>() : nullptr,
+                                           refs ? d_ref.as<long long>() : nullptr, (uint32_t)ng, d_out.as<uint32_t>(), s);
+    if (rc == VDF_OK && e == hipSuccess) e = hipMemcpyAsync(out_max, d_out.p, ng * 4, hipMemcpyDeviceToHost, s);
+    if (rc == VDF_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    d_off.release(); d_mem.release(); d_ref.release(); d_out.release();
+    if (rc) return rc;
+    if (e != hipSuccess) return fail_hip(ctx, e, "vdf_groups_max_distance");
+    return VDF_OK;
+}
+
 int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
                            uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
                            uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,

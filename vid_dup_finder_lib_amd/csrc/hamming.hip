@@ -518,6 +518,57 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
     return hipSuccess;
 }
 
+// ---- the app's Sorting::Distance key ------------------------------------------------------
+// vid_dup_finder_app/src/app/search_output.rs:43-60: for every MatchGroup, the maximum hamming_distance over all
+// pairs of its contained_paths (duplicates, then the reference if any).  One workgroup per group; member i is
+// wave-uniform (scalar loads), lanes stride over j > i.  members index `hashes`; a group with a reference takes
+// its extra member from ref_hashes[ref_index].
+__global__ __launch_bounds__(256) void group_max_distance_kernel(const uint32_t *__restrict__ hashes,
+                                                                 const unsigned long long *__restrict__ offsets,
+                                                                 const unsigned long long *__restrict__ members,
+                                                                 const uint32_t *__restrict__ ref_hashes,
+                                                                 const long long *__restrict__ ref_index,
+                                                                 uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t s_max[4];
+    const uint32_t g = blockIdx.x;
+    const unsigned long long a = offsets[g], b = offsets[g + 1];
+    const bool has_ref = ref_hashes != nullptr && ref_index != nullptr && ref_index[g] >= 0;
+    const uint32_t k = (uint32_t)(b - a) + (has_ref ? 1u : 0u);
+    auto member_ptr = [&](uint32_t idx) -> const uint32_t * {
+        return idx < (uint32_t)(b - a) ? hashes + (size_t)members[a + idx] * 32 : ref_hashes + (size_t)ref_index[g] * 32;
+    };
+    uint32_t best = 0;
+    for (uint32_t i = 0; i + 1 < k; i++) {
+        const_u32_ptr hi = (const_u32_ptr)(uintptr_t)member_ptr(i);  // wave-uniform
+        for (uint32_t j = i + 1 + threadIdx.x; j < k; j += 256) {
+            const uint4 *hj = reinterpret_cast<const uint4 *>(member_ptr(j));
+            uint32_t d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint4 v = hj[q];
+                d += __builtin_popcount(v.x ^ hi[4 * q]) + __builtin_popcount(v.y ^ hi[4 * q + 1]) +
+                     __builtin_popcount(v.z ^ hi[4 * q + 2]) + __builtin_popcount(v.w ^ hi[4 * q + 3]);
+            }
+            best = max(best, d);
+        }
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) out[g] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+}
+
+hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
+                                     const unsigned long long *members, const uint32_t *ref_hashes,
+                                     const long long *ref_index, uint32_t n_groups, uint32_t *out, hipStream_t stream)
+{
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(group_max_distance_kernel, dim3(n_groups), dim3(256), 0, stream, hashes, offsets, members,
+                       ref_hashes, ref_index, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream)
 {
     if (n_pad == 0) return hipSuccess;

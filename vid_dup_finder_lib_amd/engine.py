@@ -172,6 +172,32 @@ class Engine:
         finally:
             self.lib.vdf_groups_free(C.byref(g))
 
+    def groups_max_distance(self, hashes, groups: Sequence[Sequence[int]], ref_hashes=None,
+                            ref_index: Optional[Sequence[int]] = None) -> np.ndarray:
+        """The app's Sorting::Distance key (search_output.rs:43-60): per group, the max Hamming distance over all
+        pairs of its members (indices into `hashes`) plus, if given, its reference ref_hashes[ref_index[g]]."""
+        h = np.ascontiguousarray(hashes, dtype=np.uint64).reshape(-1, HASH_WORDS)
+        ng = len(groups)
+        offs = np.zeros(ng + 1, np.uint64)
+        offs[1:] = np.cumsum([len(g) for g in groups]) if ng else []
+        mem = np.array([m for g in groups for m in g], dtype=np.uint64)
+        if not len(mem):
+            mem = np.zeros(1, np.uint64)
+        g = VdfGroups()
+        g.n_groups = ng
+        g.offsets = offs.ctypes.data_as(C.POINTER(C.c_uint64))
+        g.members = mem.ctypes.data_as(C.POINTER(C.c_uint64))
+        rh = ri = None
+        if ref_hashes is not None and ref_index is not None:
+            rh = np.ascontiguousarray(ref_hashes, dtype=np.uint64).reshape(-1, HASH_WORDS)
+            ri = np.ascontiguousarray(ref_index, dtype=np.int64)
+            g.ref_index = ri.ctypes.data_as(C.POINTER(C.c_int64))
+        out = np.zeros(ng, np.uint32)
+        self._check(self.lib.vdf_groups_max_distance(self.ctx, h.ctypes.data, len(h),
+                                                     rh.ctypes.data if rh is not None else None,
+                                                     len(rh) if rh is not None else 0, C.byref(g), out.ctypes.data))
+        return out
+
     def search_self_device(self, d_hashes: int, d_durations: int, n: int, tol_int: int, shard_index: int = 0,
                            shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
