@@ -200,6 +200,20 @@ int vdf_groups_finish_self(vdf_groups *g);
 /* Groups for search_with_references from hits sorted by (row, col). */
 int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
 
+/* ---- batching queue for concurrent per-file callers ------------------------------------------------
+ * The app hashes one file per rayon worker (vid_dup_finder_app/src/video_hash_filesystem_cache/
+ * video_hash_filesystem_cache.rs:237-257 -> VideoHashBuilder::hash, video_hash_builder.rs:80-82,214-223).
+ * vdf_hash_queue_submit may be called from any number of threads: the clips of concurrent callers are
+ * hashed by ONE batched launch (the first caller of a batch waits up to max_wait_us for others or until
+ * max_batch clips joined).  frames = 16 gray frames of w x h, tightly packed; blocks until the hash is
+ * there.  letterbox != 0 applies Cropdetect::Letterbox first (out_crop, nullable, gets the box). */
+typedef struct vdf_hash_queue vdf_hash_queue;
+int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_batch, uint32_t max_wait_us, int letterbox,
+                          vdf_hash_queue **out);
+int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *out_hash, uint32_t *out_crop);
+int vdf_hash_queue_stats(vdf_hash_queue *q, uint64_t *n_batches, uint64_t *n_clips);
+void vdf_hash_queue_destroy(vdf_hash_queue *q);
+
 /* ---- the app's Sorting::Distance key (vid_dup_finder_app/src/app/search_output.rs:43-60) ----------
  * out_max[g] = max hamming distance over all pairs of group g's contained paths: its members (indices
  * into hashes, n x 16, host) and, when ref_hashes and groups->ref_index are given and ref_index[g] >= 0,

@@ -1,0 +1,58 @@
+"""concurrent per-clip submitters share batched launches and get exactly the batch API's hashes."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("letterbox", [False, True])
+def test_many_threads_one_batch(engine, letterbox):
+    from vid_dup_finder_lib_amd.engine import HashQueue
+
+    rng = np.random.default_rng(1)
+    n, h, w = 96, 48, 64
+    frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
+    if letterbox:
+        frames[:, :, :5, :] = 16
+        frames[::3, :, :, -7:] = 200
+    want = engine.hash_frames_letterbox(frames) if letterbox else (engine.hash_frames(frames), np.zeros((n, 4), np.uint32))
+    q = HashQueue(engine, w, h, max_batch=32, max_wait_us=20000, letterbox=letterbox)
+    got = [None] * n
+    errs = []
+
+    def worker(ids):
+        try:
+            for i in ids:
+                got[i] = q.submit(frames[i])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(range(t, n, 12),)) for t in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs and all(g is not None for g in got)
+    for i in range(n):
+        assert np.array_equal(got[i][0], want[0][i])
+        assert got[i][1] == tuple(int(x) for x in want[1][i])
+    n_batches, n_clips = q.stats()
+    assert n_clips == n and n_batches < n  # concurrent callers really were batched together
+    q.close()
+
+
+def test_single_caller_does_not_wait_for_a_full_batch(engine):
+    from vid_dup_finder_lib_amd.engine import HashQueue
+
+    rng = np.random.default_rng(2)
+    frames = rng.integers(0, 256, size=(3, 16, 32, 32), dtype=np.uint8)
+    q = HashQueue(engine, 32, 32, max_batch=1024, max_wait_us=1000)
+    for i in range(3):
+        hsh, crop = q.submit(frames[i])
+        assert np.array_equal(hsh, engine.hash_frames(frames[i:i + 1])[0]) and crop == (0, 0, 0, 0)
+    assert q.stats() == (3, 3)
+    with pytest.raises(ValueError):
+        q.submit(frames[0][:, :16, :])
+    q.close()

@@ -108,6 +108,11 @@ SIGNATURES = {
                                   C.POINTER(VdfGroups)]),
     "vdf_groups_finish_self": (C.c_int, [C.POINTER(VdfGroups)]),
     "vdf_groups_from_ref_hits": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(VdfGroups)]),
+    "vdf_hash_queue_create": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
+    "vdf_hash_queue_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdf_hash_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vdf_hash_queue_destroy": (None, [C.c_void_p]),
     "vdf_groups_max_distance": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(VdfGroups),
                                           C.c_void_p]),
     "vdf_cache_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VdfCacheSoa)]),

@@ -290,3 +290,43 @@ def groups_from_ref_hits(hits: np.ndarray) -> List[Tuple[int, List[int]]]:
         return _groups_to_lists(g)
     finally:
         lib.vdf_groups_free(C.byref(g))
+
+
+class HashQueue:
+    """Thread-safe batching of per-clip hash requests (vdf_hash_queue_*): concurrent submit()
+    calls from many threads share one batched GPU launch.  One queue per frame size."""
+
+    def __init__(self, engine: Engine, w: int, h: int, max_batch: int = 256, max_wait_us: int = 2000,
+                 letterbox: bool = False):
+        self.engine = engine
+        self.w, self.h = int(w), int(h)
+        q = C.c_void_p()
+        engine._check(engine.lib.vdf_hash_queue_create(engine.ctx, self.w, self.h, int(max_batch), int(max_wait_us),
+                                                       1 if letterbox else 0, C.byref(q)))
+        self.q = q
+
+    def submit(self, frames: np.ndarray):
+        """frames [>=16, H, W] u8 -> (hash [16] u64, crop (l, r, t, b)).  Blocks; releases the GIL while waiting."""
+        f = np.ascontiguousarray(frames[:16], dtype=np.uint8)
+        if f.shape != (16, self.h, self.w):
+            raise ValueError("a queue takes 16 frames of its own frame size")
+        out = np.zeros(HASH_WORDS, np.uint64)
+        crop = np.zeros(4, np.uint32)
+        self.engine._check(self.engine.lib.vdf_hash_queue_submit(self.q, f.ctypes.data, out.ctypes.data, crop.ctypes.data))
+        return out, tuple(int(x) for x in crop)
+
+    def stats(self):
+        nb, nc = C.c_uint64(0), C.c_uint64(0)
+        self.engine.lib.vdf_hash_queue_stats(self.q, C.byref(nb), C.byref(nc))
+        return int(nb.value), int(nc.value)
+
+    def close(self):
+        if getattr(self, "q", None):
+            self.engine.lib.vdf_hash_queue_destroy(self.q)
+            self.q = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
