@@ -299,17 +299,35 @@ __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ sr
         v4i ah[4], al[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) { ah[m] = (v4i){0, 0, 0, 0}; al[m] = (v4i){bias_h, bias_h, bias_h, bias_h}; }
-        for (int kt = 0; kt < T.n_kt; kt++) {
-            const v4i bh = T.bh[(kt * 2 + 0) * 64 + lane], bl = T.bh[(kt * 2 + 1) * 64 + lane];
+        // K-tile loop, software pipelined by hand: the four 16-byte pixel loads (and the two table fragments) of tile
+        // kt + 1 are issued before the eight MFMAs of tile kt, so a wave always has a tile's worth of loads in flight
+        auto load_tile = [&](int kt, v4i (&px)[4], v4i &tbh, v4i &tbl) {
+            tbh = T.bh[(kt * 2 + 0) * 64 + lane];
+            tbl = T.bh[(kt * 2 + 1) * 64 + lane];
             const uint32_t x = 64u * kt + 16u * g;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const uint32_t row = 64u * rg + 16u * m + r16;
-                v4i a = {0, 0, 0, 0};
-                if (row < H && x < W) a = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
-                a ^= (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-                ah[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah[m], 0, 0, 0);
-                al[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al[m], 0, 0, 0);
+                px[m] = (v4i){0, 0, 0, 0};
+                if (row < H && x < W) px[m] = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
+            }
+        };
+        const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+        v4i cur[4], nxt[4], cbh, cbl, nbh, nbl;
+        load_tile(0, cur, cbh, cbl);
+        for (int kt = 0; kt < T.n_kt; kt++) {
+            const bool more = kt + 1 < T.n_kt;
+            if (more) load_tile(kt + 1, nxt, nbh, nbl);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4i a = cur[m] ^ x80;
+                ah[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, cbh, ah[m], 0, 0, 0);
+                al[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, cbl, al[m], 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) cur[m] = nxt[m];
+                cbh = nbh; cbl = nbl;
             }
         }
         v4i b;
