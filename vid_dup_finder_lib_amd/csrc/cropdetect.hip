@@ -34,7 +34,20 @@ __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p
     for (int k = 0; k < 4; k++) hist[lane + 64 * k] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < len; i += 64) atomicAdd(&hist[p[(size_t)i * step]], 1u);
+    if (step == 1) {  // a row: four pixels per (possibly unaligned) dword load
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        const uint32_t n4 = len >> 2;
+        for (uint32_t i = lane; i < n4; i += 64) {
+            const uint32_t v = *reinterpret_cast<const u32_unaligned *>(p + 4 * (size_t)i);
+            atomicAdd(&hist[v & 255u], 1u);
+            atomicAdd(&hist[(v >> 8) & 255u], 1u);
+            atomicAdd(&hist[(v >> 16) & 255u], 1u);
+            atomicAdd(&hist[v >> 24], 1u);
+        }
+        for (uint32_t i = 4 * n4 + lane; i < len; i += 64) atomicAdd(&hist[p[i]], 1u);
+    } else {
+        for (uint32_t i = lane; i < len; i += 64) atomicAdd(&hist[p[(size_t)i * step]], 1u);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t h[4], key = 0;
