@@ -1,0 +1,105 @@
+"""Randomised differential tests: HIP path (both Hamming backends, all resize kernels) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import hashgen as hg
+from oracle import vdf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _durations(rng, n):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        return np.zeros(n, np.uint32)
+    if kind == 1:
+        return rng.integers(0, 12, size=n).astype(np.uint32)                      # many ties, tiny windows
+    if kind == 2:
+        return np.floor(np.exp(rng.uniform(0, np.log(2e5), size=n))).astype(np.uint32)
+    if kind == 3:
+        return rng.integers(4_000_000_000, 2**32, size=n, dtype=np.uint64).astype(np.uint32)  # saturating casts
+    return rng.choice(np.array([7, 8, 100, 109, 110, 111, 1000, 1100], np.uint32), size=n)
+
+
+def _clustered(rng, n):
+    """Random hashes with a random cluster structure: centres + members at random radii."""
+    w = hg.random_hashes(rng, n)
+    n_centres = int(rng.integers(1, max(2, n // 8 + 1)))
+    centres = rng.choice(n, size=min(n_centres, n), replace=False)
+    for i in range(n):
+        if rng.random() < 0.6:
+            c = int(rng.choice(centres))
+            if c != i:
+                bits = np.unpackbits(w[c].view(np.uint8), bitorder="little")
+                bits[rng.choice(1024, size=int(rng.integers(0, 420)), replace=False)] ^= 1
+                w[i] = np.packbits(bits, bitorder="little").view(np.uint64)
+    return w
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_search_fuzz(engine, seed):
+    rng = np.random.default_rng(10_000 + seed)
+    n = int(rng.integers(1, 1400))
+    w = _clustered(rng, n)
+    d = _durations(rng, n)
+    w, d, _ = hg.sort_by_duration(w, d)
+    tol = int(rng.choice([0, 1, 50, 200, 350, 351, 500, 512, 700, 1024]))
+    assert engine.search_self_sorted(w, d, tol) == orc.search_self_sorted(w, d, tol)
+    n_ref = int(rng.integers(1, 300))
+    rw = np.concatenate([w[rng.choice(n, size=n_ref // 2 + 1)], hg.random_hashes(rng, n_ref)])[:n_ref]
+    rd = np.concatenate([d[rng.choice(n, size=n_ref // 2 + 1)], _durations(rng, n_ref)])[:n_ref]
+    assert engine.search_refs_sorted(w, d, rw, rd, tol) == orc.search_refs_sorted(w, d, rw, rd, tol)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_search_fuzz_with_tiny_hit_buffer(engine, seed):
+    rng = np.random.default_rng(20_000 + seed)
+    n = int(rng.integers(200, 1200))
+    w = _clustered(rng, n)
+    d = _durations(rng, n)
+    w, d, _ = hg.sort_by_duration(w, d)
+    engine.set_hit_capacity(int(rng.integers(1, 400)))
+    try:
+        assert engine.search_self_sorted(w, d, 400) == orc.search_self_sorted(w, d, 400)
+        rw, rd = w[: n // 3], d[: n // 3]
+        assert engine.search_refs_sorted(w, d, rw, rd, 400) == orc.search_refs_sorted(w, d, rw, rd, 400)
+    finally:
+        engine.set_hit_capacity(1 << 24)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_hash_fuzz_frame_sizes(seed):
+    """Random frame sizes from 1 x 1 (up-scaling) to a few hundred pixels, random content statistics, every resize
+    kernel that accepts the size."""
+    import os
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(30_000 + seed)
+    h = int(rng.integers(1, 40)) if seed % 3 == 0 else int(rng.integers(1, 260))
+    w = int(rng.integers(1, 40)) if seed % 3 == 1 else int(rng.integers(1, 330))
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        frames = rng.integers(0, 256, size=(3, 17, h, w), dtype=np.uint8)
+    elif kind == 1:
+        frames = rng.choice(np.array([0, 255], np.uint8), size=(3, 17, h, w))               # saturating content
+    else:
+        frames = (rng.integers(0, 30, size=(3, 17, 1, 1)) + rng.integers(0, 4, size=(3, 17, h, w)) * 60).astype(np.uint8)
+    want, coefs = orc.hash_clips_with_coefs(frames)
+    care = np.abs(coefs) >= 1e-6
+    wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(3, 1024)[:, :1000]
+    for mode in (0, 1, 2, 3):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+        try:
+            got = eng.hash_frames(frames)
+        except vdf.VdfError as e:
+            assert mode in (2, 3) and e.code == -2, (mode, h, w, str(e))  # forced MFMA mode on tables that need the fallback
+            continue
+        finally:
+            eng.close()
+        gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(3, 1024)[:, :1000]
+        assert not ((gb != wb) & care).any(), (mode, h, w)
