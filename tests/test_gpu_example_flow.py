@@ -49,3 +49,31 @@ def test_two_videos_three_variants_each(engine):
     rest = hashes[1:3] + hashes[4:6]
     rg = vdf.search_with_references(refs, rest, 0.35, engine=engine)
     assert [(g.reference(), g.len()) for g in rg] == [("cat.1.mp4", 2), ("dog.1.mp4", 2)]
+
+
+def test_hash_then_reference_search_end_to_end(engine):
+    """BASELINE configs[4] shape in miniature (world size 1): hash candidate and reference clips on the device, sort,
+    search_with_references; every reference that is a noisy copy of a candidate must find exactly that candidate."""
+    import torch
+
+    from oracle import vdf_oracle as orc
+    from vid_dup_finder_lib_amd import distributed as vd
+
+    rng = np.random.default_rng(9)
+    n_cand, n_ref = 300, 60
+    cand = np.stack([_video(rng, 32, 48) for _ in range(n_cand)])
+    src = rng.choice(n_cand, size=n_ref // 2, replace=False)
+    ref = np.concatenate([np.clip(cand[src].astype(np.int16) + rng.integers(-4, 5, cand[src].shape), 0, 255).astype(np.uint8),
+                          np.stack([_video(rng, 32, 48) for _ in range(n_ref - n_ref // 2)])])
+    cd = rng.integers(100, 120, size=n_cand).astype(np.int32)
+    rd = np.concatenate([cd[src], rng.integers(100, 120, size=n_ref - n_ref // 2).astype(np.int32)])
+    groups, order = vd.hash_and_search_refs(engine, torch.from_numpy(cand).cuda(), torch.from_numpy(cd).cuda(),
+                                            torch.from_numpy(ref).cuda(), torch.from_numpy(rd).cuda(), 350)
+    found = {r: [int(order[m]) for m in ms] for r, ms in groups}
+    for k, s in enumerate(src):
+        assert int(s) in found.get(k, []), (k, s)
+    # the same thing through the oracle (hash on CPU, search on CPU)
+    ch, rh = orc.hash_clips(cand), orc.hash_clips(ref)
+    o = np.argsort(cd, kind="stable")
+    want = orc.search_refs_sorted(ch[o], cd[o].astype(np.uint32), rh, rd.astype(np.uint32), 350)
+    assert [(r, [int(o[m]) for m in ms]) for r, ms in want] == [(r, found[r]) for r, _ in want] and len(want) == len(groups)

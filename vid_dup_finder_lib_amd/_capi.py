@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdf_hip.so")
@@ -133,6 +134,15 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C vid_dup_finder_lib_amd/csrc`). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If libvdf_hip.so pulled in
+        # /opt/rocm's copy first, a later `import torch` would load a SECOND runtime, which then finds no GPU.
+        # Importing torch first makes the loader satisfy our NEEDED libamdhip64.so.7 with the copy already mapped.
+        # (C/C++/Rust hosts have no torch in the process and link /opt/rocm's runtime as usual.)
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

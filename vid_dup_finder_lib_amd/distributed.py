@@ -163,3 +163,43 @@ def search_refs_sharded(engine, d_cand_words: torch.Tensor, d_cand_dur: torch.Te
     if rank != 0:
         return None
     return _eng.groups_from_ref_hits(merged)
+
+
+def hash_and_search_refs(engine, cand_frames: torch.Tensor, cand_dur: torch.Tensor, ref_frames: torch.Tensor,
+                         ref_dur: torch.Tensor, tol_int: int, group=None, stream: int = 0):
+    """BASELINE configs[4] end to end: every rank hashes ITS candidate clips and ITS reference clips (uint8 device
+    tensors [n, >=16, H, W]; no communication), the candidate hashes are replicated with one all-gather and sorted by
+    duration (stable; paths, if any, stay with the caller), references keep rank order, then
+    search_with_references runs sharded.  Rank 0 returns (groups, order): groups = [(global reference index,
+    [positions in the sorted candidate order])], order[k] = global candidate index (rank-major) at sorted position k."""
+    rank, world = _world(group)
+    dev = cand_frames.device
+
+    def _hash(frames):
+        n, nf, h, w = frames.shape
+        out = torch.zeros((n, HASH_WORDS), dtype=torch.int64, device=dev)
+        if n:
+            torch.cuda.current_stream().synchronize() if dev.type == "cuda" and not stream else None
+            engine.hash_frames_device(frames.data_ptr(), n, nf, w, h, out.data_ptr(), stream=stream)
+        return out
+
+    cw = _hash(cand_frames.contiguous())
+    rw = _hash(ref_frames.contiguous())
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    full_w, full_d = all_gather_database(cw, cand_dur.to(torch.int32), group)
+    order = torch.sort(full_d, stable=True).indices  # Search::sort with equal paths: stable by duration
+    sorted_w = full_w.index_select(0, order).contiguous()
+    sorted_d = full_d.index_select(0, order).contiguous()
+    # global index of this rank's first reference
+    n_ref = torch.tensor([rw.shape[0]], dtype=torch.int64, device=_coll_device(group) if world > 1 else dev)
+    base = 0
+    if world > 1:
+        counts = [torch.zeros_like(n_ref) for _ in range(world)]
+        dist.all_gather(counts, n_ref, group=group)
+        base = int(sum(int(c.item()) for c in counts[:rank]))
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    groups = search_refs_sharded(engine, sorted_w, sorted_d, rw, ref_dur.to(torch.int32).contiguous(), base, tol_int,
+                                 group=group, stream=stream)
+    return (groups, order.cpu().numpy()) if rank == 0 else (None, None)
