@@ -164,6 +164,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.tol = tol_int;
     L.matched = d_matched;
     L.self_mode = (mode == 0);
+    L.shard_index = shard_index;
+    L.shard_count = shard_count;
     L.hits = ctx->hits.as<vdf_hit>();
     L.capacity = capacity;
     L.counters = ctx->counters.as<unsigned long long>();

@@ -161,9 +161,10 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__rest
 // (row tile, chunk) is outside the tile's range exit at once (a few % of the grid near the diagonal).
 __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__restrict__ tile_first,
                                                           const uint32_t *__restrict__ tile_count, uint32_t n_row_tiles,
-                                                          uint32_t group_size, uint32_t *__restrict__ group_cmin,
+                                                          uint32_t group_size, uint32_t shard_count,
+                                                          uint32_t *__restrict__ group_cmin,
                                                           uint32_t *__restrict__ group_blocks)
-{  // one workgroup per group: chunk range covered by its row tiles
+{  // one workgroup per group: chunk range covered by its row tiles; only every shard_count-th tile is this rank's
     __shared__ uint32_t s_min[4], s_max[4];
     const uint32_t g = blockIdx.x;
     uint32_t cmin = 0xFFFFFFFFu, cmax = 0;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__rest
         cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (cmax <= cmin) { cmin = 0; cmax = 0; }
         group_cmin[g] = cmin;
-        group_blocks[g] = (cmax - cmin) * group_size;
+        group_blocks[g] = (cmax - cmin) * ((group_size + shard_count - 1) / shard_count);
     }
 }
 
@@ -342,7 +343,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
     const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
     const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ group_offset, const uint32_t *__restrict__ group_cmin, uint32_t n_groups,
-    uint32_t group_size, uint32_t n_row_tiles, uint32_t chunk_cols, uint32_t tol,
+    uint32_t group_size, uint32_t shard_index, uint32_t shard_count, uint32_t n_row_tiles, uint32_t chunk_cols,
+    uint32_t tol,
     const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
     unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base)
 {
@@ -358,9 +360,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
         if (goff[mid] <= bid) gl = mid; else gh = mid;
     }
     const uint32_t idx = bid - goff[gl];
-    const uint32_t t = gl * group_size + idx % group_size;
-    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / group_size;
-    if (t >= n_row_tiles) return;
+    // this rank's tiles of the group: t = t0, t0 + shard_count, ... (t % shard_count == shard_index)
+    const uint32_t per_group = (group_size + shard_count - 1) / shard_count;
+    const uint32_t g0 = gl * group_size;
+    const uint32_t t0 = g0 + (shard_index + shard_count - g0 % shard_count) % shard_count;
+    const uint32_t t = t0 + (idx % per_group) * shard_count;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / per_group;
+    if (t >= n_row_tiles || t >= g0 + group_size) return;
     {
         const uint32_t f = ((const_u32_ptr)(uintptr_t)tile_first)[t], cnt = ((const_u32_ptr)(uintptr_t)tile_count)[t];
         if (chunk < f || chunk >= f + cnt) return;
@@ -488,7 +494,7 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, L.tile_count, L.n_row_tiles, L.tile_offset);
     if (L.n_groups) {
         hipLaunchKernelGGL(group_tiles_kernel, dim3(L.n_groups), dim3(256), 0, stream, L.tile_first, L.tile_count,
-                           L.n_row_tiles, L.group_size, L.group_cmin, L.group_blocks);
+                           L.n_row_tiles, L.group_size, L.shard_count, L.group_cmin, L.group_blocks);
         hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(64), 0, stream, L.group_blocks, L.n_groups, L.group_offset);
     }
     return hipGetLastError();
@@ -589,8 +595,8 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
                        reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,           \
                        reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
                        L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
-                       L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters,    \
-                       L.overflow_row, base)
+                       L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
+                       L.hits, L.capacity, L.counters, L.overflow_row, base)
         switch (L.ablate) {
         case 1: VDF_MFMA_LAUNCH(1); break;
         case 2: VDF_MFMA_LAUNCH(2); break;
