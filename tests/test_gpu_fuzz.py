@@ -5,7 +5,11 @@ import pytest
 import hashgen as hg
 from oracle import vdf_oracle as orc
 
+import os
+
 pytestmark = pytest.mark.gpu
+# VDF_FUZZ_SEEDS=N widens every case list for a soak run (default sizes keep the suite fast)
+_SOAK = int(os.environ.get("VDF_FUZZ_SEEDS", "0"))
 
 
 def _durations(rng, n):
@@ -36,7 +40,7 @@ def _clustered(rng, n):
     return w
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(max(40, _SOAK)))
 def test_search_fuzz(engine, seed):
     rng = np.random.default_rng(10_000 + seed)
     n = int(rng.integers(1, 1400))
@@ -51,7 +55,7 @@ def test_search_fuzz(engine, seed):
     assert engine.search_refs_sorted(w, d, rw, rd, tol) == orc.search_refs_sorted(w, d, rw, rd, tol)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, _SOAK // 8)))
 def test_search_fuzz_with_tiny_hit_buffer(engine, seed):
     rng = np.random.default_rng(20_000 + seed)
     n = int(rng.integers(200, 1200))
@@ -67,7 +71,7 @@ def test_search_fuzz_with_tiny_hit_buffer(engine, seed):
         engine.set_hit_capacity(1 << 24)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(max(24, _SOAK // 2)))
 def test_hash_fuzz_frame_sizes(seed):
     """Random frame sizes from 1 x 1 (up-scaling) to a few hundred pixels, random content statistics, every resize
     kernel that accepts the size."""
