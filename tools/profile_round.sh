@@ -15,6 +15,6 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search --
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hash -- $H1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_hash -- $H1 > /dev/null 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/sq_search -- $B1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq_hash -- $H1 > /dev/null 2>&1
 ls $O
