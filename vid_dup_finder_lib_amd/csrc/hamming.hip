@@ -330,14 +330,16 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
 }
 
 constexpr uint32_t kMfmaWaves = 4;                          // waves per workgroup sharing one staged candidate tile
-constexpr uint32_t kMfmaTileRows = 64 * kMfmaWaves;         // 64 target rows per wave
+constexpr int kRowTiles = 2;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
+constexpr int kPrefetch = kRowTiles == 1 ? 4 : 8;           // LDS fragments in flight ahead of the MFMAs
+constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
 constexpr uint32_t kMfmaSub = 2;                     // 32-column sub-tiles per LDS stage
 constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
 
 // ABLATE (timing experiments only, results are wrong when != 0): 1 = no epilogue test, 2 = no DMA after the first
 // stage, 3 = no DMA and no barrier.
 template <int ABLATE>
-__global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
+__global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
     const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
@@ -378,10 +380,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
     if (c_begin >= c_end) return;
 
     // targets: 2 row tiles of 32 per wave, all 16 k-steps (32 chunks of 16 B per hash: lane group g takes chunks 16 g ..)
-    const uint32_t row0 = t * kMfmaTileRows + wave * 64;
-    v4i a[2][16];
+    const uint32_t row0 = t * kMfmaTileRows + wave * (32 * kRowTiles);
+    v4i a[kRowTiles][16];
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++) {
+    for (int rt = 0; rt < kRowTiles; rt++) {
         const uint32_t p = row0 + 32 * rt + c31;
         uint32_t src = p;
         if (p < n_rows && row_perm) src = row_perm[p];
@@ -423,28 +425,31 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
 #pragma unroll
         for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
         if (cb + 32u * sub >= c_end) break;
-        v16f acc0 = {}, acc1 = {};
+        v16f acc[kRowTiles];
+#pragma unroll
+        for (int rt = 0; rt < kRowTiles; rt++) acc[rt] = v16f{};
         // LDS fragment reads run 8 steps ahead of the MFMAs that consume them (bounded so that 128 A + 32 C + 32 B
         // registers stay under the 256-VGPR budget of 2 waves per SIMD without spills)
         const uint32_t lds_row = (32u * sub + c31) << 5;
-        uint4 bq[8];
+        uint4 bq[kPrefetch];
 #pragma unroll
-        for (int s = 0; s < 8; s++) bq[s] = s_b[buf][lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
+        for (int s = 0; s < kPrefetch; s++) bq[s] = s_b[buf][lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
 #pragma unroll
         for (int s = 0; s < 16; s++) {
-            const uint4 bv = bq[s & 7];
+            const uint4 bv = bq[s % kPrefetch];
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
-            const v8i a0 = {a[0][s].x, a[0][s].y, a[0][s].z, a[0][s].w, 0, 0, 0, 0};
-            const v8i a1 = {a[1][s].x, a[1][s].y, a[1][s].z, a[1][s].w, 0, 0, 0, 0};
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b, acc0, 4, 4, 0, 127, 0, 127);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b, acc1, 4, 4, 0, 127, 0, 127);
-            if (s + 8 < 16) bq[s & 7] = s_b[buf][lds_row | ((uint32_t)(s + 8 + 16 * g) ^ c31)];
+#pragma unroll
+            for (int rt = 0; rt < kRowTiles; rt++) {
+                const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
+                acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
+            }
+            if (s + kPrefetch < 16) bq[s % kPrefetch] = s_b[buf][lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
         }
-        float m = acc0[0];
+        float m = acc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; r++) m = fmaxf(m, acc0[r]);
+        for (int rt = 0; rt < kRowTiles; rt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) m = fmaxf(m, acc1[r]);
+            for (int r = 0; r < 16; r++) m = fmaxf(m, acc[rt][r]);
         if (ABLATE == 1) { asm volatile("" ::"v"(m)); m = -2048.0f; }
         if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
             // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
@@ -452,10 +457,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void hamming_mfma_kernel(
             bool col_ok = j >= c_begin && j < c_end;
             if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
 #pragma unroll
-            for (int rt = 0; rt < 2; rt++) {
+            for (int rt = 0; rt < kRowTiles; rt++) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float d = rt ? acc1[r] : acc0[r];
+                    const float d = acc[rt][r];
                     if (col_ok && d >= thresh) {
                         const uint32_t p = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
                         const uint32_t lo = row_lo[p], hi = row_hi[p];
