@@ -331,7 +331,10 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
 
 constexpr uint32_t kMfmaWaves = 4;                          // waves per workgroup sharing one staged candidate tile
 constexpr int kRowTiles = 2;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
-constexpr int kPrefetch = kRowTiles == 1 ? 4 : 8;           // LDS fragments in flight ahead of the MFMAs
+#ifndef VDF_PF
+#define VDF_PF (kRowTiles == 1 ? 4 : 8)
+#endif
+constexpr int kPrefetch = VDF_PF;           // LDS fragments in flight ahead of the MFMAs
 constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
 constexpr uint32_t kMfmaSub = 2;                     // 32-column sub-tiles per LDS stage
 constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
