@@ -125,10 +125,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also at world size 1)
+    # VDF_DIST_BACKEND=gloo (testing only): ranks may outnumber GPUs; collectives run on host copies
+    dist_backend = os.environ.get("VDF_DIST_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world:
@@ -182,7 +189,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cdev = dev if dist_backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -264,7 +272,7 @@ def main():
             eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
         ev1.record()
         torch.cuda.synchronize()
-        ms_t = torch.tensor([ev0.elapsed_time(ev1) / args.steps], dtype=torch.float64, device=dev)
+        ms_t = torch.tensor([ev0.elapsed_time(ev1) / args.steps], dtype=torch.float64, device=cdev)
         if use_dist:
             dist.all_reduce(ms_t, op=dist.ReduceOp.MAX)
         ms = float(ms_t.item())

@@ -42,6 +42,10 @@ def all_gather_database(local_words: torch.Tensor, local_dur: torch.Tensor, grou
     if world == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return local_words, local_dur
     dev = local_words.device
+    if dev.type == "cuda" and dist.get_backend(group) != "nccl":
+        # test-only route (e.g. two ranks sharing one GPU over gloo): run the collective on host copies
+        w, d = all_gather_database(local_words.cpu(), local_dur.cpu(), group, force)
+        return w.to(dev), d.to(dev)
     n_local = torch.tensor([local_words.shape[0]], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
