@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
 constexpr uint32_t kMfmaWaves = 4;                          // waves per workgroup sharing one staged candidate tile
 constexpr int kRowTiles = 2;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
 #ifndef VDF_PF
-#define VDF_PF (kRowTiles == 1 ? 4 : 8)
+#define VDF_PF (kRowTiles == 1 ? 4 : 6)
 #endif
 constexpr int kPrefetch = VDF_PF;           // LDS fragments in flight ahead of the MFMAs
 constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
@@ -354,8 +354,12 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
     unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base)
 {
     const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
-    __shared__ __attribute__((aligned(16))) uint4 s_b[2][kMfmaColStep * 32];  // 2 x 16 KB: [col][chunk ^ col] swizzled
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c31 = lane & 31;
+    // 2 x 32 KB stages, [col][chunk ^ col] swizzled.  Two separate arrays (not s_b[2][..]) on purpose: the compiler
+    // then knows a DMA into one never aliases an LDS read of the other and does not wait on vmcnt before the reads.
+    __shared__ __attribute__((aligned(16))) uint4 s_b0[kMfmaColStep * 32];
+    __shared__ __attribute__((aligned(16))) uint4 s_b1[kMfmaColStep * 32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c31 = lane & 31;
+    const uint32_t wave = tid >> 6;
 
     // workgroup -> (group, chunk, row tile in group): chunk-major inside a group
     const_u32_ptr goff = (const_u32_ptr)(uintptr_t)group_offset;
@@ -405,38 +409,44 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
     // address; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
     const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
     constexpr int kDmaPerWave = (int)(kMfmaColStep * 32 / (64 * kMfmaWaves));  // 1 KB DMA instructions per wave per stage
-    uint32_t lane_off[kDmaPerWave];  // loop-invariant byte offset of this lane's source chunk inside a stage
+    // Piece i of this wave fills LDS slots L = 256 i + 64 wave + lane: column c = 8 i + c0 (c0 = 2 wave + g < 8),
+    // chunk q = lane & 31, source byte offset c * 512 + ((q ^ c) << 4).  Since c0 < 8, q ^ c = (q ^ c0) ^ 8 (i & 3):
+    // four per-lane offsets cover all pieces and the 4096 i part is wave-uniform (scalar base).
+    static_assert(kMfmaWaves == 4, "piece addressing assumes 256 slots per round of pieces");
+    const uint32_t c0 = 2 * wave + g;
+    uint32_t lane_off[4];
 #pragma unroll
-    for (int i = 0; i < kDmaPerWave; i++) {
-        const uint32_t L = 64 * kMfmaWaves * i + 64 * wave + lane, c = L >> 5, q = L & 31;
-        lane_off[i] = c * 512u + ((q ^ (c & 31)) << 4);
-    }
-    auto load_stage = [&](uint32_t cb, int buf) {
-        const char *base = reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512;  // wave-uniform (SGPR pair)
-#pragma unroll
-        for (int i = 0; i < kDmaPerWave; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off[i]),
-                                             (__attribute__((address_space(3))) void *)&s_b[buf][64 * kMfmaWaves * i + 64 * wave],
-                                             16, 0, 0);
+    for (int j = 0; j < 4; j++) lane_off[j] = c0 * 512u + ((((lane & 31) ^ c0) << 4) ^ (128u * j));
+    const uint64_t col_base = (uint64_t)(uintptr_t)col_exp;
+    auto load_piece = [&](uint32_t cb, uint4 *dst, int i) {
+        // wave-uniform base in SGPRs + 32-bit per-lane offset: the saddr form, no 64-bit VGPR address
+        const uint64_t b64 = col_base + (uint64_t)cb * 512 + 4096u * (uint32_t)i;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b64);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32));
+        const char *base = reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off[i & 3]),
+                                         (__attribute__((address_space(3))) void *)&dst[64 * kMfmaWaves * i + 64 * wave],
+                                         16, 0, 0);
     };
-    load_stage(cb0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (uint32_t cb = cb0; cb < c_end; cb += kMfmaColStep, buf ^= 1) {
-        const bool more = cb + kMfmaColStep < c_end;
-        if (more && ABLATE < 2) load_stage(cb + kMfmaColStep, buf ^ 1);  // lands under the MFMAs below
+    // one stage: MFMAs over the 64 candidates in `cur` while the next stage's DMA pieces go out to `nxt`
+    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) {
+        // The next stage's DMA pieces are issued one at a time between the MFMAs of sub-tile 0 (a 1 KB piece costs the
+        // issuing wave 60-185 cycles when bunched with the LDS reads at the top of a stage).  Branch-free so that the
+        // pinned schedule stays one region: the last stage re-fetches itself into the idle buffer.
+        const uint32_t cb_next = cb + kMfmaColStep < c_end ? cb + kMfmaColStep : cb;
 #pragma unroll
         for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
         if (cb + 32u * sub >= c_end) break;
         v16f acc[kRowTiles];
 #pragma unroll
         for (int rt = 0; rt < kRowTiles; rt++) acc[rt] = v16f{};
-        // LDS fragment reads run 8 steps ahead of the MFMAs that consume them (bounded so that 128 A + 32 C + 32 B
-        // registers stay under the 256-VGPR budget of 2 waves per SIMD without spills)
+        // LDS fragment reads run kPrefetch steps ahead of the MFMAs that consume them (bounded so that 128 A + 32 C +
+        // 4 kPrefetch B registers stay under the 256-VGPR budget of 2 waves per SIMD without spills)
         const uint32_t lds_row = (32u * sub + c31) << 5;
         uint4 bq[kPrefetch];
 #pragma unroll
-        for (int s = 0; s < kPrefetch; s++) bq[s] = s_b[buf][lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
+        for (int s = 0; s < kPrefetch; s++) bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
+        __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the whole prologue of LDS reads up front
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const uint4 bv = bq[s % kPrefetch];
@@ -446,7 +456,14 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
                 const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
                 acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
             }
-            if (s + kPrefetch < 16) bq[s % kPrefetch] = s_b[buf][lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
+            if (s + kPrefetch < 16) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
+            constexpr int kDmaEvery = 16 / kDmaPerWave;
+            const bool dma_here = ABLATE < 2 && sub == 0 && s % kDmaEvery == 0;
+            if (dma_here) load_piece(cb_next, nxt, s / kDmaEvery);
+            // pin the software pipeline: the scheduler otherwise sinks each LDS read next to its MFMA (1-2 deep)
+            __builtin_amdgcn_sched_group_barrier(0x008, kRowTiles, 0);
+            if (s + kPrefetch < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (dma_here) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
         float m = acc[0][0];
 #pragma unroll
@@ -486,7 +503,21 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
             }
         }
         }
-        if (ABLATE < 3) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with s_b[buf]
+        if (ABLATE < 3) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
+    };
+#pragma unroll
+    for (int i = 0; i < kDmaPerWave; i++) load_piece(cb0, s_b0, i);
+    // Retire the target loads here: otherwise the loop header inherits "a[] may still be in flight" from this path and
+    // the MFMAs inside the loop wait on vmcnt(0), i.e. on the DMA pieces issued just before them.
+#pragma unroll
+    for (int rt = 0; rt < kRowTiles; rt++)
+#pragma unroll
+        for (int s = 0; s < 16; s++) asm volatile("" ::"v"(a[rt][s]));
+    __syncthreads();
+    for (uint32_t cb = cb0; cb < c_end; cb += 2 * kMfmaColStep) {
+        run_stage(cb, s_b0, s_b1);
+        if (cb + kMfmaColStep >= c_end) break;
+        run_stage(cb + kMfmaColStep, s_b1, s_b0);
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
 }
