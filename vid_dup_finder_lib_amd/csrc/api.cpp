@@ -67,7 +67,7 @@ struct vdf_ctx {
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
-    uint32_t mfma_chunk_cols = 4096, mfma_group = 8192;
+    uint32_t mfma_chunk_cols = 16384, mfma_group = 8192;  // 16384-column chunks: longer workgroups amortise the target loads (swept 2048..65536)
     DevBuf group_cmin, group_offset, group_blocks;
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;

@@ -329,18 +329,27 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
     }
 }
 
-constexpr uint32_t kMfmaWaves = 4;                          // waves per workgroup sharing one staged candidate tile
+constexpr uint32_t kMfmaWaves = VDF_MFMA_WAVES;                          // waves per workgroup sharing one staged candidate tile
 constexpr int kRowTiles = 2;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
 #ifndef VDF_PF
 #define VDF_PF (kRowTiles == 1 ? 4 : 6)
 #endif
 constexpr int kPrefetch = VDF_PF;           // LDS fragments in flight ahead of the MFMAs
 constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
-constexpr uint32_t kMfmaSub = 2;                     // 32-column sub-tiles per LDS stage
+#ifndef VDF_MFMA_SUB
+#define VDF_MFMA_SUB 2
+#endif
+constexpr uint32_t kMfmaSub = VDF_MFMA_SUB;                     // 32-column sub-tiles per LDS stage
+#ifndef VDF_DMA_SUBS
+#define VDF_DMA_SUBS 1
+#endif
+constexpr uint32_t kDmaSubs = VDF_DMA_SUBS;          // leading sub-tiles of a stage that carry the next stage's DMA pieces
 constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
 
-// ABLATE (timing experiments only, results are wrong when != 0): 1 = no epilogue test, 2 = no DMA after the first
-// stage, 3 = no DMA and no barrier.
+// ABLATE (timing experiments only; != 0 reports no hits at all): 1 = hit test off, 2 = no DMA after the first stage,
+// 3 = no DMA and no barrier, 4 = no LDS reads (B fragments stay in registers; DMA and barrier kept), 5 = no LDS reads,
+// no DMA, no barrier (the bare MFMA stream inside the kernel's workgroup structure), 6 = every other DMA piece only,
+// 7 = all DMA pieces but 4 bytes per lane instead of 16 (same instruction count, a quarter of the data).
 template <int ABLATE>
 __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
     const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
     unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base)
 {
+    constexpr bool kNoLds = ABLATE == 4 || ABLATE == 5;
     const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
     // 2 x 32 KB stages, [col][chunk ^ col] swizzled.  Two separate arrays (not s_b[2][..]) on purpose: the compiler
     // then knows a DMA into one never aliases an LDS read of the other and does not wait on vmcnt before the reads.
@@ -409,31 +419,36 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
     // address; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
     const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
     constexpr int kDmaPerWave = (int)(kMfmaColStep * 32 / (64 * kMfmaWaves));  // 1 KB DMA instructions per wave per stage
-    // Piece i of this wave fills LDS slots L = 256 i + 64 wave + lane: column c = 8 i + c0 (c0 = 2 wave + g < 8),
-    // chunk q = lane & 31, source byte offset c * 512 + ((q ^ c) << 4).  Since c0 < 8, q ^ c = (q ^ c0) ^ 8 (i & 3):
-    // four per-lane offsets cover all pieces and the 4096 i part is wave-uniform (scalar base).
-    static_assert(kMfmaWaves == 4, "piece addressing assumes 256 slots per round of pieces");
+    // Piece i of this wave fills LDS slots L = 64 W i + 64 wave + lane (W waves): column c = 2 W i + c0 with
+    // c0 = 2 wave + g < 2 W, chunk q = lane & 31, source byte offset c * 512 + ((q ^ c) << 4).  Since c0 < 2 W,
+    // q ^ c = (q ^ c0) ^ (2 W i & 31): 16 / W per-lane offsets cover all pieces, the 1024 W i part is wave-uniform.
+    constexpr uint32_t kColsPerRound = 2 * kMfmaWaves;
+    constexpr int kOffsets = 32 / kColsPerRound;
+    static_assert(kOffsets >= 1 && (kOffsets & (kOffsets - 1)) == 0, "piece addressing");
     const uint32_t c0 = 2 * wave + g;
-    uint32_t lane_off[4];
+    uint32_t lane_off[kOffsets];
 #pragma unroll
-    for (int j = 0; j < 4; j++) lane_off[j] = c0 * 512u + ((((lane & 31) ^ c0) << 4) ^ (128u * j));
-    const uint64_t col_base = (uint64_t)(uintptr_t)col_exp;
-    auto load_piece = [&](uint32_t cb, uint4 *dst, int i) {
-        // wave-uniform base in SGPRs + 32-bit per-lane offset: the saddr form, no 64-bit VGPR address
-        const uint64_t b64 = col_base + (uint64_t)cb * 512 + 4096u * (uint32_t)i;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b64);
-        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32));
-        const char *base = reinterpret_cast<const char *>((uintptr_t)(((uint64_t)hi << 32) | lo));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off[i & 3]),
-                                         (__attribute__((address_space(3))) void *)&dst[64 * kMfmaWaves * i + 64 * wave],
-                                         16, 0, 0);
+    for (int j = 0; j < kOffsets; j++) lane_off[j] = c0 * 512u + ((((lane & 31) ^ c0) << 4) ^ (16u * kColsPerRound * j));
+    // buffer_load ... lds (MUBUF), not global_load_lds: after a FLAT-encoded LDS-DMA the compiler assumes lgkmcnt may
+    // complete out of order and drains every outstanding ds_read with lgkmcnt(0) before the next MFMA.
+    // The resource covers one stage (base = wave-uniform stage address, rebuilt with SALU per stage).
+    auto stage_rsrc = [&](uint32_t cb) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512), 0, kMfmaColStep * 512u, 0x00020000);
+    };
+    auto load_piece = [&](__amdgpu_buffer_rsrc_t rs, uint4 *dst, int i) __attribute__((always_inline)) {
+        if (ABLATE == 6 && (i & 1)) return;
+        auto *lds = (__attribute__((address_space(3))) void *)&dst[64 * kMfmaWaves * i + 64 * wave];
+        const int voff = (int)lane_off[i & (kOffsets - 1)], soff = (int)(512u * kColsPerRound * (uint32_t)i);
+        if constexpr (ABLATE == 7) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 4, voff, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
     };
     // one stage: MFMAs over the 64 candidates in `cur` while the next stage's DMA pieces go out to `nxt`
-    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) {
+    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) {
         // The next stage's DMA pieces are issued one at a time between the MFMAs of sub-tile 0 (a 1 KB piece costs the
         // issuing wave 60-185 cycles when bunched with the LDS reads at the top of a stage).  Branch-free so that the
         // pinned schedule stays one region: the last stage re-fetches itself into the idle buffer.
-        const uint32_t cb_next = cb + kMfmaColStep < c_end ? cb + kMfmaColStep : cb;
+        const __amdgpu_buffer_rsrc_t rs_next = stage_rsrc(cb + kMfmaColStep < c_end ? cb + kMfmaColStep : cb);
 #pragma unroll
         for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
         if (cb + 32u * sub >= c_end) break;
@@ -445,8 +460,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
         const uint32_t lds_row = (32u * sub + c31) << 5;
         uint4 bq[kPrefetch];
 #pragma unroll
-        for (int s = 0; s < kPrefetch; s++) bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
-        __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the whole prologue of LDS reads up front
+        for (int s = 0; s < kPrefetch; s++) {
+            if (kNoLds) bq[s] = make_uint4((uint32_t)a[0][s].x, (uint32_t)a[0][s].y, (uint32_t)a[0][s].z, (uint32_t)a[0][s].w);
+            else bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
+        }
+        if (!kNoLds) __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the prologue of LDS reads up front
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             const uint4 bv = bq[s % kPrefetch];
@@ -456,13 +474,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
                 const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
                 acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
             }
-            if (s + kPrefetch < 16) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
-            constexpr int kDmaEvery = 16 / kDmaPerWave;
-            const bool dma_here = ABLATE < 2 && sub == 0 && s % kDmaEvery == 0;
-            if (dma_here) load_piece(cb_next, nxt, s / kDmaEvery);
+            if (!kNoLds && s + kPrefetch < 16) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
+            constexpr int kDmaEvery = 16 * kDmaSubs / kDmaPerWave;
+            const bool dma_here = (ABLATE < 2 || ABLATE == 4 || ABLATE >= 6) && sub < kDmaSubs && (16 * (int)sub + s) % kDmaEvery == 0;
+            if (dma_here) load_piece(rs_next, nxt, (16 * (int)sub + s) / kDmaEvery);
             // pin the software pipeline: the scheduler otherwise sinks each LDS read next to its MFMA (1-2 deep)
             __builtin_amdgcn_sched_group_barrier(0x008, kRowTiles, 0);
-            if (s + kPrefetch < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (!kNoLds && s + kPrefetch < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (dma_here) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
         float m = acc[0][0];
@@ -470,7 +488,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
         for (int rt = 0; rt < kRowTiles; rt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) m = fmaxf(m, acc[rt][r]);
-        if (ABLATE == 1) { asm volatile("" ::"v"(m)); m = -2048.0f; }
+        if (ABLATE >= 1) { asm volatile("" ::"v"(m)); m = -2048.0f; }
         if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
             // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
             const uint32_t j = cb + 32u * sub + c31;
@@ -503,10 +521,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void ham
             }
         }
         }
-        if (ABLATE < 3) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
+        if (ABLATE < 3 || ABLATE == 4 || ABLATE >= 6) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
     };
 #pragma unroll
-    for (int i = 0; i < kDmaPerWave; i++) load_piece(cb0, s_b0, i);
+    for (int i = 0; i < kDmaPerWave; i++) load_piece(stage_rsrc(cb0), s_b0, i);
     // Retire the target loads here: otherwise the loop header inherits "a[] may still be in flight" from this path and
     // the MFMAs inside the loop wait on vmcnt(0), i.e. on the DMA pieces issued just before them.
 #pragma unroll
@@ -640,6 +658,10 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
         case 1: VDF_MFMA_LAUNCH(1); break;
         case 2: VDF_MFMA_LAUNCH(2); break;
         case 3: VDF_MFMA_LAUNCH(3); break;
+        case 4: VDF_MFMA_LAUNCH(4); break;
+        case 5: VDF_MFMA_LAUNCH(5); break;
+        case 6: VDF_MFMA_LAUNCH(6); break;
+        case 7: VDF_MFMA_LAUNCH(7); break;
         default: VDF_MFMA_LAUNCH(0); break;
         }
 #undef VDF_MFMA_LAUNCH

@@ -52,7 +52,10 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                                 hipStream_t stream);
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 // MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of the tile, columns by a further 128.
-constexpr uint32_t kMfmaRowPad = 256, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile (4 waves x 64; 8 waves measured slower)
+#ifndef VDF_MFMA_WAVES
+#define VDF_MFMA_WAVES 4  // waves per MFMA workgroup (build-time experiment knob; 64 target rows per wave)
+#endif
+constexpr uint32_t kMfmaRowPad = 64 * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
