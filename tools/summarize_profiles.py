@@ -63,7 +63,7 @@ for k in summary.get("fetch_search", {}):
                                            "candidates arrive through scalar-cache line fills (64-B requests): no x2 correction applied")
     if k.startswith("hamming_mfma_kernel"):
         t["hamming_mfma_kernel"] = traffic("fetch_search", "write_search", k, 2,
-                                           "candidate tiles stream through global_load_lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
+                                           "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
 for k in summary.get("fetch_hash", {}):
     if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
         t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,

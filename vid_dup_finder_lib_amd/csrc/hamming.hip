@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
 }
 
 constexpr uint32_t kMfmaWaves = VDF_MFMA_WAVES;                          // waves per workgroup sharing one staged candidate tile
-constexpr int kRowTiles = 2;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
+constexpr int kRowTiles = VDF_ROW_TILES;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
 #ifndef VDF_PF
 #define VDF_PF (kRowTiles == 1 ? 4 : 6)
 #endif
@@ -351,7 +351,7 @@ constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage
 // no DMA, no barrier (the bare MFMA stream inside the kernel's workgroup structure), 6 = every other DMA piece only,
 // 7 = all DMA pieces but 4 bytes per lane instead of 16 (same instruction count, a quarter of the data).
 template <int ABLATE>
-__global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : 2)) void hamming_mfma_kernel(
+__global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles == 2 ? 2 : 1)) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
     const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,

@@ -55,7 +55,10 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
 #ifndef VDF_MFMA_WAVES
 #define VDF_MFMA_WAVES 4  // waves per MFMA workgroup (build-time experiment knob; 64 target rows per wave)
 #endif
-constexpr uint32_t kMfmaRowPad = 64 * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
+#ifndef VDF_ROW_TILES
+#define VDF_ROW_TILES 2  // 32-row MFMA tiles per wave (build-time experiment knob)
+#endif
+constexpr uint32_t kMfmaRowPad = 32 * VDF_ROW_TILES * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
