@@ -50,9 +50,9 @@ int main()
         vdf::HostAxisTable t;
         assert(vdf::build_axis_table(sz, 16, t));
         for (int o = 0; o < 16; o++) assert(t.start[o] >= 0 && t.start[o] + t.size[o] <= (int32_t)sz);
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < 3; v++) {
             vdf::MfmaAxisTable m;
-            assert(vdf::build_mfma_axis_table(sz, v == 1, m));
+            assert(vdf::build_mfma_axis_table(sz, v, m));
             assert(m.operand.size() == (size_t)m.n_tiles * 2 * 64 * 16 && m.bias.size() == 16);
         }
     }

@@ -92,7 +92,7 @@ def test_hash_fuzz_frame_sizes(seed):
     want, coefs = orc.hash_clips_with_coefs(frames)
     care = np.abs(coefs) >= 1e-6
     wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(3, 1024)[:, :1000]
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         os.environ["VDF_RESIZE_MODE"] = str(mode)
         try:
             eng = vdf.Engine(0)
@@ -101,7 +101,7 @@ def test_hash_fuzz_frame_sizes(seed):
         try:
             got = eng.hash_frames(frames)
         except vdf.VdfError as e:
-            assert mode in (2, 3) and e.code == -2, (mode, h, w, str(e))  # forced MFMA mode on tables that need the fallback
+            assert mode in (2, 3, 4) and e.code == -2, (mode, h, w, str(e))  # forced MFMA mode on tables that need the fallback
             continue
         finally:
             eng.close()

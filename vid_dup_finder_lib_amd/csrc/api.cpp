@@ -65,13 +65,13 @@ struct vdf_ctx {
     // hash scratch
     DevBuf small, frames, out_hashes, out_dc, cos_table, crops, crop_desc, crop_tables;
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
-    std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 2 + vertical
+    std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
     uint32_t mfma_chunk_cols = 16384, mfma_group = 8192;  // 16384-column chunks: longer workgroups amortise the target loads (swept 2048..65536)
     DevBuf group_cmin, group_offset, group_blocks;
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;
-    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel
+    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
     std::vector<vdf_hit> host_hits;
 
     ~vdf_ctx()
@@ -267,13 +267,13 @@ DeviceAxisTable *axis_table(vdf_ctx *ctx, uint32_t in_size, hipStream_t stream, 
     return t;
 }
 
-DeviceMfmaTable *mfma_table(vdf_ctx *ctx, uint32_t in_size, bool vertical, hipStream_t stream, int *rc)
+DeviceMfmaTable *mfma_table(vdf_ctx *ctx, uint32_t in_size, int layout, hipStream_t stream, int *rc)
 {
-    const uint64_t key = (uint64_t)in_size * 2 + (vertical ? 1 : 0);
+    const uint64_t key = (uint64_t)in_size * 4 + (uint64_t)layout;
     auto it = ctx->mfma_tables.find(key);
     if (it != ctx->mfma_tables.end()) { *rc = VDF_OK; return it->second; }
     DeviceMfmaTable *t = new DeviceMfmaTable();
-    if (!vdf::build_mfma_axis_table(in_size, vertical, t->host)) {
+    if (!vdf::build_mfma_axis_table(in_size, layout, t->host)) {
         delete t;
         *rc = fail(ctx, VDF_E_BAD_DIMS, "cannot build resize table");
         return nullptr;
@@ -359,9 +359,12 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
     const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
     if (ctx->resize_mode != 1) {
         // Resize on the matrix cores (exact i8 x i8 -> i32): small frames fuse the DCT into the same kernel.
-        DeviceMfmaTable *mh = mfma_table(ctx, w, false, stream, &rc);
+        // frames taller than two 64-row groups go to the per-frame kernel; its whole-line form is the default
+        const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && (h + 63) / 64 <= 2);
+        const bool wide = !fused && ctx->resize_mode != 2;
+        DeviceMfmaTable *mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
-        DeviceMfmaTable *mv = mfma_table(ctx, h, true, stream, &rc);
+        DeviceMfmaTable *mv = mfma_table(ctx, h, wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, &rc);
         if (rc) return rc;
         if (mh->host.ok && mv->host.ok) {
             vdf::MfmaResizeArgs a{};
@@ -375,7 +378,6 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             a.n_rg = mv->host.n_tiles;
             a.no_persistent = ctx->hash_no_persistent;
             a.persistent_wgs_per_cu = ctx->hash_wgs_per_cu;
-            const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && a.n_rg <= 2);
             if (fused) {
                 VDF_HIP(ctx, vdf::launch_resize_dct_fused(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
                                                           ctx->cos_table.as<double>(), d_out, d_dc, stream));
@@ -383,7 +385,7 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             }
             VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
             VDF_HIP(ctx, vdf::launch_resize_mfma_frames(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
-                                                        ctx->small.as<uint8_t>(), stream));
+                                                        ctx->small.as<uint8_t>(), wide, stream));
             VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips,
                                               ctx->cos_table.as<double>(), d_out, d_dc, stream));
             return VDF_OK;
@@ -544,7 +546,7 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     }
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
-        if (m >= 0 && m <= 3) ctx->resize_mode = m;
+        if (m >= 0 && m <= 4) ctx->resize_mode = m;
     }
     if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
         if (!std::strcmp(s, "valu")) ctx->search_backend = 0;

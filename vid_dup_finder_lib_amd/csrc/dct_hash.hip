@@ -338,6 +338,63 @@ __device__ __forceinline__ void resize_row_groups(const uint8_t *__restrict__ sr
     }
 }
 
+// Large frames: the same arithmetic over a contiguous range of 16-row BLOCKS [blk_begin, blk_end) of one frame, so that
+// the four waves of a workgroup get equal shares whatever H is (1080 rows = 68 blocks = 17 each; 64-row groups dealt
+// round-robin gave 5/4/4/4, and 270 rows gave 2/1/1/1).  Blocks of a 64-row group that belong to another wave enter this
+// wave's vertical product as i8 zeros (contribution 0; the +128 re-centring bias is added once, by the caller).
+template <bool CAREFUL>
+__device__ __forceinline__ void resize_row_blocks(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
+                                                  const uint8_t *buf_end, const MfmaResizeTables &T, int blk_begin,
+                                                  int blk_end, v4i &acc_vh, v4i &acc_vl, size_t pitch = 0)
+{
+    if (pitch == 0) pitch = W;
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    const int32_t bias_h = T.bias_h[r16];
+    for (int rg = blk_begin >> 2; 4 * rg < blk_end && rg < T.n_rg; rg++) {
+        const int m_lo = max(blk_begin - 4 * rg, 0), m_hi = min(blk_end - 4 * rg, 4);  // wave-uniform
+        v4i ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { ah[m] = (v4i){0, 0, 0, 0}; al[m] = (v4i){bias_h, bias_h, bias_h, bias_h}; }
+        auto load_tile = [&](int kt, v4i (&px)[4], v4i &tbh, v4i &tbl) {
+            tbh = T.bh[(kt * 2 + 0) * 64 + lane];
+            tbl = T.bh[(kt * 2 + 1) * 64 + lane];
+            const uint32_t x = 64u * kt + 16u * g;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t row = 64u * rg + 16u * m + r16;
+                px[m] = (v4i){0, 0, 0, 0};
+                if (m >= m_lo && m < m_hi && row < H && x < W)
+                    px[m] = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
+            }
+        };
+        const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+        v4i cur[4], nxt[4], cbh, cbl, nbh, nbl;
+        load_tile(0, cur, cbh, cbl);
+        for (int kt = 0; kt < T.n_kt; kt++) {
+            const bool more = kt + 1 < T.n_kt;
+            if (more) load_tile(kt + 1, nxt, nbh, nbl);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (m >= m_lo && m < m_hi) {
+                    const v4i a = cur[m] ^ x80;
+                    ah[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, cbh, ah[m], 0, 0, 0);
+                    al[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, cbl, al[m], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) cur[m] = nxt[m];
+                cbh = nbh; cbl = nbl;
+            }
+        }
+        v4i b;
+#pragma unroll
+        for (int m = 0; m < 4; m++) b[m] = (m >= m_lo && m < m_hi) ? (int)finalize4(ah[m], al[m], T.prec_h) : 0;
+        acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 0) * 64 + lane], b, acc_vh, 0, 0, 0);
+        acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 1) * 64 + lane], b, acc_vl, 0, 0, 0);
+    }
+}
+
 // Small frames: one workgroup per clip, one wave per frame (4 frames each), resized frames go to LDS and the
 // DCT runs in the same kernel: HBM traffic = the frames once + 128 B of hash.
 // ONE_TILE (W, H <= 64): the wave's 16 pixel loads (4 frames x 4 row blocks, 16 KB) are all issued before the
@@ -465,8 +522,8 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
     }
 }
 
-// Large frames: one workgroup per frame, the four waves take alternate 64-row groups and their vertical
-// partial sums (exact i32) are added through LDS.  Writes the 16 x 16 u8 frame to `small`.
+// Large frames: one workgroup per frame, the four waves take equal contiguous shares of its 16-row blocks and their
+// vertical partial sums (exact i32) are added through LDS.  Writes the 16 x 16 u8 frame to `small`.
 __global__ __launch_bounds__(256) void resize_mfma_frame_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                 uint32_t H, size_t frame_stride, size_t clip_stride,
                                                                 const uint8_t *buf_end, MfmaResizeTables T,
@@ -478,8 +535,157 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_kernel(const uint8_t *_
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
     const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride;
-    if (src + (size_t)W * H + 64 > buf_end) resize_row_groups<true>(src, W, H, buf_end, T, (int)wave, 4, vh, vl);
-    else resize_row_groups<false>(src, W, H, buf_end, T, (int)wave, 4, vh, vl);
+    const int n_blk = (int)((H + 15) / 16), b0 = n_blk * (int)wave / 4, b1 = n_blk * ((int)wave + 1) / 4;
+    if (src + (size_t)W * H + 64 > buf_end) resize_row_blocks<true>(src, W, H, buf_end, T, b0, b1, vh, vl);
+    else resize_row_blocks<false>(src, W, H, buf_end, T, b0, b1, vh, vl);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            vl[r] += T.bias_v[4 * g + r];
+#pragma unroll
+            for (int w = 0; w < 3; w++) { vh[r] += s_part[w][0][lane][r]; vl[r] += s_part[w][1][lane][r]; }
+        }
+        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+        uint8_t *dst = small + (clip * 16 + f) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+    }
+}
+
+// ---- large frames, coalesced ------------------------------------------------------------------------------
+// The A-operand shape above makes every wave load touch 16 rows x 64 B: half lines at the frame's pitch, which caps
+// a 1080p stream at 5.3 TB/s (tools/ubench_rowload.hip; 8 rows x 128 B reads at 6.2, a linear sweep at 6.24).
+// Here one wave load covers 8 rows x 128 B (whole lines) and still lands directly in MFMA operand registers: lane
+// (a = lane & 15, g = lane >> 4) loads row R0 + (a >> 1), bytes 128 T + 64 (a & 1) + 16 g .. +15, i.e. the 16 A rows of
+// the product are 8 image rows x 2 halves of the 128-byte window.  Half 0 is a row's K-tile 2T and half 1 its K-tile
+// 2T + 1, so the window takes one product with tile 2T's coefficients (right for the even A rows, don't-care for the
+// odd ones) and one with tile 2T + 1's (the reverse): twice the MFMAs of the uncoalesced form, still < 20 % of the
+// matrix pipe at 6 TB/s.  C rows = 4 (lane >> 4) + reg, so the two halves of an image row sit in adjacent registers
+// of one lane: row R0 + 2 G + j = even[2 j] + odd[2 j + 1], no cross-lane traffic.  A lane therefore ends up with
+// rows 8 oct + 2 G + {0, 1} of every octet of a 64-row group - the k order of the vertical product is free, its
+// coefficient operand is simply built in that order (kMfmaLayoutVerticalWide).  Bit-identical to the other kernels.
+#ifdef VDF_DEBUG_WIDE
+__device__ v4i g_dbg_b[64];
+__device__ v4i g_dbg_acc[4][64];
+#endif
+template <bool CAREFUL>
+__device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
+                                                 const uint8_t *buf_end, const MfmaResizeTables &T, int q_begin,
+                                                 int q_end, v4i &acc_vh, v4i &acc_vl)
+{
+    if (q_begin >= q_end) return;
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, a16 = lane & 15;
+    const uint32_t row8 = a16 >> 1, half = a16 & 1;
+    const int32_t bias_h = T.bias_h[a16];  // C column = lane & 15 = output o
+    const int n_win = (T.n_kt + 1) / 2;
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    // one step = one 128-byte window of one 32-row quad: 4 pixel loads (one per octet) + the 4 coefficient fragments
+    auto load_step = [&](int q, int w, v4i (&px)[4], v4i (&tb)[4]) {
+        tb[0] = T.bh[((2 * w) * 2 + 0) * 64 + lane];
+        tb[1] = T.bh[((2 * w) * 2 + 1) * 64 + lane];
+        tb[2] = zero4; tb[3] = zero4;
+        if (2 * w + 1 < T.n_kt) {
+            tb[2] = T.bh[((2 * w + 1) * 2 + 0) * 64 + lane];
+            tb[3] = T.bh[((2 * w + 1) * 2 + 1) * 64 + lane];
+        }
+        const uint32_t x = 128u * w + 64u * half + 16u * g;
+#pragma unroll
+        for (int oct = 0; oct < 4; oct++) {
+            const uint32_t row = 32u * q + 8u * oct + row8;
+            px[oct] = zero4;
+            if (row < H && x < W) px[oct] = load_pixels16<CAREFUL>(src + (size_t)row * W + x, buf_end);
+        }
+    };
+    v4i eh[4], el[4], oh[4], ol[4];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int oct = 0; oct < 4; oct++) {
+            eh[oct] = zero4; oh[oct] = zero4; ol[oct] = zero4;
+            el[oct] = (v4i){bias_h, bias_h, bias_h, bias_h};
+        }
+    };
+    reset_acc();
+    v4i b = zero4;  // quads of a 64-row group that another wave owns stay i8 zeros: no contribution
+    v4i cur[4], nxt[4], ct[4], nt[4];
+    int q = q_begin, w = 0;
+    load_step(q, w, cur, ct);
+    // the (quad, window) steps form ONE software-pipelined stream: the next step's loads are issued before this step's
+    // MFMAs also across a quad boundary, so narrow frames (few windows per quad) keep loads in flight too
+    for (;;) {
+        int qn = q, wn = w + 1;
+        if (wn == n_win) { wn = 0; qn = q + 1; }
+        const bool more = qn < q_end;
+        if (more) load_step(qn, wn, nxt, nt);
+#pragma unroll
+        for (int oct = 0; oct < 4; oct++) {
+            const v4i a = cur[oct] ^ x80;
+            eh[oct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, ct[0], eh[oct], 0, 0, 0);
+            el[oct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, ct[1], el[oct], 0, 0, 0);
+            oh[oct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, ct[2], oh[oct], 0, 0, 0);
+            ol[oct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, ct[3], ol[oct], 0, 0, 0);
+        }
+        if (w == n_win - 1) {  // quad complete: its 32 tmp rows -> two bytes per octet in this lane's vertical operand
+            const int qh = q & 1;
+#ifdef VDF_DEBUG_WIDE
+            if (blockIdx.x == 0) { g_dbg_acc[0][lane] = eh[1]; g_dbg_acc[1][lane] = el[1]; g_dbg_acc[2][lane] = oh[1]; g_dbg_acc[3][lane] = ol[1]; }
+#endif
+#pragma unroll
+            for (int oct = 0; oct < 4; oct++) {
+                uint32_t two = 0;
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    int32_t v = (((eh[oct][2 * j] + oh[oct][2 * j + 1]) << 8) + el[oct][2 * j] + ol[oct][2 * j + 1]) >> T.prec_h;
+                    v = min(max(v, 0), 255);
+                    // keep the two clamps apart: fused into v_ashr_pk_u8_i32 the pair arrives with stray bits above bit 15
+                    // (measured: they were OR-ed into the neighbouring octet's bytes), which the shift-and-or below trusts
+                    asm volatile("" : "+v"(v));
+                    two |= ((uint32_t)v & 0xFFu) << (8 * j);
+                }
+                two ^= 0x8080u;  // re-centred for the next i8 product
+                // octet o8 = 4 qh + oct of the 64-row group: bytes 2 o8, 2 o8 + 1 of the operand (static register indices)
+                const int val = (int)(two << (16 * (oct & 1)));
+                if (qh) b[2 + (oct >> 1)] |= val; else b[oct >> 1] |= val;
+            }
+            reset_acc();
+            if (qh == 1 || !more) {  // last quad this wave owns in the 64-row group
+                const int rg = q >> 1;
+#ifdef VDF_DEBUG_WIDE
+                if (blockIdx.x == 0) g_dbg_b[lane] = b;
+#endif
+                acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 0) * 64 + lane], b, acc_vh, 0, 0, 0);
+                acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 1) * 64 + lane], b, acc_vl, 0, 0, 0);
+                b = zero4;
+            }
+        }
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cur[i] = nxt[i]; ct[i] = nt[i]; }
+        q = qn; w = wn;
+    }
+}
+
+// One workgroup per frame; the four waves take equal contiguous shares of the frame's 32-row quads.  T.av is in
+// kMfmaLayoutVerticalWide order.
+__global__ __launch_bounds__(256) void resize_mfma_frame_wide_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+                                                                     uint32_t H, size_t frame_stride,
+                                                                     size_t clip_stride, const uint8_t *buf_end,
+                                                                     MfmaResizeTables T, uint8_t *__restrict__ small)
+{
+    __shared__ int32_t s_part[3][2][64][4];
+    const size_t clip = blockIdx.x >> 4;
+    const uint32_t f = blockIdx.x & 15;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+    const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride;
+    const int n_q = (int)((H + 31) / 32), q0 = n_q * (int)wave / 4, q1 = n_q * ((int)wave + 1) / 4;
+    if (src + (size_t)W * H + 128 > buf_end) resize_row_quads<true>(src, W, H, buf_end, T, q0, q1, vh, vl);
+    else resize_row_quads<false>(src, W, H, buf_end, T, q0, q1, vh, vl);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
@@ -547,8 +753,9 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
     const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
     // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very
     // end of the buffer needs the careful loader
-    if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_groups<true>(src, d.w, d.h, buf_end, T, (int)wave, 4, vh, vl, pitch);
-    else resize_row_groups<false>(src, d.w, d.h, buf_end, T, (int)wave, 4, vh, vl, pitch);
+    const int n_blk = (int)((d.h + 15) / 16), b0 = n_blk * (int)wave / 4, b1 = n_blk * ((int)wave + 1) / 4;
+    if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_blocks<true>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
+    else resize_row_blocks<false>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
@@ -618,9 +825,14 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
 
 hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                      size_t frame_stride, size_t clip_stride, const uint8_t *buf_end,
-                                     const MfmaResizeArgs &a, uint8_t *small, hipStream_t stream)
+                                     const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
+    if (wide) {  // a.av is in kMfmaLayoutVerticalWide order
+        hipLaunchKernelGGL(resize_mfma_frame_wide_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, w,
+                           h, frame_stride, clip_stride, buf_end, make_tables(a), small);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(resize_mfma_frame_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, w, h,
                        frame_stride, clip_stride, buf_end, make_tables(a), small);
     return hipGetLastError();

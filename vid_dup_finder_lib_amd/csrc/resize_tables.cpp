@@ -75,7 +75,7 @@ bool build_axis_table(uint32_t in_size, uint32_t out_size, HostAxisTable &t)
     return true;
 }
 
-bool build_mfma_axis_table(uint32_t in_size, bool vertical, MfmaAxisTable &t)
+bool build_mfma_axis_table(uint32_t in_size, int layout, MfmaAxisTable &t)
 {
     t = MfmaAxisTable();
     const uint32_t D = 16;
@@ -108,7 +108,9 @@ bool build_mfma_axis_table(uint32_t in_size, bool vertical, MfmaAxisTable &t)
         for (int l = 0; l < 64; l++)
             for (int j = 0; j < 16; j++) {
                 const int g = l >> 4, o = l & 15;
-                const int pos = vertical ? 64 * tile + 16 * (j >> 2) + 4 * g + (j & 3) : 64 * tile + 16 * g + j;
+                const int pos = layout == kMfmaLayoutVertical       ? 64 * tile + 16 * (j >> 2) + 4 * g + (j & 3)
+                                : layout == kMfmaLayoutVerticalWide ? 64 * tile + 8 * (j >> 1) + 2 * g + (j & 1)
+                                                                    : 64 * tile + 16 * g + j;
                 const int32_t c = full[(size_t)o * n_tiles * 64 + pos];
                 int32_t lo = ((c + 128) & 255) - 128;  // c = 256 hi + lo, lo in [-128, 127]
                 int32_t hi = (c - lo) / 256;

@@ -21,6 +21,7 @@ struct MfmaAxisTable {
     // n_tiles x {hi, lo} x 64 lanes x 16 bytes.
     //   horizontal (B operand): byte j of lane l in tile kt  = C[o = l & 15][x = 64 kt + 16 (l >> 4) + j]
     //   vertical   (A operand): byte j = 4 m + r of lane l in group rg = C[oy = l & 15][y = 64 rg + 16 m + 4 (l >> 4) + r]
+    //   vertical, wide kernel:  byte j of lane l in group rg           = C[oy = l & 15][y = 64 rg + 8 (j >> 1) + 2 (l >> 4) + (j & 1)]
     std::vector<int8_t> operand;
     std::vector<int32_t> bias;  // [16]
     int32_t n_tiles = 0;
@@ -29,6 +30,9 @@ struct MfmaAxisTable {
 };
 
 // in_size == 16 yields the identity (the reference copies when no resize is needed).
-bool build_mfma_axis_table(uint32_t in_size, bool vertical, MfmaAxisTable &t);
+// layout: 0 = horizontal, 1 = vertical, 2 = vertical for resize_mfma_frame_wide_kernel (the k order of a 64-row group is free
+// as long as both operands of the product agree; the wide kernel's lanes hold rows 8 oct + 2 g + {0, 1} of every octet).
+enum { kMfmaLayoutHorizontal = 0, kMfmaLayoutVertical = 1, kMfmaLayoutVerticalWide = 2 };
+bool build_mfma_axis_table(uint32_t in_size, int layout, MfmaAxisTable &t);
 
 }  // namespace vdf

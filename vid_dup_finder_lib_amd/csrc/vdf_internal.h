@@ -90,7 +90,7 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
                                    hipStream_t stream);
 hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                      size_t frame_stride, size_t clip_stride, const uint8_t *buf_end,
-                                     const MfmaResizeArgs &a, uint8_t *small, hipStream_t stream);
+                                     const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream);
 // ---- letterbox crop detection + cropped resize -------------------------------------------
 struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
     uint32_t x0, y0, w, h;
