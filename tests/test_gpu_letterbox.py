@@ -59,7 +59,7 @@ def test_reference_kats_and_random_frames_match_oracle(engine, h, w):
         assert tuple(got[0]) == (1, 1, 1, 2)  # video_frames_gray.rs:444-459
 
 
-@pytest.mark.parametrize("h,w", [(40, 56), (64, 64), (90, 160), (217, 131)])
+@pytest.mark.parametrize("h,w", [(40, 56), (64, 64), (90, 160), (217, 131), (120, 256), (270, 480), (300, 200), (136, 333)])
 def test_letterbox_hash_matches_oracle(engine, h, w):
     """crop_video_frames(Letterbox) + from_frames: same crop, same hash bits (don't-care rule) as hashing the cropped
     copies on the CPU; the device reads the crop box in place."""

@@ -444,12 +444,13 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     }
     std::vector<vdf::CropClipDesc> desc(n_clips);
     std::vector<vdf::CropTableEntry> entries;
+    const bool wide = w >= 192;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
     std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
     auto entry_for = [&](uint32_t size, bool vertical, int *rc) -> uint32_t {
         const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
         auto it = index.find(key);
         if (it != index.end()) return it->second;
-        DeviceMfmaTable *t = mfma_table(ctx, size, vertical, stream, rc);
+        DeviceMfmaTable *t = mfma_table(ctx, size, !vertical ? vdf::kMfmaLayoutHorizontal : wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, rc);
         if (*rc) return 0;
         if (!t->host.ok) { *rc = fail(ctx, VDF_E_BAD_DIMS, "crop box size whose coefficients do not fit the i8 split"); return 0; }
         vdf::CropTableEntry e{t->operand.p, t->bias.as<int32_t>(), t->host.n_tiles, t->host.precision};
@@ -475,7 +476,8 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
     VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_clips, w, frame_stride, clip_stride, buf_end,
                                                  ctx->crop_desc.as<vdf::CropClipDesc>(),
-                                                 ctx->crop_tables.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), stream));
+                                                 ctx->crop_tables.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), wide,
+                                                 stream));
     VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out,
                                       d_dc, stream));
     return VDF_OK;

@@ -34,19 +34,46 @@ __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p
     for (int k = 0; k < 4; k++) hist[lane + 64 * k] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // Letterbox bars are runs of one value: 64 lanes adding to the same bin serialise in the LDS (measured: 3.5 ms to
+    // probe 1000 1080p clips).  When every active lane holds the same value one lane adds the total; otherwise a lane
+    // whose four pixels are equal adds 4 at once.  Same histogram, fewer atomics.
     if (step == 1) {  // a row: four pixels per (possibly unaligned) dword load
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
         const uint32_t n4 = len >> 2;
-        for (uint32_t i = lane; i < n4; i += 64) {
-            const uint32_t v = *reinterpret_cast<const u32_unaligned *>(p + 4 * (size_t)i);
-            atomicAdd(&hist[v & 255u], 1u);
-            atomicAdd(&hist[(v >> 8) & 255u], 1u);
-            atomicAdd(&hist[(v >> 16) & 255u], 1u);
-            atomicAdd(&hist[v >> 24], 1u);
+        for (uint32_t i0 = 0; i0 < n4; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool active = i < n4;
+            const uint32_t v = active ? *reinterpret_cast<const u32_unaligned *>(p + 4 * (size_t)i) : 0u;
+            const bool same4 = v == (v & 255u) * 0x01010101u;
+            const uint32_t first = __builtin_amdgcn_readfirstlane(v);  // lane 0 is active whenever the loop runs
+            const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+            if (__builtin_amdgcn_ballot_w64(active && same4 && v == first) == act) {
+                if (lane == 0) atomicAdd(&hist[first & 255u], 4u * (uint32_t)__builtin_popcountll(act));
+            } else if (active) {
+                if (same4) {
+                    atomicAdd(&hist[v & 255u], 4u);
+                } else {
+                    atomicAdd(&hist[v & 255u], 1u);
+                    atomicAdd(&hist[(v >> 8) & 255u], 1u);
+                    atomicAdd(&hist[(v >> 16) & 255u], 1u);
+                    atomicAdd(&hist[v >> 24], 1u);
+                }
+            }
         }
         for (uint32_t i = 4 * n4 + lane; i < len; i += 64) atomicAdd(&hist[p[i]], 1u);
     } else {
-        for (uint32_t i = lane; i < len; i += 64) atomicAdd(&hist[p[(size_t)i * step]], 1u);
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool active = i < len;
+            const uint32_t v = active ? p[(size_t)i * step] : 0u;
+            const uint32_t first = __builtin_amdgcn_readfirstlane(v);
+            const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+            if (__builtin_amdgcn_ballot_w64(active && v == first) == act) {
+                if (lane == 0) atomicAdd(&hist[first], (uint32_t)__builtin_popcountll(act));
+            } else if (active) {
+                atomicAdd(&hist[v], 1u);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -576,9 +576,10 @@ __device__ v4i g_dbg_acc[4][64];
 template <bool CAREFUL>
 __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
                                                  const uint8_t *buf_end, const MfmaResizeTables &T, int q_begin,
-                                                 int q_end, v4i &acc_vh, v4i &acc_vl)
+                                                 int q_end, v4i &acc_vh, v4i &acc_vl, size_t pitch = 0)
 {
     if (q_begin >= q_end) return;
+    if (pitch == 0) pitch = W;  // tightly packed rows unless a crop box is read in place
     const uint32_t lane = threadIdx.x & 63, g = lane >> 4, a16 = lane & 15;
     const uint32_t row8 = a16 >> 1, half = a16 & 1;
     const int32_t bias_h = T.bias_h[a16];  // C column = lane & 15 = output o
@@ -599,7 +600,7 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
         for (int oct = 0; oct < 4; oct++) {
             const uint32_t row = 32u * q + 8u * oct + row8;
             px[oct] = zero4;
-            if (row < H && x < W) px[oct] = load_pixels16<CAREFUL>(src + (size_t)row * W + x, buf_end);
+            if (row < H && x < W) px[oct] = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
         }
     };
     v4i eh[4], el[4], oh[4], ol[4];
@@ -727,6 +728,7 @@ hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_
 
 // Cropped clips (letterbox crop box read in place: no cropped copy of the frames is ever made).  Every clip may have
 // its own box, hence its own coefficient tables: a per-clip descriptor names the box and the two table entries.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
                                                                   size_t frame_stride, size_t clip_stride,
                                                                   const uint8_t *buf_end,
@@ -753,9 +755,15 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
     const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
     // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very
     // end of the buffer needs the careful loader
-    const int n_blk = (int)((d.h + 15) / 16), b0 = n_blk * (int)wave / 4, b1 = n_blk * ((int)wave + 1) / 4;
-    if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_blocks<true>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
-    else resize_row_blocks<false>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
+    if (WIDE) {  // whole-line loads as in resize_mfma_frame_wide_kernel (vertical tables in kMfmaLayoutVerticalWide order)
+        const int n_q = (int)((d.h + 31) / 32), q0 = n_q * (int)wave / 4, q1 = n_q * ((int)wave + 1) / 4;
+        if (src + (size_t)d.h * pitch + 128 > buf_end) resize_row_quads<true>(src, d.w, d.h, buf_end, T, q0, q1, vh, vl, pitch);
+        else resize_row_quads<false>(src, d.w, d.h, buf_end, T, q0, q1, vh, vl, pitch);
+    } else {     // narrow frames: a 128-byte window would be half empty
+        const int n_blk = (int)((d.h + 15) / 16), b0 = n_blk * (int)wave / 4, b1 = n_blk * ((int)wave + 1) / 4;
+        if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_blocks<true>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
+        else resize_row_blocks<false>(src, d.w, d.h, buf_end, T, b0, b1, vh, vl, pitch);
+    }
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
@@ -777,11 +785,15 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
 
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
-                                      const CropTableEntry *tables, uint8_t *small, hipStream_t stream)
+                                      const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_mfma_cropped_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, pitch,
-                       frame_stride, clip_stride, buf_end, desc, tables, small);
+    if (wide)
+        hipLaunchKernelGGL(resize_mfma_cropped_kernel<true>, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames,
+                           pitch, frame_stride, clip_stride, buf_end, desc, tables, small);
+    else
+        hipLaunchKernelGGL(resize_mfma_cropped_kernel<false>, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames,
+                           pitch, frame_stride, clip_stride, buf_end, desc, tables, small);
     return hipGetLastError();
 }
 

@@ -105,7 +105,7 @@ hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t fram
                             size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
-                                      const CropTableEntry *tables, uint8_t *small, hipStream_t stream);
+                                      const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);
 hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream);
 
