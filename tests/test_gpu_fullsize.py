@@ -139,3 +139,55 @@ def test_ten_million_all_pairs_single_gpu(engine):
     assert overflow == 0xFFFFFFFF and st["pairs"] == n * (n - 1) // 2
     assert {tuple(map(int, h)) for h in hits} == {(s, t) for s, t in truth.items()}
     print(f"10 M: {st['pairs']:.4g} pairs, kernel {st['kernel_ms']:.0f} ms, {st['pairs'] / st['kernel_ms'] * 1e3:.3g} pairs/s")
+
+
+def test_c5_end_to_end_from_frames_single_gpu(engine):
+    """configs[4] END TO END at full size on one GPU: 1 M candidate clips + 100 k reference clips of 16 x 64 x 64 u8
+    (72 GB of frames resident in HBM) -> hashes -> search_with_references with +-5 % duration windows.
+    Half of the references are copies of candidate clips (same frames, same duration): each must find exactly its source
+    (iid-pixel clips hash to effectively random bits, ~500 apart); a sample of hashes is checked against the oracle."""
+    if engine.backend != "mfma":
+        pytest.skip("one backend is enough for the 72 GB case")
+    if torch.cuda.mem_get_info()[0] < 90 * 2**30:
+        pytest.skip("needs 90 GB of free HBM")
+    import time
+    from vid_dup_finder_lib_amd import distributed as vd
+
+    n_cand, n_ref = 1_000_000, 100_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20250615)
+    cand = torch.empty((n_cand, 16, 64, 64), dtype=torch.uint8, device="cuda")
+    for c0 in range(0, n_cand, 50_000):  # bounded temporaries
+        cand[c0:c0 + 50_000] = torch.randint(0, 256, (min(50_000, n_cand - c0), 16, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+    rng = np.random.default_rng(20250616)
+    cd = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n_cand))).astype(np.int32)
+    src = rng.choice(n_cand, size=n_ref // 2, replace=False)
+    origin = np.concatenate([src, np.full(n_ref - n_ref // 2, -1)])
+    perm = rng.permutation(n_ref)
+    origin = origin[perm]
+    ref = torch.randint(0, 256, (n_ref, 16, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+    planted = np.nonzero(origin >= 0)[0]
+    ref[torch.from_numpy(planted).cuda()] = cand[torch.from_numpy(origin[planted]).cuda()]
+    rd = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n_ref))).astype(np.int32)
+    rd[planted] = cd[origin[planted]]
+    d_cd, d_rd = torch.from_numpy(cd).cuda(), torch.from_numpy(rd).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    groups, order = vd.hash_and_search_refs(engine, cand, d_cd, ref, d_rd, 350)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pos_of = np.empty(n_cand, np.int64)
+    pos_of[order] = np.arange(n_cand)
+    assert [r for r, _ in groups] == sorted(int(r) for r in planted)  # only the planted references match, in reference order
+    for r, members in groups:
+        assert members == [int(pos_of[origin[r]])], (r, members)
+    # a sample of device hashes against the oracle (don't-care rule)
+    sample = rng.choice(n_cand, size=24, replace=False)
+    got = engine.hash_frames(cand[torch.from_numpy(np.sort(sample)).cuda()].cpu().numpy())
+    want, coefs = orc.hash_clips_with_coefs(cand[torch.from_numpy(np.sort(sample)).cuda()].cpu().numpy())
+    care = np.abs(coefs) >= 1e-6
+    gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(-1, 1024)[:, :1000]
+    wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(-1, 1024)[:, :1000]
+    assert not ((gb != wb) & care).any()
+    print(f"C5 end to end: {n_cand + n_ref} clips ({(n_cand + n_ref) * 65536 / 1e9:.1f} GB of frames) hashed and "
+          f"{n_ref} references searched in {dt * 1e3:.1f} ms wall; {len(groups)} groups")
