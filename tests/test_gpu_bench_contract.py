@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_emits_the_contract_line(backend):
     env = dict(os.environ, VDF_SEARCH_BACKEND=backend)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--n-hashes", "30000", "--hash-clips", "3000"], capture_output=True, text=True, timeout=600, env=env)
+                          "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly ONE JSON line on stdout
