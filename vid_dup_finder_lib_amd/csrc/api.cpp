@@ -69,6 +69,7 @@ struct vdf_ctx {
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
     uint32_t mfma_chunk_cols = 16384, mfma_group = 8192;  // 16384-column chunks: longer workgroups amortise the target loads (swept 2048..65536)
     DevBuf group_cmin, group_offset, group_blocks;
+    uint32_t mfma_xcd_stripe = 0;
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
@@ -173,6 +174,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     if (mfma) {
         if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
+        L.xcd_stripe = ctx->mfma_xcd_stripe;
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
         if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
@@ -558,6 +560,7 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
         long c = std::atol(s);
         if (c >= 32 && c <= (1 << 22)) ctx->mfma_chunk_cols = (uint32_t)c;
     }
+    if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_MFMA_GROUP")) {
         long c = std::atol(s);
         if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__rest
 __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__restrict__ tile_first,
                                                           const uint32_t *__restrict__ tile_count, uint32_t n_row_tiles,
                                                           uint32_t group_size, uint32_t shard_count,
-                                                          uint32_t *__restrict__ group_cmin,
+                                                          uint32_t xcd_stripe, uint32_t *__restrict__ group_cmin,
                                                           uint32_t *__restrict__ group_blocks)
 {  // one workgroup per group: chunk range covered by its row tiles; only every shard_count-th tile is this rank's
     __shared__ uint32_t s_min[4], s_max[4];
@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__rest
         cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (cmax <= cmin) { cmin = 0; cmax = 0; }
         group_cmin[g] = cmin;
-        group_blocks[g] = (cmax - cmin) * ((group_size + shard_count - 1) / shard_count);
+        uint32_t n_chunks = cmax - cmin;
+        if (xcd_stripe) n_chunks = (n_chunks + 7u) & ~7u;  // whole rounds of 8 chunks: workgroup id % 8 = chunk % 8 = XCD
+        group_blocks[g] = n_chunks * ((group_size + shard_count - 1) / shard_count);
     }
 }
 
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     uint32_t group_size, uint32_t shard_index, uint32_t shard_count, uint32_t n_row_tiles, uint32_t chunk_cols,
     uint32_t tol,
     const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
-    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base)
+    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base,
+    uint32_t xcd_stripe)
 {
     constexpr bool kNoLds = ABLATE == 4 || ABLATE == 5;
     const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
@@ -383,8 +386,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     const uint32_t per_group = (group_size + shard_count - 1) / shard_count;
     const uint32_t g0 = gl * group_size;
     const uint32_t t0 = g0 + (shard_index + shard_count - g0 % shard_count) % shard_count;
-    const uint32_t t = t0 + (idx % per_group) * shard_count;
-    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / per_group;
+    // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2.  Chunk-major order alone makes all 8
+    // stream the SAME chunk at the same time (8 copies in 8 L2s); striped, workgroup id % 8 selects one of 8 ADJACENT
+    // chunks, so an XCD's resident workgroups share one chunk and no two XCDs cache the same candidates.  Adjacent chunks
+    // have nearly the same number of valid row tiles, so the XCDs stay balanced.
+    const uint32_t k = xcd_stripe ? idx >> 3 : idx;
+    const uint32_t t = t0 + (k % per_group) * shard_count;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + (xcd_stripe ? 8u * (k / per_group) + (idx & 7u) : k / per_group);
     if (t >= n_row_tiles || t >= g0 + group_size) return;
     {
         const uint32_t f = ((const_u32_ptr)(uintptr_t)tile_first)[t], cnt = ((const_u32_ptr)(uintptr_t)tile_count)[t];
@@ -551,7 +559,7 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, L.tile_count, L.n_row_tiles, L.tile_offset);
     if (L.n_groups) {
         hipLaunchKernelGGL(group_tiles_kernel, dim3(L.n_groups), dim3(256), 0, stream, L.tile_first, L.tile_count,
-                           L.n_row_tiles, L.group_size, L.shard_count, L.group_cmin, L.group_blocks);
+                           L.n_row_tiles, L.group_size, L.shard_count, L.xcd_stripe, L.group_cmin, L.group_blocks);
         hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(64), 0, stream, L.group_blocks, L.n_groups, L.group_offset);
     }
     return hipGetLastError();
@@ -653,7 +661,7 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
                        reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
                        L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
                        L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
-                       L.hits, L.capacity, L.counters, L.overflow_row, base)
+                       L.hits, L.capacity, L.counters, L.overflow_row, base, L.xcd_stripe)
         switch (L.ablate) {
         case 1: VDF_MFMA_LAUNCH(1); break;
         case 2: VDF_MFMA_LAUNCH(2); break;
