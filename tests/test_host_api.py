@@ -61,3 +61,23 @@ def test_gen_hashes_option_mapping():
     assert vdf.Cropdetect.LETTERBOX.value == "letterbox"
     with pytest.raises(vdf.VidProc):
         vdf.gen_hashes(np.zeros((1, 16, 8, 8), np.uint8), ["p"], [1], cropdetect=vdf.Cropdetect.MOTION)
+
+
+def test_test_util_random_constructors():
+    """video_hash.rs:272-306 (feature test-util): random_hash has 1000 fair bits and zero padding; hash_with_spatial_distance
+    lands at exactly the requested distance and may flip padding bits; the metric axioms of video_hash.rs:325-371 hold."""
+    rng = np.random.default_rng(3)
+    a = vdf.VideoHash.random_hash(rng)
+    assert str(a.src_path()) in ("", ".")
+    assert a.duration() == 0
+    bits = np.unpackbits(a.hash.view(np.uint8), bitorder="little")
+    assert not bits[1000:].any() and 400 < bits[:1000].sum() < 600
+    for d in (0, 1, 350, 600, 1024):
+        b = a.hash_with_spatial_distance(d, rng)
+        assert a.hamming_distance(b) == d == b.hamming_distance(a)
+    assert a.hamming_distance(a) == 0
+    c = a.hash_with_spatial_distance(100, rng)
+    e = c.hash_with_spatial_distance(50, rng)
+    assert a.hamming_distance(e) <= a.hamming_distance(c) + c.hamming_distance(e)  # triangle inequality
+    with pytest.raises(ValueError):
+        a.hash_with_spatial_distance(1025, rng)

@@ -164,6 +164,27 @@ class VideoHash:
     def empty_hash(cls, name) -> "VideoHash":
         return cls(np.zeros(HASH_WORDS, np.uint64), name, 0)
 
+    # test_util constructors that draw random bits (video_hash.rs:272-306); rng = numpy Generator in place of StdRng
+    @classmethod
+    def random_hash(cls, rng: np.random.Generator) -> "VideoHash":
+        """1000 fair bits, padding bits 1000..1023 zero, empty path, duration 0 (video_hash.rs:293-306)."""
+        bits = rng.integers(0, 2, size=HASH_WORDS * 64, dtype=np.uint8)
+        bits[HASH_BITS:] = 0
+        return cls(np.packbits(bits, bitorder="little").view(np.uint64).copy(), "", 0)
+
+    def hash_with_spatial_distance(self, target_distance: int, rng: np.random.Generator) -> "VideoHash":
+        """A hash at exactly `target_distance` bits from this one; any of the 1024 positions may flip, padding included
+        (video_hash.rs:272-291).  Upstream random-walks single flips until the distance is first reached, which never
+        terminates in practice beyond the 512-bit equilibrium; by symmetry the first-hit point is uniform on the sphere of
+        that radius, which `target_distance` distinct random positions sample directly."""
+        if not 0 <= target_distance <= HASH_WORDS * 64:
+            raise ValueError("target_distance must be within 0..1024")
+        bits = np.unpackbits(self.hash.view(np.uint8), bitorder="little")
+        bits[rng.choice(HASH_WORDS * 64, size=target_distance, replace=False)] ^= 1
+        out = VideoHash(np.packbits(bits, bitorder="little").view(np.uint64).copy(), self._src_path, self._duration)
+        assert self.hamming_distance(out) == target_distance
+        return out
+
     def _key(self):
         return (tuple(int(x) for x in self.hash), rust_path_key(self._src_path), self._duration)
 
