@@ -665,8 +665,8 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
             }
         }
         if (!more) break;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { cur[i] = nxt[i]; ct[i] = nt[i]; }
+        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2]; cur[3] = nxt[3];
+        ct[0] = nt[0]; ct[1] = nt[1]; ct[2] = nt[2]; ct[3] = nt[3];
         q = qn; w = wn;
     }
 }
