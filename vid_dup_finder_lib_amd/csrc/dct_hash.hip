@@ -273,16 +273,21 @@ __device__ __forceinline__ v4i load_pixels16(const uint8_t *p, const uint8_t *bu
     return r;
 }
 
+// v_ashr_pk_u8_i32 d, a, b, s: d[7:0] = sat_u8(a >> s), d[15:8] = sat_u8(b >> s) - shift, clamp and pack for two values in
+// one VALU op.  Only bits 15:0 of the result are defined (hipcc's own use of it trusts the upper half to be zero, which it is
+// not: found by the parity tests), so the two halves are joined with a byte permute that never looks at the upper bits.
+__device__ __forceinline__ uint32_t ashr_pk_u8(int32_t a, int32_t b, int shift)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(shift));
+    return d;
+}
+
 __device__ __forceinline__ uint32_t finalize4(v4i hi, v4i lo, int prec)
 {  // four (256 hi + lo) >> prec, clamped to u8, packed little-endian, re-centred for the next i8 product
-    uint32_t packed = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int32_t s = ((hi[r] << 8) + lo[r]) >> prec;
-        s = min(max(s, 0), 255);
-        packed |= (uint32_t)s << (8 * r);
-    }
-    return packed ^ 0x80808080u;
+    const uint32_t p01 = ashr_pk_u8((hi[0] << 8) + lo[0], (hi[1] << 8) + lo[1], prec);
+    const uint32_t p23 = ashr_pk_u8((hi[2] << 8) + lo[2], (hi[3] << 8) + lo[3], prec);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;  // bytes: p01.b0, p01.b1, p23.b0, p23.b1
 }
 
 // Row groups rg_begin, rg_begin + rg_step, ... of one frame; accumulates the vertical partial sums.
@@ -638,16 +643,10 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
 #endif
 #pragma unroll
             for (int oct = 0; oct < 4; oct++) {
-                uint32_t two = 0;
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    int32_t v = (((eh[oct][2 * j] + oh[oct][2 * j + 1]) << 8) + el[oct][2 * j] + ol[oct][2 * j + 1]) >> T.prec_h;
-                    v = min(max(v, 0), 255);
-                    // keep the two clamps apart: fused into v_ashr_pk_u8_i32 the pair arrives with stray bits above bit 15
-                    // (measured: they were OR-ed into the neighbouring octet's bytes), which the shift-and-or below trusts
-                    asm volatile("" : "+v"(v));
-                    two |= ((uint32_t)v & 0xFFu) << (8 * j);
-                }
+                // rows 2G and 2G + 1 of the octet: even-tile part in registers 0 / 2, odd-tile part in registers 1 / 3
+                const int32_t s0 = ((eh[oct][0] + oh[oct][1]) << 8) + el[oct][0] + ol[oct][1];
+                const int32_t s1 = ((eh[oct][2] + oh[oct][3]) << 8) + el[oct][2] + ol[oct][3];
+                uint32_t two = ashr_pk_u8(s0, s1, T.prec_h) & 0xFFFFu;  // only bits 15:0 of the packed result are defined
                 two ^= 0x8080u;  // re-centred for the next i8 product
                 // octet o8 = 4 qh + oct of the 64-row group: bytes 2 o8, 2 o8 + 1 of the operand (static register indices)
                 const int val = (int)(two << (16 * (oct & 1)));
