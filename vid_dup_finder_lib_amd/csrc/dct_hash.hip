@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256) void resize_dct_hash_fused_kernel(
 // Persistent form of the ONE_TILE fused kernel (W, H <= 64, W % 16 == 0 so no load crosses the buffer end):
 // a workgroup loops over clips and issues the NEXT clip's 16 loads per lane (64 KB per workgroup) as soon as the
 // resize has consumed the current pixels, so HBM streams underneath the DCT instead of after it.
+// FULL = W == H == 64: every lane's loads are in range, so the zero fill and the per-lane predicates (exec-mask
+// juggling, 58 register moves per wave and clip) disappear.
+template <bool FULL>
 __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
     const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
     MfmaResizeTables T, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
@@ -494,8 +497,8 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
         for (int q = 0; q < 4; q++) {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                px[q][m] = (v4i){0, 0, 0, 0};
-                if (16u * m + r16 < H && col_ok)
+                if (!FULL) px[q][m] = (v4i){0, 0, 0, 0};
+                if (FULL || (16u * m + r16 < H && col_ok))
                     px[q][m] = load_pixels16<false>(base + (size_t)(4 * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
             }
         }
@@ -821,9 +824,14 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t grid = (uint32_t)std::min<size_t>(n_clips, (size_t)cus * a.persistent_wgs_per_cu);
-        hipLaunchKernelGGL(resize_dct_hash_persistent_kernel, dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
-                           (uint32_t)n_clips);
+        if (w == 64 && h == 64)
+            hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<true>, dim3(grid), dim3(256), 0, stream, frames, w, h,
+                               frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
+                               (uint32_t)n_clips);
+        else
+            hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<false>, dim3(grid), dim3(256), 0, stream, frames, w, h,
+                               frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
+                               (uint32_t)n_clips);
     } else if (a.n_kt == 1 && a.n_rg == 1)
         hipLaunchKernelGGL(resize_dct_hash_fused_kernel<true>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w,
                            h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes, out_dontcare);
