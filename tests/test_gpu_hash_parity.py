@@ -111,3 +111,31 @@ def test_full_hd_clip_matches_oracle(engine):
     rng = np.random.default_rng(1080)
     frames = rng.integers(0, 256, size=(2, 16, 1080, 1920), dtype=np.uint8)
     _check(engine, frames)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (48, 80), (120, 136), (270, 480), (301, 203)])
+def test_strided_and_misaligned_device_buffers(engine, h, w):
+    """vdf_hash_frames_u8_device takes any frame_stride >= W*H, any clip_stride, any base alignment and ignores frames
+    beyond the 16th (video_hash.rs:53): padded strides, 18 frames per clip and a base pointer 3 bytes off 16-byte alignment
+    must hash exactly like the packed copy (covers every resize kernel's addressing and its end-of-buffer guard)."""
+    import torch
+
+    rng = np.random.default_rng(h * 1000 + w)
+    n, nf = 5, 18
+    frames = rng.integers(0, 256, size=(n, nf, h, w), dtype=np.uint8)
+    fs, base = w * h + 37, 3
+    cs = nf * fs + 101
+    buf = np.full(base + (n - 1) * cs + (nf - 1) * fs + w * h, 0xAB, np.uint8)  # ends exactly at the last byte of the last frame
+    for c in range(n):
+        for f in range(nf):
+            o = base + c * cs + f * fs
+            buf[o:o + w * h] = frames[c, f].reshape(-1)
+    d_buf = torch.from_numpy(buf).cuda()
+    d_out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.hash_frames_device(d_buf.data_ptr() + base, n, nf, w, h, d_out.data_ptr(), frame_stride=fs, clip_stride=cs)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint64)
+    want = engine.hash_frames(frames[:, :16].copy())
+    assert np.array_equal(got, want)
+    _check(engine, frames[:, :16].copy())
