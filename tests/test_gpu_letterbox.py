@@ -126,3 +126,29 @@ def test_gen_hashes_mirrors_the_builder_default(engine):
     assert np.array_equal(np.stack([p.hash for p in plain]), engine.hash_frames(frames))
     with pytest.raises(vdf.NotEnoughFrames):
         vdf.gen_hashes(frames[:, :10], ["p"] * 6, [0] * 6, engine=engine)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (90, 160), (270, 480)])
+def test_letterbox_strided_misaligned_device_buffers(engine, h, w):
+    """The device letterbox entry point with padded frame/clip strides, 17 frames per clip and a base pointer 5 bytes off
+    alignment: same crops and hashes as the packed host path."""
+    rng = np.random.default_rng(11 * h + w)
+    n, nf = 6, 17
+    frames = _letterboxed(rng, n, h, w)
+    frames = np.concatenate([frames, frames[:, :nf - frames.shape[1]]], axis=1) if frames.shape[1] < nf else frames[:, :nf]
+    fs, base = w * h + 29, 5
+    cs = nf * fs + 77
+    buf = np.full(base + (n - 1) * cs + (nf - 1) * fs + w * h, 0x55, np.uint8)
+    for c in range(n):
+        for f in range(nf):
+            o = base + c * cs + f * fs
+            buf[o:o + w * h] = frames[c, f].reshape(-1)
+    d_buf = torch.from_numpy(buf).cuda()
+    d_out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    crops = engine.hash_frames_letterbox_device(d_buf.data_ptr() + base, n, nf, w, h, d_out.data_ptr(), frame_stride=fs,
+                                                clip_stride=cs)
+    torch.cuda.synchronize()
+    want_h, want_c = engine.hash_frames_letterbox(np.ascontiguousarray(frames))
+    assert np.array_equal(crops, want_c)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want_h)

@@ -125,9 +125,12 @@ class Engine:
         return (out, crops, dc) if want_dontcare else (out, crops)
 
     def cropdetect_letterbox_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
-                                    d_crops: int, stream: int = 0):
-        self._check(self.lib.vdf_cropdetect_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, w * h,
-                                                             w * h * frames_per_clip, d_crops, stream or None))
+                                    d_crops: int, stream: int = 0, frame_stride: Optional[int] = None,
+                                    clip_stride: Optional[int] = None):
+        fs = w * h if frame_stride is None else frame_stride
+        cs = fs * frames_per_clip if clip_stride is None else clip_stride
+        self._check(self.lib.vdf_cropdetect_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h, fs, cs,
+                                                             d_crops, stream or None))
 
     def hash_frames_cropped_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
                                    crops: Optional[np.ndarray], d_out: int, d_dontcare: int = 0, stream: int = 0):
@@ -138,11 +141,14 @@ class Engine:
                                                                d_dontcare or None, stream or None))
 
     def hash_frames_letterbox_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
-                                     d_out: int, d_dontcare: int = 0, stream: int = 0) -> np.ndarray:
+                                     d_out: int, d_dontcare: int = 0, stream: int = 0,
+                                     frame_stride: Optional[int] = None, clip_stride: Optional[int] = None) -> np.ndarray:
         crops = np.zeros((n_clips, 4), np.uint32)
+        fs = w * h if frame_stride is None else frame_stride
+        cs = fs * frames_per_clip if clip_stride is None else clip_stride
         self._check(self.lib.vdf_hash_frames_u8_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h,
-                                                                 w * h, w * h * frames_per_clip, d_out,
-                                                                 d_dontcare or None, crops.ctypes.data, stream or None))
+                                                                 fs, cs, d_out, d_dontcare or None, crops.ctypes.data,
+                                                                 stream or None))
         return crops
 
     # ------------------------------------------------------------------- search
