@@ -137,6 +137,9 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.tile_rows = mfma ? vdf::kMfmaRowPad : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
+    // (row tile, chunk) workgroups are numbered with 32 bits: widen the chunks rather than refuse very large inputs
+    while ((uint64_t)L.n_row_tiles * ((n_cols + L.chunk_cols - 1) / L.chunk_cols) >= 0x40000000ull && L.chunk_cols < (1u << 22))
+        L.chunk_cols *= 2;
     const size_t padded_rows = (size_t)L.n_row_tiles * L.tile_rows;
     VDF_HIP(ctx, ctx->row_lo.reserve(padded_rows * 4));
     VDF_HIP(ctx, ctx->row_hi.reserve(padded_rows * 4));
