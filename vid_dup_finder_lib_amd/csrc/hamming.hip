@@ -421,10 +421,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     }
     const float thresh = 1024.0f - 2.0f * (float)min(tol, 1024u);
 
-    // stage loader: a 32-column stage is 1024 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col of that
-    // column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged with
-    // global_load_lds: the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane SOURCE
-    // address; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
+    // stage loader: a stage is kMfmaColStep columns of 32 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col
+    // of that column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged by
+    // LDS-DMA (buffer_load ... lds): the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane
+    // SOURCE offset; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
     const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
     constexpr int kDmaPerWave = (int)(kMfmaColStep * 32 / (64 * kMfmaWaves));  // 1 KB DMA instructions per wave per stage
     // Piece i of this wave fills LDS slots L = 64 W i + 64 wave + lane (W waves): column c = 2 W i + c0 with
