@@ -107,3 +107,38 @@ def test_hash_fuzz_frame_sizes(seed):
             eng.close()
         gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(3, 1024)[:, :1000]
         assert not ((gb != wb) & care).any(), (mode, h, w)
+
+
+@pytest.mark.parametrize("seed", range(max(10, _SOAK // 20)))
+def test_hash_fuzz_large_frames(seed):
+    """Decoder-sized frames (129..900 rows, up to 1500 wide, odd sizes included): the whole-line per-frame kernel (auto and
+    forced), the previous per-frame kernel and the scalar kernel against the oracle."""
+    import os
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(70_000 + seed)
+    h, w = int(rng.integers(129, 900)), int(rng.integers(17, 1500))
+    if seed % 4 == 0:
+        w = (w + 127) // 128 * 128  # line-aligned pitch
+    frames = rng.integers(0, 256, size=(2, 16, h, w), dtype=np.uint8)
+    if seed % 3 == 0:
+        frames = (frames // 16 * 16 + rng.integers(0, 3, size=(2, 16, 1, 1))).astype(np.uint8)  # banded content
+    want, coefs = orc.hash_clips_with_coefs(frames)
+    care = np.abs(coefs) >= 1e-6
+    wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(2, 1024)[:, :1000]
+    for mode in (0, 1, 2, 4):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+        try:
+            got = eng.hash_frames(frames)
+        except vdf.VdfError as e:
+            assert mode in (2, 4) and e.code == -2, (mode, h, w, str(e))
+            continue
+        finally:
+            eng.close()
+        gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(2, 1024)[:, :1000]
+        assert not ((gb != wb) & care).any(), (mode, h, w)
