@@ -139,3 +139,10 @@ def test_strided_and_misaligned_device_buffers(engine, h, w):
     want = engine.hash_frames(frames[:, :16].copy())
     assert np.array_equal(got, want)
     _check(engine, frames[:, :16].copy())
+
+
+def test_uhd_clip_matches_oracle(engine):
+    """3840 x 2160: 68 quads, 30 windows; also the largest coefficient windows the tests see (405 vertical taps)."""
+    rng = np.random.default_rng(2160)
+    frames = rng.integers(0, 256, size=(1, 16, 2160, 3840), dtype=np.uint8)
+    _check(engine, frames)
