@@ -172,7 +172,8 @@ def main():
         full_w, full_d = vd.all_gather_database(shard_w, shard_d, force=use_dist)
         groups = vd.search_self_sharded(eng, full_w, full_d, tol_int, stream=stream)
         st = eng.last_stats()
-        kernel_ms.append((st["kernel_ms"], st["n_launches"], st["pairs"], st["pairs_computed"], st["n_hits"]))
+        kernel_ms.append((st["kernel_ms"], st["n_launches"], st["pairs"], st["pairs_computed"], st["n_hits"],
+                          st["pairs_early_exit"], st["early_exit_bits"]))
         if rank == 0:
             n_groups = len(groups)
 
@@ -217,9 +218,17 @@ def main():
     else:
         kname = "hamming_mfma_kernel"
         tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
+        ee_bits = int(kernel_ms[-1][6])
+        executed = (k_comp - k_early * (1.0 - ee_bits / 1024.0 if ee_bits else 0.0)) * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, "traffic": read_traffic(kname),
                     "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
+                    "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
+                                   "executed_tflops": executed, "executed_frac": executed / MFMA_FP4_PEAK_TFLOPS,
+                                   "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
+                                           "exceed the tolerance cannot contain a hit and stops there (exact); 'achieved' "
+                                           "counts the algorithmic 2048 FLOP per pair, executed_* what the MFMAs really did"},
                     "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
                             "2048 FLOP per pair; integer results, bit-identical to XOR + popcount"}
         extra = {"hbm_operand_stream_model": hbm_model}

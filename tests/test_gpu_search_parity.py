@@ -213,3 +213,31 @@ def test_groups_max_distance_matches_bruteforce(engine):
         want_r.append(max(orc.hamming(hs[i], hs[j]) for i in range(len(hs)) for j in range(i + 1, len(hs))))
     assert got_r.tolist() == want_r
     assert engine.groups_max_distance(w, []).tolist() == []
+
+
+@pytest.mark.parametrize("step", [0, 7, 10, 11, 12, 13, 16])
+@pytest.mark.parametrize("tol", [0, 120, 350, 600])
+def test_early_exit_step_never_changes_results(step, tol, monkeypatch):
+    """The MFMA kernel may stop a 32 x 32 block after 64 (step + 1) bits when every partial distance already exceeds the
+    tolerance.  Any step must give the oracle's groups: steps where nearly every block exits (small tol), steps where none
+    does (tol 600), clustered data whose blocks contain hits, and the disabled test (16)."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_SEARCH_BACKEND", "mfma")
+    monkeypatch.setenv("VDF_MFMA_PRUNE_STEP", str(step))
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(1000 * step + tol)
+        words, dur = hg.planted_set(rng, 3000, n_clusters=60, max_copies=6, max_flips=min(tol + 40, 700),
+                                    durations="zero" if tol % 2 else "log")
+        words, dur, _ = hg.sort_by_duration(words, dur)
+        got = eng.search_self_sorted(words, dur, tol)
+        want = orc.search_self_sorted(words, dur, tol)
+        assert got == want
+        st = eng.last_stats()
+        assert st["early_exit_bits"] in (0, 448, 576, 704, 768, 832, 896)
+        assert st["pairs_early_exit"] <= st["pairs_computed"]
+        if step == 16:
+            assert st["early_exit_bits"] == 0 and st["pairs_early_exit"] == 0
+    finally:
+        eng.close()

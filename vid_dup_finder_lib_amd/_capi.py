@@ -50,6 +50,9 @@ class VdfSearchStats(C.Structure):
         ("n_tiles", C.c_uint64),
         ("n_launches", C.c_uint32),
         ("kernel_ms", C.c_float),
+        ("pairs_early_exit", C.c_uint64),
+        ("early_exit_bits", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 

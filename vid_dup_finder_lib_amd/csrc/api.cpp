@@ -70,6 +70,7 @@ struct vdf_ctx {
     uint32_t mfma_chunk_cols = 16384, mfma_group = 8192;  // 16384-column chunks: longer workgroups amortise the target loads (swept 2048..65536)
     DevBuf group_cmin, group_offset, group_blocks;
     uint32_t mfma_xcd_stripe = 0;
+    int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
@@ -176,8 +177,25 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
 
     if (mfma) {
-        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
+        bool ablate_set = false;
+        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) { L.ablate = std::atoi(ab); ablate_set = L.ablate != 0; }
         L.xcd_stripe = ctx->mfma_xcd_stripe;
+        // Early-exit step: the first k-step after which unrelated hashes (partial distance bits / 2 +- sqrt(bits) / 2) are,
+        // 4 sigma down, still more than tol apart - then nearly every 32 x 32 block stops there.  Exact whatever is picked.
+        L.prune_step = 16;
+        if (ctx->mfma_prune_step >= 0) {
+            L.prune_step = ctx->mfma_prune_step;
+        } else if (ablate_set) {
+            L.prune_step = 16;
+        } else {
+            for (int st = 6; st <= 13; st++) {
+                const double bits = 64.0 * (st + 1);
+                if (bits / 2 - 2.0 * std::sqrt(bits) >= (double)tol_int + 1) { L.prune_step = st; break; }
+            }
+        }
+        // the kernel is instantiated for steps 6, 8, 10, 11, 12, 13 (and 16 = no test): round up
+        L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 13 ? L.prune_step : 16;
+        if (L.ablate) L.prune_step = 16;
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
         if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
@@ -237,6 +255,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     ctx->stats.n_tiles += total_tiles;
     ctx->stats.n_launches += 1;
     ctx->stats.kernel_ms += ms;
+    ctx->stats.pairs_early_exit += fin[3];
+    ctx->stats.early_exit_bits = (mfma && L.prune_step < 15) ? 64u * (uint32_t)(L.prune_step + 1) : 0u;
     return VDF_OK;
 }
 
@@ -564,6 +584,7 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
         if (c >= 32 && c <= (1 << 22)) ctx->mfma_chunk_cols = (uint32_t)c;
     }
     if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
+    if (const char *s = std::getenv("VDF_MFMA_PRUNE_STEP")) ctx->mfma_prune_step = std::atoi(s);
     if (const char *s = std::getenv("VDF_MFMA_GROUP")) {
         long c = std::atol(s);
         if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;

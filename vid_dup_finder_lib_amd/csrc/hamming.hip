@@ -352,7 +352,12 @@ constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage
 // 3 = no DMA and no barrier, 4 = no LDS reads (B fragments stay in registers; DMA and barrier kept), 5 = no LDS reads,
 // no DMA, no barrier (the bare MFMA stream inside the kernel's workgroup structure), 6 = every other DMA piece only,
 // 7 = all DMA pieces but 4 bytes per lane instead of 16 (same instruction count, a quarter of the data).
-template <int ABLATE>
+// CHK (< 15): early exit.  A Hamming distance only grows as more bit positions are counted, so if after k-steps 0..CHK
+// (64 (CHK + 1) bits) every pair of the wave's 32 x 32 blocks is already MORE than `tol` apart, none can be a hit and the
+// remaining 15 - CHK steps are skipped - exact for any data.  Unrelated hashes sit at (bits / 2) +- sqrt(bits) / 2, so at
+// tolerance 350 the test after 832 bits (CHK = 12) passes for ~99.8 % of the blocks and saves 3 of 16 MFMA steps; blocks that
+// do contain a near pair simply run to the end.  The host picks CHK from the tolerance (16 = no test).
+template <int ABLATE, int CHK>
 __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles == 2 ? 2 : 1)) void hamming_mfma_kernel(
     const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
         }
     }
     const float thresh = 1024.0f - 2.0f * (float)min(tol, 1024u);
+    const float thresh_chk = 64.0f * (float)(CHK + 1) - 2.0f * (float)min(tol, 1024u);  // partial dot >= this <=> partial distance <= tol
 
     // stage loader: a stage is kMfmaColStep columns of 32 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col
     // of that column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged by
@@ -452,6 +458,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
     };
     // one stage: MFMAs over the 64 candidates in `cur` while the next stage's DMA pieces go out to `nxt`
+    uint32_t n_early = 0;  // sub-tiles (32 columns x this wave's 32 kRowTiles rows) that took the early exit
     auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) {
         // The next stage's DMA pieces are issued one at a time between the MFMAs of sub-tile 0 (a 1 KB piece costs the
         // issuing wave 60-185 cycles when bunched with the LDS reads at the top of a stage).  Branch-free so that the
@@ -473,8 +480,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
             else bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
         }
         if (!kNoLds) __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the prologue of LDS reads up front
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
+        auto k_step = [&](int s) __attribute__((always_inline)) {
             const uint4 bv = bq[s % kPrefetch];
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
 #pragma unroll
@@ -490,6 +496,29 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
             __builtin_amdgcn_sched_group_barrier(0x008, kRowTiles, 0);
             if (!kNoLds && s + kPrefetch < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (dma_here) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        };
+        constexpr int kFirst = CHK < 15 ? CHK + 1 : 16;  // k-steps before the early-exit test
+#pragma unroll
+        for (int s = 0; s < kFirst; s++) k_step(s);
+        if (CHK < 15) {
+            float pm = acc[0][0];
+#pragma unroll
+            for (int rt = 0; rt < kRowTiles; rt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) pm = fmaxf(pm, acc[rt][r]);
+            if (__builtin_amdgcn_ballot_w64(pm >= thresh_chk) == 0ull) {
+                // no pair of these blocks can end within tol: skip the rest, but not the DMA pieces it would have issued
+                n_early += 1;
+#pragma unroll
+                for (int s = kFirst; s < 16; s++) {
+                    constexpr int kDmaEvery = 16 * kDmaSubs / kDmaPerWave;
+                    if ((ABLATE < 2 || ABLATE == 4 || ABLATE >= 6) && sub < kDmaSubs && (16 * (int)sub + s) % kDmaEvery == 0)
+                        load_piece(rs_next, nxt, (16 * (int)sub + s) / kDmaEvery);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int s = kFirst; s < 16; s++) k_step(s);
         }
         float m = acc[0][0];
 #pragma unroll
@@ -546,6 +575,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
         run_stage(cb + kMfmaColStep, s_b1, s_b0);
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
+    if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u * kRowTiles));
 }
 
 hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,
@@ -655,22 +685,32 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
     if (L.tile_rows != kMfmaTileRows) return hipErrorInvalidValue;
     for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
         const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
-#define VDF_MFMA_LAUNCH(AB)                                                                                         \
-    hipLaunchKernelGGL(hamming_mfma_kernel<AB>, dim3(nb), dim3(64 * kMfmaWaves), 0, stream,                                      \
+#define VDF_MFMA_LAUNCH(AB, CK)                                                                                     \
+    hipLaunchKernelGGL((hamming_mfma_kernel<AB, CK>), dim3(nb), dim3(64 * kMfmaWaves), 0, stream,                            \
                        reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,           \
                        reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
                        L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
                        L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
                        L.hits, L.capacity, L.counters, L.overflow_row, base, L.xcd_stripe)
         switch (L.ablate) {
-        case 1: VDF_MFMA_LAUNCH(1); break;
-        case 2: VDF_MFMA_LAUNCH(2); break;
-        case 3: VDF_MFMA_LAUNCH(3); break;
-        case 4: VDF_MFMA_LAUNCH(4); break;
-        case 5: VDF_MFMA_LAUNCH(5); break;
-        case 6: VDF_MFMA_LAUNCH(6); break;
-        case 7: VDF_MFMA_LAUNCH(7); break;
-        default: VDF_MFMA_LAUNCH(0); break;
+        case 1: VDF_MFMA_LAUNCH(1, 16); break;
+        case 2: VDF_MFMA_LAUNCH(2, 16); break;
+        case 3: VDF_MFMA_LAUNCH(3, 16); break;
+        case 4: VDF_MFMA_LAUNCH(4, 16); break;
+        case 5: VDF_MFMA_LAUNCH(5, 16); break;
+        case 6: VDF_MFMA_LAUNCH(6, 16); break;
+        case 7: VDF_MFMA_LAUNCH(7, 16); break;
+        default:
+            switch (L.prune_step) {  // smallest instantiated step >= the requested one
+            case 0: case 1: case 2: case 3: case 4: case 5: case 6: VDF_MFMA_LAUNCH(0, 6); break;
+            case 7: case 8: VDF_MFMA_LAUNCH(0, 8); break;
+            case 9: case 10: VDF_MFMA_LAUNCH(0, 10); break;
+            case 11: VDF_MFMA_LAUNCH(0, 11); break;
+            case 12: VDF_MFMA_LAUNCH(0, 12); break;
+            case 13: VDF_MFMA_LAUNCH(0, 13); break;
+            default: VDF_MFMA_LAUNCH(0, 16); break;
+            }
+            break;
         }
 #undef VDF_MFMA_LAUNCH
         hipError_t e = hipGetLastError();

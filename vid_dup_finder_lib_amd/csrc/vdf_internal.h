@@ -30,6 +30,7 @@ struct SearchLaunch {
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
     uint32_t *group_cmin, *group_offset, *group_blocks;  // [n_groups (+1)]: chunk-major grouped order (MFMA backend), else null
     int ablate = 0;                       // timing experiments only (VDF_MFMA_ABLATE), wrong results when != 0
+    int prune_step = 16;                  // MFMA backend: k-step after which a block that cannot contain a hit stops (16 = never)
     uint32_t xcd_stripe = 0;              // MFMA backend: 1 = candidate chunks striped over the 8 XCDs (chunk = base + 8 k + blockIdx % 8)
     uint32_t shard_index = 0, shard_count = 1;  // row tiles t with t % shard_count == shard_index are this launch's
     uint32_t n_groups, group_size;        // n_groups = 0 for the VALU backend (compact tile list)
