@@ -81,7 +81,7 @@ typedef struct vdf_search_stats {
     uint32_t n_launches;    /* distance-kernel launches (1 unless the hit buffer overflowed) */
     float kernel_ms;        /* HIP-event time of the distance kernel(s), on their stream */
     uint64_t pairs_early_exit; /* of pairs_computed: comparisons that stopped before the last bit because the partial distance
-                                  of their whole 32 x 32 block already exceeded the tolerance (MFMA backend; exact) */
+                                  of their whole block already exceeded the tolerance (exact; both backends) */
     uint32_t early_exit_bits;  /* bit positions counted before that test (0 = test disabled) */
     uint32_t reserved;
 } vdf_search_stats;

@@ -217,13 +217,14 @@ def test_groups_max_distance_matches_bruteforce(engine):
 
 @pytest.mark.parametrize("step", [0, 7, 10, 11, 12, 13, 16])
 @pytest.mark.parametrize("tol", [0, 120, 350, 600])
-def test_early_exit_step_never_changes_results(step, tol, monkeypatch):
+@pytest.mark.parametrize("backend", ["mfma", "valu"])
+def test_early_exit_step_never_changes_results(backend, step, tol, monkeypatch):
     """The MFMA kernel may stop a 32 x 32 block after 64 (step + 1) bits when every partial distance already exceeds the
     tolerance.  Any step must give the oracle's groups: steps where nearly every block exits (small tol), steps where none
     does (tol 600), clustered data whose blocks contain hits, and the disabled test (16)."""
     import vid_dup_finder_lib_amd as vdf
 
-    monkeypatch.setenv("VDF_SEARCH_BACKEND", "mfma")
+    monkeypatch.setenv("VDF_SEARCH_BACKEND", backend)
     monkeypatch.setenv("VDF_MFMA_PRUNE_STEP", str(step))
     eng = vdf.Engine(0)
     try:

@@ -176,26 +176,24 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.counters = ctx->counters.as<unsigned long long>();
     L.overflow_row = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 4);
 
-    if (mfma) {
-        bool ablate_set = false;
-        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) { L.ablate = std::atoi(ab); ablate_set = L.ablate != 0; }
-        L.xcd_stripe = ctx->mfma_xcd_stripe;
-        // Early-exit step: the first k-step after which unrelated hashes (partial distance bits / 2 +- sqrt(bits) / 2) are,
-        // 4 sigma down, still more than tol apart - then nearly every 32 x 32 block stops there.  Exact whatever is picked.
-        L.prune_step = 16;
-        if (ctx->mfma_prune_step >= 0) {
-            L.prune_step = ctx->mfma_prune_step;
-        } else if (ablate_set) {
-            L.prune_step = 16;
-        } else {
-            for (int st = 6; st <= 13; st++) {
-                const double bits = 64.0 * (st + 1);
-                if (bits / 2 - 2.0 * std::sqrt(bits) >= (double)tol_int + 1) { L.prune_step = st; break; }
-            }
+    // Early-exit step (both backends): the first 64-bit k-step after which unrelated hashes (partial distance bits / 2 +-
+    // sqrt(bits) / 2) are, 4 sigma down, still more than tol apart - then nearly every block stops there.  Exact whatever is
+    // picked.  Kernels are instantiated for steps 6, 8, 10, 11, 12, 13 (MFMA) / 6, 10, 12 (VALU): round up; 16 = no test.
+    L.prune_step = 16;
+    if (ctx->mfma_prune_step >= 0) {
+        L.prune_step = ctx->mfma_prune_step;
+    } else {
+        for (int st = 6; st <= 13; st++) {
+            const double bits = 64.0 * (st + 1);
+            if (bits / 2 - 2.0 * std::sqrt(bits) >= (double)tol_int + 1) { L.prune_step = st; break; }
         }
-        // the kernel is instantiated for steps 6, 8, 10, 11, 12, 13 (and 16 = no test): round up
-        L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 13 ? L.prune_step : 16;
+    }
+    if (mfma) L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 13 ? L.prune_step : 16;
+    else L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 10 ? 10 : L.prune_step <= 12 ? 12 : 16;
+    if (mfma) {
+        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
         if (L.ablate) L.prune_step = 16;
+        L.xcd_stripe = ctx->mfma_xcd_stripe;
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
         if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
@@ -256,7 +254,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     ctx->stats.n_launches += 1;
     ctx->stats.kernel_ms += ms;
     ctx->stats.pairs_early_exit += fin[3];
-    ctx->stats.early_exit_bits = (mfma && L.prune_step < 15) ? 64u * (uint32_t)(L.prune_step + 1) : 0u;
+    ctx->stats.early_exit_bits = L.prune_step < 15 ? 64u * (uint32_t)(L.prune_step + 1) : 0u;
     return VDF_OK;
 }
 

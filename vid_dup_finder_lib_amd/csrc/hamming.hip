@@ -200,7 +200,9 @@ __global__ void group_scan_kernel(const uint32_t *__restrict__ group_blocks, uin
     }
 }
 
-template <int R>
+// CHKW (< 32): exact early exit, as in the MFMA kernel below - after CHKW of the 32 dwords, a candidate that every lane's rows
+// are already more than `tol` away from cannot be a hit for this wave and the remaining dwords are skipped.
+template <int R, int CHKW>
 __global__ __launch_bounds__(256) void hamming_tile_kernel(
     const uint32_t *__restrict__ row_hashes, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
     uint32_t row_index_base, const uint32_t *__restrict__ col_hashes, const uint32_t *__restrict__ row_lo,
@@ -255,13 +257,14 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
     }
 
     const_u32_ptr cols = (const_u32_ptr)(uintptr_t)col_hashes;
+    uint32_t n_early = 0;  // candidates this wave left early (x 64 R pairs each)
     for (uint32_t c = c_begin; c < c_end; ++c) {
         const_u32_ptr cp = cols + (size_t)c * 32;
         uint32_t d[R];
 #pragma unroll
         for (int k = 0; k < R; k++) d[k] = 0u;
 #pragma unroll
-        for (int w = 0; w < 32; ++w) {
+        for (int w = 0; w < (CHKW < 32 ? CHKW : 32); ++w) {
             const uint32_t cw = cp[w];  // SGPR
 #pragma unroll
             for (int k = 0; k < R; k++) d[k] += __builtin_popcount(rw[k][w] ^ cw);
@@ -269,6 +272,18 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
         uint32_t m = d[0];
 #pragma unroll
         for (int k = 1; k < R; k++) m = min(m, d[k]);
+        if (CHKW < 32) {
+            if (__builtin_amdgcn_ballot_w64(m <= tol) == 0ull) { n_early += 1; continue; }  // partial distances only grow
+#pragma unroll
+            for (int w = CHKW; w < 32; ++w) {
+                const uint32_t cw = cp[w];
+#pragma unroll
+                for (int k = 0; k < R; k++) d[k] += __builtin_popcount(rw[k][w] ^ cw);
+            }
+            m = d[0];
+#pragma unroll
+            for (int k = 1; k < R; k++) m = min(m, d[k]);
+        }
         if (__builtin_amdgcn_ballot_w64(m <= tol) != 0ull) {
             // rare path: window, consumption bitmap, append
             bool col_ok = true;
@@ -290,6 +305,7 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
         }
     }
     if (threadIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * TILE_ROWS);
+    if (CHKW < 32 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (64u * R));
 }
 
 // ---- exact Hamming distances on the matrix cores ---------------------------------------------------------
@@ -598,23 +614,31 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)
 {
     if (total_tiles == 0) return hipSuccess;
-#define VDF_LAUNCH(RR)                                                                                              \
-    hipLaunchKernelGGL(hamming_tile_kernel<RR>, dim3(nb), dim3(256), 0, stream, L.row_hashes, L.row_perm,            \
+#define VDF_LAUNCH(RR, CW)                                                                                          \
+    hipLaunchKernelGGL((hamming_tile_kernel<RR, CW>), dim3(nb), dim3(256), 0, stream, L.row_hashes, L.row_perm,      \
                        L.n_rows, L.row_index_base, L.col_hashes, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,          \
                        L.tile_first, L.tile_offset, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
                        L.hits, L.capacity, L.counters, L.overflow_row, base)
+#define VDF_LAUNCH_R(RR)                                                                                            \
+    switch (L.prune_step) { /* instantiated: after 14, 22, 26 dwords = k-steps 6, 10, 12 of the MFMA kernel */      \
+    case 6: VDF_LAUNCH(RR, 14); break;                                                                              \
+    case 8: case 10: VDF_LAUNCH(RR, 22); break;                                                                     \
+    case 11: case 12: VDF_LAUNCH(RR, 26); break;                                                                    \
+    default: VDF_LAUNCH(RR, 32); break;                                                                             \
+    }
     // HIP limits a grid to 2^32 work-items in x: slices of at most kMaxBlocksPerLaunch workgroups
     for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
         const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
         switch (L.tile_rows / 256) {
-        case 1: VDF_LAUNCH(1); break;
-        case 2: VDF_LAUNCH(2); break;
-        case 4: VDF_LAUNCH(4); break;
+        case 1: VDF_LAUNCH_R(1); break;
+        case 2: VDF_LAUNCH_R(2); break;
+        case 4: VDF_LAUNCH_R(4); break;
         default: return hipErrorInvalidValue;
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+#undef VDF_LAUNCH_R
 #undef VDF_LAUNCH
     return hipSuccess;
 }
