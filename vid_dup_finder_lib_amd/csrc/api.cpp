@@ -67,9 +67,10 @@ struct vdf_ctx {
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
-    uint32_t mfma_chunk_cols = 16384, mfma_group = 8192;  // 16384-column chunks: longer workgroups amortise the target loads (swept 2048..65536)
+    uint32_t mfma_chunk_cols = 0, mfma_group = 8192;  // 0 = pick the chunk width per search (search_core); VDF_MFMA_CHUNK_COLS overrides
     DevBuf group_cmin, group_offset, group_blocks;
     uint32_t mfma_xcd_stripe = 0;
+    uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
     int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows;
@@ -138,6 +139,13 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     L.tile_rows = mfma ? vdf::kMfmaRowPad : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
+    if (mfma && L.chunk_cols == 0) {
+        // Long chunks amortise a workgroup's target loads (65536 columns measured best at 1 M hashes), but a small search
+        // must still be cut into enough workgroups to fill and balance 256 CUs: halve (down to 4096) until there are >= 8192 of them
+        // (swept at 10 k .. 1 M hashes, tools/sweep_sizes.py).
+        L.chunk_cols = 65536;
+        while (L.chunk_cols > 4096 && (uint64_t)L.n_row_tiles * ((n_cols + L.chunk_cols - 1) / L.chunk_cols) < ctx->mfma_min_wgs) L.chunk_cols /= 2;
+    }
     // (row tile, chunk) workgroups are numbered with 32 bits: widen the chunks rather than refuse very large inputs
     while ((uint64_t)L.n_row_tiles * ((n_cols + L.chunk_cols - 1) / L.chunk_cols) >= 0x40000000ull && L.chunk_cols < (1u << 22))
         L.chunk_cols *= 2;
@@ -583,6 +591,7 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     }
     if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_MFMA_PRUNE_STEP")) ctx->mfma_prune_step = std::atoi(s);
+    if (const char *s = std::getenv("VDF_MFMA_MIN_WGS")) { const long v = std::atol(s); if (v >= 1 && v <= (1 << 24)) ctx->mfma_min_wgs = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_GROUP")) {
         long c = std::atol(s);
         if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;

@@ -355,7 +355,7 @@ constexpr int kRowTiles = VDF_ROW_TILES;                                // 32-ro
 constexpr int kPrefetch = VDF_PF;           // LDS fragments in flight ahead of the MFMAs
 constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
 #ifndef VDF_MFMA_SUB
-#define VDF_MFMA_SUB 2
+#define VDF_MFMA_SUB (VDF_MFMA_WAVES >= 8 ? 4 : 2)  // 8 waves = one workgroup per CU: 2 x 64 KB of LDS stages fit
 #endif
 constexpr uint32_t kMfmaSub = VDF_MFMA_SUB;                     // 32-column sub-tiles per LDS stage
 #ifndef VDF_DMA_SUBS

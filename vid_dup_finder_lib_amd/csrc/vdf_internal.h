@@ -55,7 +55,8 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 // MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of the tile, columns by a further 128.
 #ifndef VDF_MFMA_WAVES
-#define VDF_MFMA_WAVES 4  // waves per MFMA workgroup (build-time experiment knob; 64 target rows per wave)
+#define VDF_MFMA_WAVES 8  // waves per MFMA workgroup (64 target rows per wave).  8 x 128-column stages is the measured best once the
+                          // early exit is on (113.8 ms vs 118.1 for 8 x 64 columns and ~126 for 4 waves); 4 was best without it
 #endif
 #ifndef VDF_ROW_TILES
 #define VDF_ROW_TILES 2  // 32-row MFMA tiles per wave (build-time experiment knob)
