@@ -154,6 +154,7 @@ def test_c5_end_to_end_from_frames_single_gpu(engine):
     from vid_dup_finder_lib_amd import distributed as vd
 
     n_cand, n_ref = 1_000_000, 100_000
+    torch.cuda.empty_cache()  # earlier tests leave cached blocks; 72 GB is easier to get from a clean allocator
     g = torch.Generator(device="cuda")
     g.manual_seed(20250615)
     cand = torch.empty((n_cand, 16, 64, 64), dtype=torch.uint8, device="cuda")
