@@ -496,7 +496,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
             else bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
         }
         if (!kNoLds) __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the prologue of LDS reads up front
-        auto k_step = [&](int s) __attribute__((always_inline)) {
+        constexpr int kFirst = CHK < 15 ? CHK + 1 : 16;  // k-steps before the early-exit test; later fragments are only read
+                                                         // if the block has to run to the end (rare)
+        auto k_step = [&](int s, int limit) __attribute__((always_inline)) {  // limit: fragments >= limit are not prefetched
             const uint4 bv = bq[s % kPrefetch];
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
 #pragma unroll
@@ -504,18 +506,17 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
                 const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
                 acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
             }
-            if (!kNoLds && s + kPrefetch < 16) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
+            if (!kNoLds && s + kPrefetch < limit) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
             constexpr int kDmaEvery = 16 * kDmaSubs / kDmaPerWave;
             const bool dma_here = (ABLATE < 2 || ABLATE == 4 || ABLATE >= 6) && sub < kDmaSubs && (16 * (int)sub + s) % kDmaEvery == 0;
             if (dma_here) load_piece(rs_next, nxt, (16 * (int)sub + s) / kDmaEvery);
             // pin the software pipeline: the scheduler otherwise sinks each LDS read next to its MFMA (1-2 deep)
             __builtin_amdgcn_sched_group_barrier(0x008, kRowTiles, 0);
-            if (!kNoLds && s + kPrefetch < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (!kNoLds && s + kPrefetch < limit) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (dma_here) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         };
-        constexpr int kFirst = CHK < 15 ? CHK + 1 : 16;  // k-steps before the early-exit test
 #pragma unroll
-        for (int s = 0; s < kFirst; s++) k_step(s);
+        for (int s = 0; s < kFirst; s++) k_step(s, kFirst);
         if (CHK < 15) {
             float pm = acc[0][0];
 #pragma unroll
@@ -534,7 +535,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
                 continue;
             }
 #pragma unroll
-            for (int s = kFirst; s < 16; s++) k_step(s);
+            for (int f = kFirst; f < 16 && f < kFirst + kPrefetch; f++)
+                if (!kNoLds) bq[f % kPrefetch] = cur[lds_row | ((uint32_t)(f + 16 * g) ^ c31)];
+#pragma unroll
+            for (int s = kFirst; s < 16; s++) k_step(s, 16);
         }
         float m = acc[0][0];
 #pragma unroll
