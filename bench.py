@@ -88,8 +88,14 @@ def cpu_baseline_hash(clips_per_thread=96):
     with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: the analogue of the app's rayon par_bridge
         list(ex.map(orc.hash_clips, chunks))
     dt = time.perf_counter() - t0
+    n1 = min(n_clips, 4 * clips_per_thread)  # the same work on ONE thread (SURVEY 8d asks for T = 1 and T = all)
+    t1 = time.perf_counter()
+    orc.hash_clips(frames[:n1])
+    dt1 = time.perf_counter() - t1
     return {"value": n_clips * 16 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle from_frames over a {cores}-thread pool, {n_clips} clips of 16x64x64"}
+            "single_thread_value": n1 * 16 / dt1,
+            "sample": f"oracle from_frames over a {cores}-thread pool, {n_clips} clips of 16x64x64 "
+                      f"(single thread: {n1} clips)"}
 
 
 def read_traffic(name):
