@@ -242,3 +242,23 @@ def test_early_exit_step_never_changes_results(backend, step, tol, monkeypatch):
             assert st["early_exit_bits"] == 0 and st["pairs_early_exit"] == 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 511, 512, 513, 1023, 1025, 4095, 4097, 8193])
+def test_tile_and_chunk_boundaries(engine, n):
+    """Database sizes around the 512-row workgroup tile, the 128-column LDS stage and the 4096-column minimum chunk."""
+    rng = np.random.default_rng(n)
+    words, dur = hg.planted_set(rng, n, n_clusters=max(1, n // 40), max_flips=360, durations="log" if n % 2 else "zero")
+    words, dur, _ = hg.sort_by_duration(words, dur)
+    _both_self(engine, words, dur, 350)
+
+
+def test_chunk_boundary_65536(engine):
+    """One candidate chunk is 65536 columns by default: a database just over it, all durations equal (every row tile
+    crosses the chunk boundary), checked against the oracle on the rows around the boundary and by planted recovery."""
+    n = 65536 + 700
+    rng = np.random.default_rng(65536)
+    words, dur = hg.planted_set(rng, n, n_clusters=300, max_flips=340, durations="zero")
+    got = engine.search_self_sorted(words, dur, 350)
+    want = orc.search_self_sorted(words, dur, 350)
+    assert got == want
