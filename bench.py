@@ -3,7 +3,13 @@
 1 M hashes, default tolerance 0.35 -> 350, one MI355X), plus the DCT-hash throughput on 64x64 frame stacks
 (configs[2]) reported in the same JSON line under "hash".
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Launched by torch.distributed.run (RANK in the environment) this process IS a
+rank; launched plainly it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process
+BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's status.  --single-process uses
+the C ABI's multi-GPU context instead (vdf_ctx_create_multi: one host thread per device inside the library, no torch
+collectives): the form a Rust caller of search() gets.
 
 A step = one full pass of the search hot path over the database resident in HBM: (N > 1: RCCL all-gather of the
 per-rank shards,) duration windows + tile list, the tiled XOR+popcount kernel, hit download, host replay of the
@@ -108,6 +114,31 @@ def read_traffic(name):
         return None
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a CHILD process tree (never exec: this may run under a
+    profiler that has already initialised the GPU) and relay rank 0's line.  Nothing here imports torch."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +150,14 @@ def main():
     ap.add_argument("--tolerance", type=float, default=0.35)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-windowed", dest="windowed", action="store_false", help="skip the windowed-durations leg")
+    ap.add_argument("--ten-million", type=int, default=10_000_000,
+                    help="size of the north_star target leg (all-pairs at one GPU; 0 = skip; only at --gpus 1)")
+    ap.add_argument("--no-valu", dest="valu_leg", action="store_false", help="skip the XOR+popcount backend leg")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 inside ONE process through vdf_ctx_create_multi (no torch.distributed)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and not args.single_process:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -216,27 +254,34 @@ def main():
                          "candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per pair (see traffic)"}
     if backend == "valu":
         kname = "hamming_tile_kernel"
-        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname), kernel_ms=k_ms, pairs_per_launch=k_pairs)
+        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname),
+                        traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
+                        kernel_ms=k_ms, pairs_per_launch=k_pairs)
         valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
         valu["frac"] = valu["achieved"] / valu["peak"]
         extra = {"valu": valu}
         dtype = "u32 (xor + popcount over 32 dwords per hash)"
     else:
         kname = "hamming_mfma_kernel"
-        tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
         k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
         ee_bits = int(kernel_ms[-1][6])
         executed = (k_comp - k_early * (1.0 - ee_bits / 1024.0 if ee_bits else 0.0)) * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, "traffic": read_traffic(kname),
+        # frac prices the MFMA work the kernel EXECUTED (blocks that take the exact early exit stop after ee_bits of the
+        # 1024 bit positions); the algorithmic 2048 FLOP per pair are reported beside it, never as the headline fraction
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": executed, "peak": MFMA_FP4_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": executed / MFMA_FP4_PEAK_TFLOPS,
+                    "algorithmic_achieved": alg_tflops, "algorithmic_frac": alg_tflops / MFMA_FP4_PEAK_TFLOPS,
+                    "traffic": read_traffic(kname),
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the committed "
+                                      "profile run of this workload; not measured in this run)",
                     "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
                     "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
-                                   "executed_tflops": executed, "executed_frac": executed / MFMA_FP4_PEAK_TFLOPS,
                                    "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
-                                           "exceed the tolerance cannot contain a hit and stops there (exact); 'achieved' "
-                                           "counts the algorithmic 2048 FLOP per pair, executed_* what the MFMAs really did"},
+                                           "exceed the tolerance cannot contain a hit and stops there (exact)"},
                     "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
-                            "2048 FLOP per pair; integer results, bit-identical to XOR + popcount"}
+                            "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
+                            "pair; integer results, bit-identical to XOR + popcount"}
         extra = {"hbm_operand_stream_model": hbm_model}
         dtype = "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)"
     out = {
@@ -261,15 +306,98 @@ def main():
         wd = torch.from_numpy(dur.view(np.int32)).to(dev)
         ww = torch.from_numpy(words[: args.n_hashes].view(np.int64)).to(dev)
         torch.cuda.synchronize()
-        eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+        for _ in range(max(args.warmup, 1)):
+            eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+        w_k = []
         t1 = time.perf_counter()
-        hits_w, _, _ = eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
-        dtw = time.perf_counter() - t1
+        for _ in range(args.steps):
+            hits_w, _, _ = eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+            w_k.append(eng.last_stats()["kernel_ms"])
+        dtw = (time.perf_counter() - t1) / args.steps
         st = eng.last_stats()
-        out["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"], "kernel_ms": st["kernel_ms"],
-                           "ms": dtw * 1e3, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
-                           "note": "log-uniform durations, one-sided x1.1 window (search_algorithm.rs:99)"}
+        out["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"],
+                           "waste_ratio": st["pairs_computed"] / max(st["pairs"], 1), "kernel_ms": float(np.mean(w_k)),
+                           "ms": dtw * 1e3, "steps": args.steps, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
+                           "note": "log-uniform durations, one-sided x1.1 window (search_algorithm.rs:99); mean over steps"}
         del ww, wd
+
+    # ---- the north_star's literal formulation next to the default one: XOR + popcount on the VALU (hamming_tile_kernel),
+    # same database, same step.  1 GPU only, rank 0.
+    if rank == 0 and world == 1 and args.valu_leg and backend != "valu":
+        old_env = os.environ.get("VDF_SEARCH_BACKEND")
+        os.environ["VDF_SEARCH_BACKEND"] = "valu"
+        try:
+            eng_v = vdf.Engine(local_rank)
+        finally:
+            if old_env is None:
+                os.environ.pop("VDF_SEARCH_BACKEND", None)
+            else:
+                os.environ["VDF_SEARCH_BACKEND"] = old_env
+        full_w, full_d = shard_w, shard_d
+        vd.search_self_sharded(eng_v, full_w, full_d, tol_int, stream=stream)  # warm-up
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        gv = vd.search_self_sharded(eng_v, full_w, full_d, tol_int, stream=stream)
+        torch.cuda.synchronize()
+        dtv = time.perf_counter() - tv
+        sv = eng_v.last_stats()
+        lane_ops = (sv["pairs_computed"] - sv["pairs_early_exit"] * (1.0 - sv["early_exit_bits"] / 1024.0
+                                                                      if sv["early_exit_bits"] else 0.0)) * LANEOPS_PER_PAIR
+        out["valu_backend"] = {"kernel": "hamming_tile_kernel", "pairs_per_s": pairs / dtv, "ms_per_step": dtv * 1e3,
+                               "kernel_ms": sv["kernel_ms"], "match_groups": len(gv), "steps": 1,
+                               "valu": {"achieved": lane_ops / (sv["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                                        "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS},
+                               "note": "XOR + v_bcnt over 32 dwords per pair, candidates streamed through SGPRs; same exact "
+                                       "early exit; identical MatchGroups"}
+        assert len(gv) == n_groups, "VALU and MFMA backends disagree"
+        eng_v.close()
+
+    # ---- the north_star's own target size: all-pairs search() over 10 M VideoHashes on ONE GPU (BASELINE configs[3]'s
+    # database at 1 GPU).  One warm-up at a tenth of the size (allocations), one timed step.  Generated on the device.
+    if rank == 0 and world == 1 and args.ten_million > 0:
+        n10 = args.ten_million
+        g10 = torch.Generator(device=dev)
+        g10.manual_seed(20250614)
+        lo32 = torch.randint(0, 2**32, (n10, 16), dtype=torch.int64, device=dev, generator=g10)
+        hi32 = torch.randint(0, 2**32, (n10, 16), dtype=torch.int64, device=dev, generator=g10)
+        w10 = lo32 | (hi32 << 32)
+        del lo32, hi32
+        w10[:, 15] &= (1 << 40) - 1
+        # planted near-duplicates: every 100 000th hash gets a copy with 0..340 flipped bits right behind it
+        src10 = torch.arange(0, n10 - 1, 100_000, device=dev)
+        rng10 = np.random.default_rng(20250614)
+        rows = w10[src10].cpu().numpy().view(np.uint64)
+        for r in range(len(rows)):
+            bits = np.unpackbits(rows[r].view(np.uint8), bitorder="little")
+            bits[rng10.choice(1024, size=int(rng10.integers(0, 341)), replace=False)] ^= 1
+            rows[r] = np.packbits(bits, bitorder="little").view(np.uint64)
+        w10[src10 + 1] = torch.from_numpy(rows.view(np.int64)).to(dev)
+        d10 = torch.zeros(n10, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        vd.search_self_sharded(eng, w10[: n10 // 10], d10[: n10 // 10], tol_int, stream=stream)
+        torch.cuda.synchronize()
+        t10 = time.perf_counter()
+        g10r = vd.search_self_sharded(eng, w10, d10, tol_int, stream=stream)
+        torch.cuda.synchronize()
+        dt10 = time.perf_counter() - t10
+        s10 = eng.last_stats()
+        p10 = n10 * (n10 - 1) // 2
+        ex10 = (s10["pairs_computed"] - s10["pairs_early_exit"] * (1.0 - s10["early_exit_bits"] / 1024.0
+                                                                   if s10["early_exit_bits"] else 0.0))
+        k10 = s10["kernel_ms"] * 1e-3
+        out["ten_million"] = {"workload": f"all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
+                                          f"{tol_int}, ONE GPU (north_star target; BASELINE configs[3] database)",
+                              "n_hashes": n10, "pairs": p10, "steps": 1, "ms_per_step": dt10 * 1e3,
+                              "pairs_per_s": p10 / dt10, "kernel_ms": s10["kernel_ms"], "n_launches": s10["n_launches"],
+                              "match_groups": len(g10r), "planted_pairs": int(len(src10)),
+                              "hbm_operand_stream_frac": p10 / dt10 * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
+        if backend != "valu":
+            out["ten_million"]["roofline"] = {"bound": "mfma", "kernel": "hamming_mfma_kernel",
+                                              "achieved": ex10 * FLOP_PER_PAIR / k10 / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": ex10 * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                                              "algorithmic_frac": s10["pairs_computed"] * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                                              "traffic": None}
+        del w10, d10
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM; clips are independent, so every rank hashes its
     # own args.hash_clips clips with no communication (weak scaling) and the job rate is the sum -----------------

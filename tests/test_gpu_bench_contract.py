@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_emits_the_contract_line(backend):
     env = dict(os.environ, VDF_SEARCH_BACKEND=backend)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20"], capture_output=True, text=True, timeout=600, env=env)
+                          "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20", "--ten-million", "200000"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly ONE JSON line on stdout
@@ -33,4 +33,14 @@ def test_bench_emits_the_contract_line(backend):
     assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
     h = d["hash"]
     assert h["unit"] == "frames/s" and h["roofline"]["bound"] == "hbm" and h["cpu_baseline"]["kind"] == "port"
-    assert d["match_groups"] > 0 and d["windowed"]["pairs"] > 0
+    assert d["match_groups"] > 0 and d["windowed"]["pairs"] > 0 and d["windowed"]["steps"] == 1
+    assert d["windowed"]["waste_ratio"] >= 1.0
+    t = d["ten_million"]  # the north_star's target leg (here at a test size)
+    assert t["n_hashes"] == 200000 and t["pairs"] == 200000 * 199999 // 2 and t["match_groups"] >= t["planted_pairs"] - 1
+    if backend == "mfma":
+        # frac prices the MFMA work actually executed; the algorithmic figure is reported beside it and is never smaller
+        assert r["algorithmic_frac"] >= r["frac"] and "traffic_source" in r
+        v = d["valu_backend"]
+        assert v["match_groups"] == d["match_groups"] and v["pairs_per_s"] > 0 and 0 < v["valu"]["frac"] < 1.2
+    else:
+        assert "valu_backend" not in d

@@ -1,0 +1,105 @@
+"""Two ranks driving the REAL engine (both on GPU 0, collectives over gloo - RCCL refuses two ranks on one device):
+  * `python bench.py --gpus 2` started plainly launches its own ranks, prints one JSON line, and finds the same
+    MatchGroups as the 1-rank run over the same database;
+  * search_self_sharded through the hit-buffer overflow protocol (consumption bitmap broadcast from rank 0, uploaded
+    and consumed on torch's current stream) and search_refs_sharded, against the oracle."""
+import json
+import os
+import pickle
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _bench(extra, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--hash-clips", "2000",
+                          "--hash-hd-clips", "0", "--ten-million", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu"] + extra,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    n1 = 30000
+    n2 = int(round(n1 * 2 ** 0.5))
+    two = _bench(["--gpus", "2", "--n-hashes", str(n1)], {"VDF_DIST_BACKEND": "gloo"})
+    one = _bench(["--gpus", "1", "--n-hashes", str(n2)])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["n_hashes"] == n2 == one["config"]["n_hashes"]
+    assert abs(two["config"]["hashes_per_gpu_shard"] * 2 - n2) <= 1
+    assert two["match_groups"] == one["match_groups"] > 0
+    assert two["config"]["pairs"] == one["config"]["pairs"] == n2 * (n2 - 1) // 2
+    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0
+
+
+def _worker(rank, world, port, capacity, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hashgen as hg
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import distributed as vd
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    eng = vdf.Engine(0)
+    rng = np.random.default_rng(4242)
+    words, dur = hg.planted_set(rng, 3000, n_clusters=40, max_copies=30, max_flips=150, durations="windowed")
+    words[1000:1400] = words[1000]  # 400 identical hashes with equal durations: ~80 000 hits from one region
+    dur[1000:1400] = dur[1000]
+    w, d, _ = hg.sort_by_duration(words, dur)
+    lo, hi = vd.split_range(len(d), rank, world)
+    side = torch.cuda.Stream(device=dev)  # a non-default current stream: the library must order itself behind it
+    with torch.cuda.stream(side):
+        fw, fd = vd.all_gather_database(torch.from_numpy(w[lo:hi].view(np.int64)).to(dev),
+                                        torch.from_numpy(d[lo:hi].view(np.int32)).to(dev))
+        groups = vd.search_self_sharded(eng, fw, fd, 350, capacity=capacity)
+        calls_stream = eng.last_stats()["n_launches"]
+    # and once on torch's legacy default stream (handle 0)
+    groups0 = vd.search_self_sharded(eng, fw, fd, 350, capacity=capacity)
+    pick = np.random.default_rng(5).choice(len(d), size=301, replace=False)
+    rw, rd = w[pick].copy(), d[pick].copy()
+    a, b = vd.split_range(len(rd), rank, world)
+    refs = vd.search_refs_sharded(eng, fw, fd, torch.from_numpy(rw[a:b].view(np.int64)).to(dev),
+                                  torch.from_numpy(rd[a:b].view(np.int32)).to(dev), a, 300, capacity=capacity)
+    if rank == 0:
+        with open(os.path.join(out_dir, "res.pkl"), "wb") as f:
+            pickle.dump({"groups": groups, "groups0": groups0, "refs": refs, "w": w, "d": d, "rw": rw, "rd": rd}, f)
+    else:
+        assert groups is None and refs is None
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.parametrize("capacity", [1 << 20, 500])
+def test_two_ranks_real_engine_match_oracle(tmp_path, capacity):
+    import torch.multiprocessing as mp
+
+    from oracle import vdf_oracle as orc
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, capacity, str(tmp_path)), nprocs=2, join=True)
+    res = pickle.load(open(tmp_path / "res.pkl", "rb"))
+    want = orc.search_self_sorted(res["w"], res["d"], 350)
+    assert res["groups"] == want and res["groups0"] == want
+    assert res["refs"] == orc.search_refs_sorted(res["w"], res["d"], res["rw"], res["rd"], 300)

@@ -81,16 +81,36 @@ def _gather_hits(hits: np.ndarray, group=None) -> Optional[np.ndarray]:
     return allh
 
 
+def _stream_for(t: torch.Tensor, stream: Optional[int]) -> int:
+    """The hipStream_t the library must launch on so that it is ordered behind the torch work that produced `t`
+    (collectives, index_select, the bitmap upload): torch's CURRENT stream unless the caller names one.  The library's
+    own stream (handle 0 / NULL) has no ordering with torch's streams, so it is never the default here."""
+    if stream:
+        return int(stream)
+    if t.device.type == "cuda":
+        return int(torch.cuda.current_stream(t.device).cuda_stream)
+    return 0
+
+
+def _before_engine_call(t: torch.Tensor, stream: int) -> None:
+    """torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream": in that case
+    (and only then) the torch-side producers are drained first."""
+    if not stream and t.device.type == "cuda":
+        torch.cuda.synchronize(t.device)
+
+
 def _coll_device(group=None) -> torch.device:
     backend = dist.get_backend(group) if dist.is_initialized() else "gloo"
     return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
 
 def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_int: int, capacity: int = 1 << 22,
-                        group=None, stream: int = 0) -> Optional[List[List[int]]]:
+                        group=None, stream: Optional[int] = None) -> Optional[List[List[int]]]:
     """search() over a replicated, sorted database.  Returns the groups (lists of sorted indices, reference
-    order) on rank 0 and None elsewhere.  d_words/d_dur live on this rank's GPU."""
+    order) on rank 0 and None elsewhere.  d_words/d_dur live on this rank's GPU.  stream=None: torch's current stream
+    (the one the all-gather and the consumption-bitmap copies are ordered on)."""
     rank, world = _world(group)
+    stream = _stream_for(d_words, stream)
     n = int(d_dur.shape[0])
     if n == 0:
         return [] if rank == 0 else None
@@ -100,6 +120,7 @@ def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_
     row_begin = 0
     row_end = UINT32_MAX
     while row_begin < n:
+        _before_engine_call(d_words, stream)
         hits, n_hits, overflow = engine.search_self_device(
             d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, shard_index=rank, shard_count=world,
             row_begin=row_begin, row_end=row_end, d_matched=(d_matched.data_ptr() if d_matched is not None else 0),
@@ -151,13 +172,15 @@ def split_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def search_refs_sharded(engine, d_cand_words: torch.Tensor, d_cand_dur: torch.Tensor, d_ref_words: torch.Tensor,
                         d_ref_dur: torch.Tensor, ref_index_base: int, tol_int: int, capacity: int = 1 << 22,
-                        group=None, stream: int = 0) -> Optional[List[Tuple[int, List[int]]]]:
+                        group=None, stream: Optional[int] = None) -> Optional[List[Tuple[int, List[int]]]]:
     """search_with_references() with the candidates replicated and THIS rank's slice of the references
     (global positions ref_index_base ..).  Rank 0 returns [(ref_index, [candidate indices])] in reference order."""
     rank, world = _world(group)
+    stream = _stream_for(d_cand_words, stream)
     n_ref = int(d_ref_dur.shape[0])
     n_cand = int(d_cand_dur.shape[0])
     if n_ref and n_cand:
+        _before_engine_call(d_cand_words, stream)
         hits, _ = engine.search_refs_device(d_cand_words.data_ptr(), d_cand_dur.data_ptr(), n_cand,
                                             d_ref_words.data_ptr(), d_ref_dur.data_ptr(), n_ref, tol_int,
                                             ref_index_base=ref_index_base, capacity=capacity, stream=stream)
@@ -170,7 +193,7 @@ def search_refs_sharded(engine, d_cand_words: torch.Tensor, d_cand_dur: torch.Te
 
 
 def hash_and_search_refs(engine, cand_frames: torch.Tensor, cand_dur: torch.Tensor, ref_frames: torch.Tensor,
-                         ref_dur: torch.Tensor, tol_int: int, group=None, stream: int = 0):
+                         ref_dur: torch.Tensor, tol_int: int, group=None, stream: Optional[int] = None):
     """BASELINE configs[4] end to end: every rank hashes ITS candidate clips and ITS reference clips (uint8 device
     tensors [n, >=16, H, W]; no communication), the candidate hashes are replicated with one all-gather and sorted by
     duration (stable; paths, if any, stay with the caller), references keep rank order, then
@@ -178,12 +201,13 @@ def hash_and_search_refs(engine, cand_frames: torch.Tensor, cand_dur: torch.Tens
     [positions in the sorted candidate order])], order[k] = global candidate index (rank-major) at sorted position k."""
     rank, world = _world(group)
     dev = cand_frames.device
+    stream = _stream_for(cand_frames, stream)
 
     def _hash(frames):
         n, nf, h, w = frames.shape
         out = torch.zeros((n, HASH_WORDS), dtype=torch.int64, device=dev)
         if n:
-            torch.cuda.current_stream().synchronize() if dev.type == "cuda" and not stream else None
+            _before_engine_call(frames, stream)
             engine.hash_frames_device(frames.data_ptr(), n, nf, w, h, out.data_ptr(), stream=stream)
         return out
 
