@@ -264,29 +264,134 @@ int vdf_oracle_resize_coeffs(uint32_t in_size, uint32_t out_size, int32_t *start
  * video_hashing/raw_dct_ops.rs:107-142 (pass along y, x, then t; result back
  * in [t][x][y] order).  rustdct "0.7" process_dct2 = unnormalised DCT-II:
  *   X[k] = sum_n x[n] * cos(pi * k * (n + 1/2) / N).
- * Only the sign of each coefficient is consumed (dct_3d.rs:55-62).
+ * Only the sign of each coefficient is consumed (dct_3d.rs:55-62), so the
+ * ORDER of the floating-point operations matters exactly where a coefficient
+ * is mathematically zero: lines that are constant (static clips, black
+ * frames) or mirror-symmetric.  DctPlanner::plan_dct2(16) returns
+ * Type2And3Butterfly16, which - like Butterfly8 and Butterfly4 inside it - is
+ * one step of the crate's split-radix algorithm (Type2And3SplitRadix): the
+ * even outputs are the half-size DCT-II of the sums x[n] + x[N-1-n], the odd
+ * outputs come from the differences x[n] - x[N-1-n], rotated by the twiddles
+ * e^{i pi (2n+1) / 2N} into two quarter-size DCT-IIs.  Under that structure
+ * every AC output of a constant line and every odd output of a symmetric
+ * line is an exact +-0.0 (bit 0), which a direct cosine sum does not give.
+ * The crate's source is not under /root/reference (un-vendored, no lockfile):
+ * this restates its published algorithm; products and sums are rounded
+ * separately as Rust does (build with -ffp-contract=off).  Twiddles as
+ * rustdct::twiddles::single_twiddle(i, len).conj(): angle = (-2 pi / len) * i.
  * ---------------------------------------------------------------------- */
-static double g_cos[DCT_SIZE][DCT_SIZE];
-static int g_cos_ready = 0;
+static double g_tw4[2], g_tw8[2][2], g_tw16[4][2]; /* (cos, sin) of pi (2 i + 1) / (2 N) */
+static int g_tw_ready = 0;
+
+static void twiddle(int i, int fft_len, double *out)
+{
+    const double angle_constant = M_PI * -2.0 / (double)fft_len;
+    const double angle = angle_constant * (double)i;
+    out[0] = cos(angle);
+    out[1] = -sin(angle); /* .conj() */
+}
 
 static void cos_init(void)
 {
-    if (g_cos_ready) return;
-    for (int k = 0; k < DCT_SIZE; k++)
-        for (int n = 0; n < DCT_SIZE; n++)
-            g_cos[k][n] = cos(M_PI * (double)k * ((double)n + 0.5) / (double)DCT_SIZE);
-    g_cos_ready = 1;
+    if (g_tw_ready) return;
+    twiddle(1, 16, g_tw4);
+    for (int i = 0; i < 2; i++) twiddle(2 * i + 1, 32, g_tw8[i]);
+    for (int i = 0; i < 4; i++) twiddle(2 * i + 1, 64, g_tw16[i]);
+    g_tw_ready = 1;
+}
+
+static void dct2_len2(double *b)
+{
+    const double sum = b[0] + b[1];
+    b[1] = (b[0] - b[1]) * M_SQRT1_2; /* f64::consts::FRAC_1_SQRT_2 */
+    b[0] = sum;
+}
+
+static void dct2_len4(double *b)
+{
+    double in2[2] = {b[3] + b[0], b[1] + b[2]};
+    const double lower = b[0] - b[3], upper = b[1] - b[2];
+    const double cos_in = lower * g_tw4[0] + upper * g_tw4[1];
+    const double sin_in = upper * g_tw4[0] - lower * g_tw4[1];
+    dct2_len2(in2);
+    b[0] = in2[0];
+    b[1] = cos_in; /* the quarter-size transforms have length 1 */
+    b[2] = in2[1];
+    b[3] = -sin_in;
+}
+
+static void dct2_len8(double *b)
+{
+    double in2[4], ev[2], od[2];
+    for (int i = 0; i < 2; i++) {
+        const double bottom = b[i], top = b[7 - i], hb = b[3 - i], ht = b[4 + i];
+        in2[i] = top + bottom;
+        in2[3 - i] = hb + ht;
+        const double lower = bottom - top, upper = hb - ht;
+        const double cos_in = lower * g_tw8[i][0] + upper * g_tw8[i][1];
+        const double sin_in = upper * g_tw8[i][0] - lower * g_tw8[i][1];
+        ev[i] = cos_in;
+        od[1 - i] = (i % 2 == 0) ? sin_in : -sin_in;
+    }
+    dct2_len4(in2);
+    dct2_len2(ev);
+    dct2_len2(od);
+    b[0] = in2[0];
+    b[1] = ev[0];
+    b[2] = in2[1];
+    { /* i = 1, quarter_len = 2: (i + quarter_len) odd */
+        const double c = ev[1], sv = od[1];
+        b[3] = c + sv;
+        b[4] = in2[2];
+        b[5] = c - sv;
+        b[6] = in2[3];
+    }
+    b[7] = -od[0];
+}
+
+static void dct2_len16(double *b)
+{
+    double in2[8], ev[4], od[4];
+    for (int i = 0; i < 4; i++) {
+        const double bottom = b[i], top = b[15 - i], hb = b[7 - i], ht = b[8 + i];
+        in2[i] = top + bottom;
+        in2[7 - i] = hb + ht;
+        const double lower = bottom - top, upper = hb - ht;
+        const double cos_in = lower * g_tw16[i][0] + upper * g_tw16[i][1];
+        const double sin_in = upper * g_tw16[i][0] - lower * g_tw16[i][1];
+        ev[i] = cos_in;
+        od[3 - i] = (i % 2 == 0) ? sin_in : -sin_in;
+    }
+    dct2_len8(in2);
+    dct2_len4(ev);
+    dct2_len4(od);
+    b[0] = in2[0];
+    b[1] = ev[0];
+    b[2] = in2[1];
+    for (int i = 1; i < 4; i++) {
+        const double c = ev[i];
+        const double sv = ((i + 4) % 2 == 0) ? -od[4 - i] : od[4 - i];
+        b[i * 4 - 1] = c + sv;
+        b[i * 4] = in2[i * 2];
+        b[i * 4 + 1] = c - sv;
+        b[i * 4 + 2] = in2[i * 2 + 1];
+    }
+    b[15] = -od[0];
 }
 
 static void dct16_line(double *x, int stride)
 {
-    double out[DCT_SIZE];
-    for (int k = 0; k < DCT_SIZE; k++) {
-        double acc = 0.0;
-        for (int n = 0; n < DCT_SIZE; n++) acc += x[n * stride] * g_cos[k][n];
-        out[k] = acc;
-    }
-    for (int k = 0; k < DCT_SIZE; k++) x[k * stride] = out[k];
+    double b[DCT_SIZE];
+    for (int n = 0; n < DCT_SIZE; n++) b[n] = x[n * stride];
+    dct2_len16(b);
+    for (int k = 0; k < DCT_SIZE; k++) x[k * stride] = b[k];
+}
+
+/* one line, exposed for the tests */
+void vdf_oracle_dct16(double *line)
+{
+    cos_init();
+    dct16_line(line, 1);
 }
 
 /* cube[t][x][y], in place. */

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
                                                C.POINTER(C.c_int16), C.c_int32, C.POINTER(C.c_int32)]
         L.vdf_oracle_dct3d.restype = None
         L.vdf_oracle_dct3d.argtypes = [C.POINTER(C.c_double)]
+        L.vdf_oracle_dct16.restype = None
+        L.vdf_oracle_dct16.argtypes = [C.POINTER(C.c_double)]
         L.vdf_oracle_hash_frames16.restype = C.c_int
         L.vdf_oracle_hash_frames16.argtypes = [u8p, C.c_uint32, u64p, C.POINTER(C.c_double)]
         L.vdf_oracle_hash_clip.restype = C.c_int
@@ -131,6 +133,14 @@ def dct3d(cube: np.ndarray) -> np.ndarray:
     """Unnormalised 3-D DCT-II of a [t][x][y] f64 cube (raw_dct_ops.rs:107-142)."""
     out = np.array(cube, dtype=np.float64, order="C").reshape(DCT_SIZE, DCT_SIZE, DCT_SIZE).copy()
     lib().vdf_oracle_dct3d(_p(out, C.c_double))
+    return out
+
+
+def dct16(line) -> np.ndarray:
+    """One unnormalised 16-point DCT-II by the oracle's split-radix butterfly."""
+    out = np.ascontiguousarray(line, dtype=np.float64).copy()
+    assert out.shape == (DCT_SIZE,)
+    lib().vdf_oracle_dct16(_p(out, C.c_double))
     return out
 
 
@@ -347,12 +357,60 @@ def np_resize_frame(frame: np.ndarray) -> np.ndarray:
     return tmp.astype(np.uint8)
 
 
-def np_hash_frames16(frames16: np.ndarray, want_coefs: bool = False):
-    """[16,16(y),16(x)] u8 -> hash words via scipy's DCT (type 2, unnormalised up to a factor 2 per axis)."""
-    from scipy.fft import dctn
+def _np_twiddle(i: int, fft_len: int):
+    """rustdct::twiddles::single_twiddle(i, fft_len).conj() as (re, im)."""
+    angle = (np.pi * -2.0 / fft_len) * i
+    return float(np.cos(angle)), float(-np.sin(angle))
 
+
+def np_dct2_splitradix(x: np.ndarray) -> np.ndarray:
+    """Unnormalised DCT-II along the LAST axis (length 2, 4, 8 or 16) by rustdct's split-radix recursion
+    (Type2And3SplitRadix / the Type2And3Butterfly{4,8,16} steps derived from it): an independent, vectorised twin of
+    oracle/vdf_oracle.c dct2_len16.  numpy rounds every product and sum separately, as Rust does."""
+    n = x.shape[-1]
+    if n == 1:
+        return x.copy()
+    if n == 2:
+        return np.stack([x[..., 0] + x[..., 1], (x[..., 0] - x[..., 1]) * np.sqrt(0.5)], axis=-1)
+    half, q = n // 2, n // 4
+    in2 = np.empty(x.shape[:-1] + (half,))
+    ev = np.empty(x.shape[:-1] + (q,))
+    od = np.empty(x.shape[:-1] + (q,))
+    for i in range(q):
+        bottom, top, hb, ht = x[..., i], x[..., n - i - 1], x[..., half - i - 1], x[..., half + i]
+        in2[..., i] = top + bottom
+        in2[..., half - i - 1] = hb + ht
+        lower, upper = bottom - top, hb - ht
+        re, im = _np_twiddle(2 * i + 1, 4 * n)
+        ev[..., i] = lower * re + upper * im
+        sin_in = upper * re - lower * im
+        od[..., q - i - 1] = sin_in if i % 2 == 0 else -sin_in
+    o2, oe, oo = np_dct2_splitradix(in2), np_dct2_splitradix(ev), np_dct2_splitradix(od)
+    out = np.empty_like(x)
+    out[..., 0], out[..., 1], out[..., 2] = o2[..., 0], oe[..., 0], o2[..., 1]
+    for i in range(1, q):
+        c = oe[..., i]
+        sv = -oo[..., q - i] if (i + q) % 2 == 0 else oo[..., q - i]
+        out[..., 4 * i - 1] = c + sv
+        out[..., 4 * i] = o2[..., 2 * i]
+        out[..., 4 * i + 1] = c - sv
+        out[..., 4 * i + 2] = o2[..., 2 * i + 1]
+    out[..., n - 1] = -oo[..., 0]
+    return out
+
+
+def np_dct3d(cube: np.ndarray) -> np.ndarray:
+    """[t][x][y] f64 cube -> 3-D DCT-II, passes along y, x, t in the reference's order (raw_dct_ops.rs:118-132)."""
+    d = np_dct2_splitradix(np.ascontiguousarray(cube, dtype=np.float64))                 # y (last axis)
+    d = np.swapaxes(np_dct2_splitradix(np.ascontiguousarray(np.swapaxes(d, 1, 2))), 1, 2)  # x
+    d = np.swapaxes(np_dct2_splitradix(np.ascontiguousarray(np.swapaxes(d, 0, 2))), 0, 2)  # t
+    return d
+
+
+def np_hash_frames16(frames16: np.ndarray, want_coefs: bool = False):
+    """[16,16(y),16(x)] u8 -> hash words via the numpy split-radix twin (bit-identical coefficients to the C oracle)."""
     cube = np.transpose(np.asarray(frames16[:DCT_SIZE], dtype=np.float64), (0, 2, 1)) - 128.0  # [t][x][y]
-    d = dctn(cube, type=2, norm=None) / 8.0
+    d = np_dct3d(cube)
     coefs = d[:HASH_SIZE, :HASH_SIZE, :HASH_SIZE].reshape(-1)
     bits = coefs > 0.0
     words = np.zeros(HASH_WORDS, np.uint64)

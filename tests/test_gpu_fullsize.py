@@ -79,7 +79,8 @@ def test_hundred_thousand_frame_stacks(engine):
     care = np.abs(coefs) >= 1e-6
     gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(64, 1024)[:, :1000]
     wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(64, 1024)[:, :1000]
-    assert not ((gb != wb) & care).any()
+    assert not (gb != wb).any()  # whole words, no don't-care mask: device and oracle run the same operation sequence
+    assert np.array_equal(dc.cpu().numpy()[idx], (~care).sum(axis=1))
     assert int(dc.sum().item()) < n // 100  # near-zero coefficients are rare on iid pixels (~7e-4 of clips)
     # hashes of iid clips are ~uniform: mean popcount close to 500
     pop = np.unpackbits(out1[:2000].cpu().numpy().view(np.uint8), axis=1).sum(axis=1).mean()
@@ -194,6 +195,6 @@ def test_c5_end_to_end_from_frames_single_gpu(engine):
     care = np.abs(coefs) >= 1e-6
     gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(-1, 1024)[:, :1000]
     wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(-1, 1024)[:, :1000]
-    assert not ((gb != wb) & care).any()
+    assert not (gb != wb).any()
     print(f"C5 end to end: {n_cand + n_ref} clips ({(n_cand + n_ref) * 65536 / 1e9:.1f} GB of frames) hashed and "
           f"{n_ref} references searched in {dt * 1e3:.1f} ms wall (first call {dt_first * 1e3:.1f} ms); {len(groups)} groups")

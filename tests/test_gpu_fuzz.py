@@ -106,7 +106,7 @@ def test_hash_fuzz_frame_sizes(seed):
         finally:
             eng.close()
         gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(3, 1024)[:, :1000]
-        assert not ((gb != wb) & care).any(), (mode, h, w)
+        assert not (gb != wb).any(), (mode, h, w)
 
 
 @pytest.mark.parametrize("seed", range(max(10, _SOAK // 20)))
@@ -141,4 +141,4 @@ def test_hash_fuzz_large_frames(seed):
         finally:
             eng.close()
         gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(2, 1024)[:, :1000]
-        assert not ((gb != wb) & care).any(), (mode, h, w)
+        assert not (gb != wb).any(), (mode, h, w)

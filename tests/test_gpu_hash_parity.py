@@ -1,8 +1,10 @@
 """HIP VideoHash construction (through the C ABI) vs the CPU oracle.
 
-Parity rule: device and oracle both compute the DCT in f64; a bit is don't-care iff the
-oracle's |coef| < 1e-6 (unnormalised rustdct scale); every other bit must be identical.  The resize stage
-is integer arithmetic and must be bit-exact, which the 1e-6 rule then carries through the DCT."""
+Device and oracle run the SAME f64 operation sequence (rustdct's split-radix butterflies, products and sums rounded
+separately, identical twiddle constants), and the resize is exact integer arithmetic, so the comparison is on whole hash
+words: no bit is masked.  The don't-care rule of DESIGN.md (|coef| < 1e-6) only describes how far the ORACLE can be
+trusted against the real crate; the device reports the per-clip count of such coefficients and it must equal the
+oracle's count exactly."""
 import numpy as np
 import pytest
 
@@ -21,10 +23,10 @@ def _check(engine, frames):
     want, coefs = orc.hash_clips_with_coefs(frames)
     care = np.abs(coefs) >= TINY
     gb, wb = _bits(got)[:, :1000], _bits(want)[:, :1000]
-    bad = (gb != wb) & care
-    assert not bad.any(), f"{bad.sum()} hash bits differ outside the don't-care set"
+    bad = gb != wb
+    assert not bad.any(), f"{bad.sum()} hash bits differ ({(bad & care).sum()} of them outside the don't-care set)"
     assert (_bits(got)[:, 1000:] == 0).all()  # padding bits stay zero when built from frames
-    assert (dc >= (~care).sum(axis=1) - 1).all() or True
+    assert np.array_equal(dc, (~care).sum(axis=1)), "device don't-care count differs from the oracle's"
     return got, want, care
 
 
@@ -66,16 +68,28 @@ def test_extra_frames_ignored_and_too_few_rejected(engine):
     assert np.array_equal(vh.hash, a[0]) and vh.duration() == 3 and vh.src_path() == "x.mp4"
 
 
-def test_constant_and_extreme_clips_run(engine):
-    """Static clips have every temporal AC coefficient mathematically zero: outside the parity claim,
-    but the DC-plane bits (kt = 0) are well defined and the call must not fail."""
-    frames = np.zeros((2, 16, 64, 64), np.uint8)
-    frames[1] = 255
-    got, dc = engine.hash_frames(frames, want_dontcare=True)
-    want, coefs = orc.hash_clips_with_coefs(frames)
-    care = np.abs(coefs) >= TINY
-    assert not ((_bits(got)[:, :1000] != _bits(want)[:, :1000]) & care).any()
-    assert (dc >= 900).all()
+@pytest.mark.parametrize("h,w", [(16, 16), (64, 64), (90, 160), (270, 480)])
+def test_static_constant_and_symmetric_clips_unmasked(engine, h, w):
+    """The clips whose coefficients are mathematically zero in bulk (slideshows, black frames, mirrored content): under
+    rustdct's butterfly structure those coefficients are exact +-0.0, so the bits are 0 - not rounding noise.
+    Unmasked: identical frames -> every kt >= 1 bit is 0; constant frames -> every AC bit is 0, DC bit = (value > 128);
+    left-right mirrored frames -> every odd-kx bit is 0; and all words equal the oracle's."""
+    rng = np.random.default_rng(h * 77 + w)
+    one = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    half = rng.integers(0, 256, size=(16, h, w // 2), dtype=np.uint8)
+    frames = np.stack([np.broadcast_to(one, (16, h, w)), np.zeros((16, h, w), np.uint8), np.full((16, h, w), 255, np.uint8),
+                       np.full((16, h, w), 128, np.uint8), np.full((16, h, w), 129, np.uint8),
+                       np.concatenate([half, half[:, :, ::-1]], axis=2)]).astype(np.uint8)
+    got, want, care = _check(engine, frames)
+    bits = _bits(got)[:, :1000]
+    kt, kx = np.arange(1000) // 100, (np.arange(1000) // 10) % 10
+    assert not bits[0][kt >= 1].any() and bits[0][:100].any()
+    assert not bits[1].any() and not bits[3].any()            # all-black and mid-grey (pix - 128 <= 0): the empty hash
+    assert bits[2][0] == 1 and not bits[2][1:].any()          # all-white: only the DC bit
+    assert bits[4][0] == 1 and not bits[4][1:].any()
+    small = np.stack([orc.resize_frame(f) for f in frames[5]])
+    if np.array_equal(small, small[:, :, ::-1]):              # the resized frames are still mirror-symmetric
+        assert not bits[5][kx % 2 == 1].any()
 
 
 def test_batch_consistency(engine):

@@ -342,10 +342,24 @@ vdf::ResizeAxisTable dev_view(const DeviceAxisTable *t)
 int ensure_cos_table(vdf_ctx *ctx, hipStream_t stream)
 {
     if (ctx->cos_table.p) return VDF_OK;
-    double tab[16 * 16 + 17];  // [k][n] matrix, then the 17 magnitudes cos(m pi / 32)
+    // [k][n] cosine matrix (kept for reference kernels), then the constants of the split-radix DCT-16 in the order
+    // dct_hash.hip reads them: 4 + 2 + 1 twiddles (cos, sin) and sqrt(1/2).  Computed exactly as rustdct does
+    // (twiddles::single_twiddle(i, len).conj(): angle = (-2 pi / len) * i) so that they equal the oracle's bit for bit.
+    double tab[16 * 16 + 17];
     for (int k = 0; k < 16; k++)
         for (int n = 0; n < 16; n++) tab[k * 16 + n] = std::cos(M_PI * (double)k * ((double)n + 0.5) / 16.0);
-    for (int m = 0; m < 17; m++) tab[256 + m] = std::cos(M_PI * (double)m / 32.0);
+    int at = 256;
+    auto twiddle = [&](int i, int fft_len) {
+        const double angle_constant = M_PI * -2.0 / (double)fft_len;
+        const double angle = angle_constant * (double)i;
+        tab[at++] = std::cos(angle);
+        tab[at++] = -std::sin(angle);
+    };
+    for (int i = 0; i < 4; i++) twiddle(2 * i + 1, 64);
+    for (int i = 0; i < 2; i++) twiddle(2 * i + 1, 32);
+    twiddle(1, 16);
+    tab[at++] = M_SQRT1_2;
+    tab[at++] = 0.0; tab[at++] = 0.0;
     int rc = upload(ctx, ctx->cos_table, tab, sizeof tab, stream);
     if (rc) return rc;
     VDF_HIP(ctx, hipStreamSynchronize(stream));

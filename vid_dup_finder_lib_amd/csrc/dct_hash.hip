@@ -72,51 +72,79 @@ __global__ __launch_bounds__(256) void resize_generic_kernel(
     }
 }
 
-// 16-point unnormalised DCT-II pruned to outputs 0..9:  X[k] = sum_n v[n] cos(pi k (2n + 1) / 32).
-// One even/odd split: cos(pi k (2(15-n)+1)/32) = (-1)^k cos(pi k (2n+1)/32).  Every matrix entry is
-// +-cos(m pi / 32) for m = 0..16, so the kernel keeps just those 17 magnitudes (wave-uniform, SGPR pairs)
-// and folds the sign into the FMA's negate modifier at compile time; 80 distinct SGPR-pair constants
-// would not fit the scalar register file.
-struct CosRef { int m; int sign; };
-__device__ constexpr CosRef cos_ref(int k, int n)
+// 16-point unnormalised DCT-II,  X[k] = sum_n v[n] cos(pi k (2n + 1) / 32),  outputs 0..9.
+// Only the SIGN of a coefficient is consumed (dct_3d.rs:55-62), so the order of the floating-point operations decides the
+// bit wherever the coefficient is mathematically zero - and that is not exotic: every temporal AC coefficient of a static
+// clip, every AC coefficient of a black frame, every odd coefficient of a mirror-symmetric line.  rustdct 0.7's
+// plan_dct2(16) is Type2And3Butterfly16: split-radix steps (16 -> 8 + 4 + 4, 8 -> 4 + 2 + 2, 4 -> 2 + 1 + 1) in which
+// even outputs come from the sums v[n] + v[N-1-n] and odd outputs from the differences v[n] - v[N-1-n] rotated by
+// e^{i pi (2n+1) / 2N}; a constant or symmetric line then yields exact +-0.0 there (bit 0).  This is the same operation
+// sequence as oracle/vdf_oracle.c dct2_len16, with every product and sum rounded separately like Rust does
+// (contraction off), so the coefficients - not just their signs - are bit-identical to the oracle's.
+// The 15 constants (twiddles + sqrt(1/2)) are wave-uniform and live in SGPR pairs; unused outputs fall to dead-code elimination.
+#pragma clang fp contract(off)
+struct DctTw {
+    double t16[4][2], t8[2][2], t4[2], h;  // (cos, sin) of pi (2 i + 1) / (2 N); h = sqrt(1/2)
+};
+
+__device__ __forceinline__ void dct2_len2(double &a, double &b, const DctTw &T)
 {
-    int a = (k * (2 * n + 1)) % 64;  // angle in units of pi/32, period 64
-    int sign = 1;
-    if (a > 32) a = 64 - a;          // cos(2 pi - x) = cos x
-    if (a > 16) { a = 32 - a; sign = -1; }  // cos(pi - x) = -cos x
-    return CosRef{a, sign};
+    const double sum = a + b;
+    b = (a - b) * T.h;
+    a = sum;
 }
 
-template <int K, int N>
-__device__ __forceinline__ double dct_term(double x, const double (&cm)[17], double acc)
+__device__ __forceinline__ void dct2_len4(double (&b)[4], const DctTw &T)
 {
-    constexpr CosRef r = cos_ref(K, N);
-    if constexpr (r.m == 16) return acc;  // cos(pi/2) = 0
-    else if constexpr (r.sign > 0) return fma(x, cm[r.m], acc);
-    else return fma(-x, cm[r.m], acc);
+    double i0 = b[3] + b[0], i1 = b[1] + b[2];
+    const double lower = b[0] - b[3], upper = b[1] - b[2];
+    const double cos_in = lower * T.t4[0] + upper * T.t4[1];
+    const double sin_in = upper * T.t4[0] - lower * T.t4[1];
+    dct2_len2(i0, i1, T);
+    b[0] = i0; b[1] = cos_in; b[2] = i1; b[3] = -sin_in;
 }
 
-template <int K>
-__device__ __forceinline__ double dct_out(const double (&u)[8], const double (&d)[8], const double (&cm)[17])
+__device__ __forceinline__ void dct2_len8(double (&b)[8], const DctTw &T)
 {
-    const double (&x)[8] = (K & 1) ? d : u;
-    double acc = 0.0;
-    acc = dct_term<K, 0>(x[0], cm, acc); acc = dct_term<K, 1>(x[1], cm, acc);
-    acc = dct_term<K, 2>(x[2], cm, acc); acc = dct_term<K, 3>(x[3], cm, acc);
-    acc = dct_term<K, 4>(x[4], cm, acc); acc = dct_term<K, 5>(x[5], cm, acc);
-    acc = dct_term<K, 6>(x[6], cm, acc); acc = dct_term<K, 7>(x[7], cm, acc);
-    return acc;
-}
-
-__device__ __forceinline__ void dct16_pruned(const double (&v)[16], double (&out)[10], const double (&cm)[17])
-{
-    double u[8], d[8];
+    double in2[4], ev[2], od[2];
 #pragma unroll
-    for (int n = 0; n < 8; n++) { u[n] = v[n] + v[15 - n]; d[n] = v[n] - v[15 - n]; }
-    out[0] = dct_out<0>(u, d, cm); out[1] = dct_out<1>(u, d, cm); out[2] = dct_out<2>(u, d, cm);
-    out[3] = dct_out<3>(u, d, cm); out[4] = dct_out<4>(u, d, cm); out[5] = dct_out<5>(u, d, cm);
-    out[6] = dct_out<6>(u, d, cm); out[7] = dct_out<7>(u, d, cm); out[8] = dct_out<8>(u, d, cm);
-    out[9] = dct_out<9>(u, d, cm);
+    for (int i = 0; i < 2; i++) {
+        const double bottom = b[i], top = b[7 - i], hb = b[3 - i], ht = b[4 + i];
+        in2[i] = top + bottom;
+        in2[3 - i] = hb + ht;
+        const double lower = bottom - top, upper = hb - ht;
+        ev[i] = lower * T.t8[i][0] + upper * T.t8[i][1];
+        const double sin_in = upper * T.t8[i][0] - lower * T.t8[i][1];
+        od[1 - i] = (i % 2 == 0) ? sin_in : -sin_in;
+    }
+    dct2_len4(in2, T);
+    dct2_len2(ev[0], ev[1], T);
+    dct2_len2(od[0], od[1], T);
+    b[0] = in2[0]; b[1] = ev[0]; b[2] = in2[1];
+    b[3] = ev[1] + od[1]; b[4] = in2[2]; b[5] = ev[1] - od[1]; b[6] = in2[3];
+    b[7] = -od[0];
+}
+
+__device__ __forceinline__ void dct16_pruned(const double (&v)[16], double (&out)[10], const DctTw &T)
+{
+    double in2[8], ev[4], od[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double bottom = v[i], top = v[15 - i], hb = v[7 - i], ht = v[8 + i];
+        in2[i] = top + bottom;
+        in2[7 - i] = hb + ht;
+        const double lower = bottom - top, upper = hb - ht;
+        ev[i] = lower * T.t16[i][0] + upper * T.t16[i][1];
+        const double sin_in = upper * T.t16[i][0] - lower * T.t16[i][1];
+        od[3 - i] = (i % 2 == 0) ? sin_in : -sin_in;
+    }
+    dct2_len8(in2, T);
+    dct2_len4(ev, T);
+    dct2_len4(od, T);
+    out[0] = in2[0]; out[1] = ev[0]; out[2] = in2[1];
+    // i = 1: (i + 4) odd -> +od[3];  i = 2: (i + 4) even -> -od[2]
+    out[3] = ev[1] + od[3]; out[4] = in2[2]; out[5] = ev[1] - od[3]; out[6] = in2[3];
+    out[7] = ev[2] + (-od[2]); out[8] = in2[4]; out[9] = ev[2] - (-od[2]);
 }
 
 constexpr int kPadY = 17;  // [t][kx][y] rows padded to 17 doubles
@@ -138,9 +166,12 @@ __device__ __forceinline__ void dct_hash_block(DctShared &sh, const_f64_ptr cosv
                                                uint64_t *__restrict__ out_hashes, uint32_t *__restrict__ out_dontcare)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double cm[17];  // cos(m pi / 32), wave-uniform (scalar loads)
+    DctTw cm;  // wave-uniform constants (scalar loads): cos_table[256 ..] = t16, t8, t4, h in this order
 #pragma unroll
-    for (int m = 0; m < 17; m++) cm[m] = cosv[256 + m];
+    for (int i = 0; i < 4; i++) { cm.t16[i][0] = cosv[256 + 2 * i]; cm.t16[i][1] = cosv[257 + 2 * i]; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { cm.t8[i][0] = cosv[264 + 2 * i]; cm.t8[i][1] = cosv[265 + 2 * i]; }
+    cm.t4[0] = cosv[268]; cm.t4[1] = cosv[269]; cm.h = cosv[270];
     // pass y: thread (t, x) owns one 16-pixel column
     {
         const uint32_t t = tid >> 4, x = tid & 15;
