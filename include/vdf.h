@@ -19,9 +19,14 @@
  *     into the arrays the caller passed.
  *   - Functions with the suffix _device take DEVICE pointers (HIP allocations on the
  *     context's GPU) and a hipStream_t passed as void* (NULL = the context's own non-blocking
- *     stream, NOT the legacy default stream); everything else takes host pointers.
- *   - A context is bound to one GPU.  Multi-GPU runs use one process (and one context) per
- *     GPU; see DESIGN.md "Multi-GPU".
+ *     stream, NOT the legacy default stream) and need a single-device context; everything else
+ *     takes host pointers (or, *_shards, one device pointer per GPU of a multi-GPU context).
+ *   - The search calls need their (candidate) arrays in sorted order and return VDF_E_INVAL when the
+ *     durations are not ascending.
+ *   - vdf_ctx_create() binds a context to one GPU.  vdf_ctx_create_multi() makes ONE context over several GPUs of
+ *     the node (one host thread and one stream per device inside the library): the host-array calls
+ *     (vdf_search_self, vdf_search_refs, vdf_hash_frames_u8[_letterbox]) then fan out by themselves, and the
+ *     *_shards calls take data that is already resident on the devices.  See DESIGN.md "Multi-GPU".
  *   - Thread safety: a context serialises its own calls with an internal mutex, so
  *     vdf_hash_frames_u8 may be called from many threads (the app hashes from rayon workers,
  *     vid_dup_finder_app/src/video_hash_filesystem_cache/video_hash_filesystem_cache.rs:246).
@@ -49,7 +54,8 @@ typedef enum vdf_status {
     VDF_E_HIP = -3,               /* HIP runtime failure or no usable GPU */
     VDF_E_OOM = -4,
     VDF_E_INVAL = -5,
-    VDF_E_OVERFLOW = -6           /* a caller-provided hit buffer was too small */
+    VDF_E_OVERFLOW = -6,          /* a caller-provided hit buffer was too small */
+    VDF_E_RCCL = -7               /* librccl could not be loaded, or a collective failed (multi-GPU contexts only) */
 } vdf_status;
 
 typedef struct vdf_ctx vdf_ctx;
@@ -88,6 +94,19 @@ typedef struct vdf_search_stats {
 
 /* ---- context ------------------------------------------------------------------------------ */
 int vdf_ctx_create(int device_id, vdf_ctx **out);
+/* One context over n_devices GPUs of this node: the single search() / search_with_references() call of the crate
+ * (src/video_hashing/video_dup_finder.rs:7-13,19-46, called once per run from vid_dup_finder_app/src/app/app_fns.rs:
+ * 478-482) then uses all of them.  Inside: one host thread + stream per device; the sorted database is replicated on every
+ * device (from the caller's host arrays directly, or - *_shards calls - by an RCCL all-gather over xGMI), row tiles of the
+ * triangle are dealt round-robin, the host merges the hits and replays the greedy grouping once, so the MatchGroups are
+ * identical for every device count.  A device may be listed more than once (testing on one GPU): its slots then share
+ * the GPU and the collective is replaced by device-to-device copies. */
+int vdf_ctx_create_multi(const int *device_ids, int n_devices, vdf_ctx **out);
+int vdf_ctx_device_count(const vdf_ctx *ctx);        /* 1 for vdf_ctx_create */
+int vdf_ctx_device_at(const vdf_ctx *ctx, int slot); /* HIP device id of a slot, -1 if out of range */
+/* Per-device statistics of the last search on a multi-GPU context (vdf_ctx_last_search_stats gives the sums, with
+ * kernel_ms = the slowest device's). */
+int vdf_ctx_device_search_stats(const vdf_ctx *ctx, int slot, vdf_search_stats *out);
 void vdf_ctx_destroy(vdf_ctx *ctx);
 const char *vdf_last_error(const vdf_ctx *ctx); /* ctx may be NULL: last ctx_create failure */
 const char *vdf_version(void);
@@ -203,6 +222,29 @@ int vdf_replay_self(size_t n, const vdf_hit *hits, uint64_t n_hits, uint32_t row
 int vdf_groups_finish_self(vdf_groups *g);
 /* Groups for search_with_references from hits sorted by (row, col). */
 int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
+
+/* ---- multi-GPU contexts: data already resident on the devices -------------------------------------------------
+ * Array arguments have one entry per slot of the context (vdf_ctx_device_count()); pointer k is a DEVICE pointer on
+ * the GPU of slot k.  The caller's work that produced the buffers must be complete (the library runs on its own
+ * streams).  Results are identical to the single-device calls on the concatenated arrays.
+ *
+ * vdf_search_self_shards: the sorted database (Search::sort order, search_algorithm.rs:55-61) cut into consecutive
+ *   shards, shard k on device k (sizes may differ, may be 0).  One all-gather of the hashes ((n / G) x 16 x u64 per
+ *   device) and one of the durations replicate it - ncclAllGather over xGMI when the shards are equal, the same
+ *   exchange as grouped ncclBroadcasts otherwise - then as vdf_search_self.  RCCL failures -> VDF_E_RCCL.
+ * vdf_search_refs_shards: candidates sharded and gathered the same way; the references are the concatenation of the
+ *   per-device reference shards (group ref_index = position in that concatenation); device k searches its own.
+ * vdf_hash_frames_u8_shards: every device hashes its own clips (independent: no communication);
+ *   d_out_dontcare may be NULL (or hold NULLs). */
+int vdf_search_self_shards(vdf_ctx *ctx, const uint64_t *const *d_hash_shards, const uint32_t *const *d_dur_shards,
+                           const size_t *shard_n, uint32_t tol_int, vdf_groups *out);
+int vdf_search_refs_shards(vdf_ctx *ctx, const uint64_t *const *d_cand_hash_shards, const uint32_t *const *d_cand_dur_shards,
+                           const size_t *cand_shard_n, const uint64_t *const *d_ref_hash_shards,
+                           const uint32_t *const *d_ref_dur_shards, const size_t *ref_shard_n, uint32_t tol_int,
+                           vdf_groups *out);
+int vdf_hash_frames_u8_shards(vdf_ctx *ctx, const uint8_t *const *d_frames, const size_t *n_clips, uint32_t frames_per_clip,
+                              uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *const *d_out_hashes,
+                              uint32_t *const *d_out_dontcare);
 
 /* ---- batching queue for concurrent per-file callers ------------------------------------------------
  * The app hashes one file per rayon worker (vid_dup_finder_app/src/video_hash_filesystem_cache/

@@ -20,6 +20,7 @@ VDF_E_HIP = -3
 VDF_E_OOM = -4
 VDF_E_INVAL = -5
 VDF_E_OVERFLOW = -6
+VDF_E_RCCL = -7
 
 DCT_SIZE = 16
 HASH_SIZE = 10
@@ -73,6 +74,10 @@ _ctx = C.c_void_p
 # name -> (restype, argtypes).  Keep in step with include/vdf.h; tests/test_capi_symbols.py checks both ways.
 SIGNATURES = {
     "vdf_ctx_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "vdf_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]),
+    "vdf_ctx_device_count": (C.c_int, [_ctx]),
+    "vdf_ctx_device_at": (C.c_int, [_ctx, C.c_int]),
+    "vdf_ctx_device_search_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(VdfSearchStats)]),
     "vdf_ctx_destroy": (None, [_ctx]),
     "vdf_last_error": (C.c_char_p, [_ctx]),
     "vdf_version": (C.c_char_p, []),
@@ -107,6 +112,14 @@ SIGNATURES = {
     "vdf_search_refs_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.c_void_p]),
+    "vdf_search_self_shards": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.c_uint32, C.POINTER(VdfGroups)]),
+    "vdf_search_refs_shards": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32,
+                                         C.POINTER(VdfGroups)]),
+    "vdf_hash_frames_u8_shards": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_void_p)]),
     "vdf_row_tile_size": (C.c_uint32, []),
     "vdf_replay_self": (C.c_int, [C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.POINTER(VdfGroups)]),

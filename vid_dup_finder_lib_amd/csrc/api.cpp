@@ -7,97 +7,44 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include <numeric>
-#include <string>
-#include <vector>
 
-#include "resize_tables.h"
-#include "vdf_internal.h"
+#include "vdf_ctx.h"
 
 namespace {
-
 thread_local std::string g_create_error;
+}
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { p = nullptr; return e; }
-        cap = want;
-        return hipSuccess;
+vdf_ctx::~vdf_ctx()
+{
+    if (!subs.empty() || !workers.empty()) vdf_impl::destroy_multi(this);
+    if (copy_pool) vdf_impl::destroy_copy_pool(this);
+    for (auto &kv : axis_tables) {
+        kv.second->start.release(); kv.second->size.release(); kv.second->w.release();
+        delete kv.second;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct DeviceAxisTable {
-    DevBuf start, size, w;
-    vdf::HostAxisTable host;
-};
-
-struct DeviceMfmaTable {
-    DevBuf operand, bias;
-    vdf::MfmaAxisTable host;
-};
-
-}  // namespace
-
-struct vdf_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::mutex mu;
-    std::string err;
-    uint64_t hit_capacity = 1ull << 24;
-    vdf_search_stats stats{};
-    uint32_t tile_rows = 256 * vdf::kDefaultRowsPerLane;
-    uint32_t chunk_cols = vdf::kDefaultChunkCols;
-    // search scratch
-    DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
-    DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
-    // hash scratch
-    DevBuf small, frames, out_hashes, out_dc, cos_table, crops, crop_desc, crop_tables;
-    std::map<uint32_t, DeviceAxisTable *> axis_tables;
-    std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
-    int hash_no_persistent = 0, hash_wgs_per_cu = 3;
-    uint32_t mfma_chunk_cols = 0, mfma_group = 8192;  // 0 = pick the chunk width per search (search_core); VDF_MFMA_CHUNK_COLS overrides
-    DevBuf group_cmin, group_offset, group_blocks;
-    uint32_t mfma_xcd_stripe = 0;
-    uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
-    int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
-    int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
-    DevBuf exp_cols, exp_rows;
-    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
-    std::vector<vdf_hit> host_hits;
-
-    ~vdf_ctx()
-    {
-        for (auto &kv : axis_tables) {
-            kv.second->start.release(); kv.second->size.release(); kv.second->w.release();
-            delete kv.second;
-        }
-        for (auto &kv : mfma_tables) {
-            kv.second->operand.release(); kv.second->bias.release();
-            delete kv.second;
-        }
-        DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
-                         &hits, &perm, &matched, &exp_cols, &exp_rows, &group_cmin, &group_offset, &group_blocks, &up_hashes, &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames,
-                         &out_hashes, &out_dc, &cos_table, &crops, &crop_desc, &crop_tables};
-        for (DevBuf *b : all) b->release();
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+    for (auto &kv : mfma_tables) {
+        kv.second->operand.release(); kv.second->bias.release();
+        delete kv.second;
     }
-};
+    DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
+                     &hits, &perm, &matched, &exp_cols, &exp_rows, &group_cmin, &group_offset, &group_blocks, &up_hashes,
+                     &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables};
+    for (DevBuf *b : all) b->release();
+    for (PinBuf &b : pin) b.release();
+    for (PinBuf &b : pin_out) b.release();
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (stream) (void)hipStreamDestroy(stream);
+}
 
-namespace {
+namespace vdf_impl {
+
+void set_create_error(const std::string &msg) { g_create_error = msg; }
 
 int fail(vdf_ctx *ctx, int code, const std::string &msg)
 {
@@ -112,13 +59,12 @@ int fail_hip(vdf_ctx *ctx, hipError_t e, const char *what)
     return fail(ctx, e == hipErrorOutOfMemory ? VDF_E_OOM : VDF_E_HIP, msg);
 }
 
-#define VDF_HIP(ctx, call)                                           \
-    do {                                                             \
-        hipError_t e__ = (call);                                     \
-        if (e__ != hipSuccess) return fail_hip((ctx), e__, #call);   \
-    } while (0)
-
-bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; }
+bool is_sorted_u32(const uint32_t *d, size_t n)
+{
+    for (size_t i = 1; i < n; i++)
+        if (d[i] < d[i - 1]) return false;
+    return true;
+}
 
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
@@ -199,8 +145,10 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     if (mfma) L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 13 ? L.prune_step : 16;
     else L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 10 ? 10 : L.prune_step <= 12 ? 12 : 16;
     if (mfma) {
+#ifdef VDF_BENCH_ABLATE  // timing-experiment builds only (tools/sweep_ablate.sh): the ablated kernels report no hits
         if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
         if (L.ablate) L.prune_step = 16;
+#endif
         L.xcd_stripe = ctx->mfma_xcd_stripe;
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
@@ -231,9 +179,13 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
                                            row_begin, row_end, shard_index, shard_count, L, stream));
     uint32_t total_tiles = 0;
+    unsigned long long unsorted = 0;
     VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
                                 hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipMemcpyAsync(&unsorted, L.counters + 5, 8, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
+    // the windows are binary searches over the candidate durations (search_algorithm.rs:93-117,173-185 rely on Search::sort)
+    if (unsorted) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
 
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
@@ -560,30 +512,58 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
                                d_out, d_dc, stream);
 }
 
-}  // namespace
 
-extern "C" {
-
-int vdf_ctx_create(int device_id, vdf_ctx **out)
+int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
+                                     size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
+                                     size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
+                                     uint64_t capacity, uint64_t *n_hits, hipStream_t s)
 {
-    if (!out) return VDF_E_INVAL;
+    ctx->stats = vdf_search_stats{};
+    *n_hits = 0;
+    if (n_ref == 0 || n_cand == 0) return VDF_OK;
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    // References arrive in the caller's order; tiles want neighbouring rows to share a duration window, so
+    // rows are visited through a stable duration-sorted permutation (reported indices stay the caller's).
+    std::vector<uint32_t> rdur(n_ref), perm(n_ref);
+    VDF_HIP(ctx, hipMemcpyAsync(rdur.data(), d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
+    VDF_HIP(ctx, hipStreamSynchronize(s));
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rdur[a] < rdur[b]; });
+    int rc = upload(ctx, ctx->perm, perm.data(), n_ref * 4, s);
+    if (rc) return rc;
+    uint32_t overflow_row = 0;
+    rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
+                     ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
+                     capacity, n_hits, &overflow_row, s);
+    if (rc) return rc;
+    if (*n_hits > capacity) return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size");
+    return VDF_OK;
+}
+
+
+int create_single(int device_id, vdf_ctx **out, std::string *err)
+{
     *out = nullptr;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
-        g_create_error = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+        *err = std::string("no usable HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0");
         (void)hipGetLastError();
         return VDF_E_HIP;
     }
-    if (device_id < 0 || device_id >= count) { g_create_error = "device id out of range"; return VDF_E_INVAL; }
+    if (device_id < 0 || device_id >= count) { *err = "device id out of range"; return VDF_E_INVAL; }
     vdf_ctx *ctx = new (std::nothrow) vdf_ctx();
     if (!ctx) return VDF_E_OOM;
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+    for (int i = 0; ok && i < 2; i++)
+        ok = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
-        g_create_error = std::string("context setup failed: ") + hipGetErrorString(hipGetLastError());
+        *err = std::string("context setup failed: ") + hipGetErrorString(hipGetLastError());
         delete ctx;
         return VDF_E_HIP;
     }
@@ -623,12 +603,176 @@ int vdf_ctx_create(int device_id, vdf_ctx **out)
     return VDF_OK;
 }
 
+// search() over a sorted database that is already resident on EVERY device of the context (each device's
+// up_hashes / up_dur): row tiles are dealt round-robin over the devices (tile t -> device t % G), every device emits
+// the thresholded pairs of its tiles, the host merges them and replays search_self's consumption ONCE
+// (search_algorithm.rs:131-170) -> the same MatchGroups for every G.  Hit-buffer overflow: rows below the smallest
+// row that lost a hit on any device are complete and are replayed; the consumption bitmap goes back to every device and
+// the search resumes from that row.
+int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *out)
+{
+    const int G = device_count(ctx);
+    uint64_t capacity = ctx->hit_capacity;
+    std::vector<uint8_t> matched(n, 0);
+    std::vector<uint32_t> bitmap;  // 1 bit per entry, built on the first overflow, then updated with the new members only
+    bool use_bitmap = false;
+    std::vector<vdf_hit> merged;
+    uint32_t row_begin = 0;
+    uint64_t span = n;  // rows per launch; shrinks after an overflow, grows back afterwards
+    ctx->stats = vdf_search_stats{};
+    for (int k = 0; k < G; k++) device_ctx(ctx, k)->stats = vdf_search_stats{};
+    while (row_begin < n) {
+        const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
+        int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
+            if (d->host_hits.size() < capacity) d->host_hits.resize(capacity);
+            return search_core(d, 0, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n, d->up_hashes.as<uint64_t>(),
+                               d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
+                               use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, d->host_hits.data(), capacity,
+                               &d->r_n_hits, &d->r_overflow, d->stream);
+        });
+        if (rc) { vdf_groups_free(out); return rc; }
+        uint32_t overflow_row = 0xFFFFFFFFu;
+        for (int k = 0; k < G; k++) overflow_row = std::min(overflow_row, device_ctx(ctx, k)->r_overflow);
+        const uint32_t complete_end = std::min(overflow_row, row_end);
+        const vdf_hit *hp;
+        uint64_t nh;
+        if (G == 1) {
+            hp = device_ctx(ctx, 0)->host_hits.data();
+            nh = std::min(device_ctx(ctx, 0)->r_n_hits, capacity);
+        } else {  // every device's list is sorted by (row, col) and the devices own disjoint rows
+            merged.clear();
+            for (int k = 0; k < G; k++) {
+                const vdf_ctx *d = device_ctx(ctx, k);
+                const vdf_hit *b = d->host_hits.data(), *e = b + std::min(d->r_n_hits, capacity);
+                e = std::lower_bound(b, e, vdf_hit{complete_end, 0u}, hit_less);  // rows >= complete_end are searched again
+                const size_t mid = merged.size();
+                merged.insert(merged.end(), b, e);
+                std::inplace_merge(merged.begin(), merged.begin() + (ptrdiff_t)mid, merged.end(), hit_less);
+            }
+            hp = merged.data();
+            nh = merged.size();
+        }
+        const uint64_t old_members = out->n_groups ? out->offsets[out->n_groups] : 0;
+        rc = vdf_replay_self(n, hp, nh, row_begin, complete_end, matched.data(), out);
+        if (rc) { vdf_groups_free(out); return fail(ctx, rc, "replay failed"); }
+        if (overflow_row == 0xFFFFFFFFu) {
+            row_begin = row_end;
+            span = std::min<uint64_t>(n, span * 4);
+        } else {
+            const uint64_t progress = complete_end - row_begin;
+            if (progress == 0) {
+                // Not even one row fit: give a single row the whole buffer (its hits are < n).
+                span = 1;
+                if (capacity < n) capacity = n;
+            } else {
+                span = std::max<uint64_t>(progress * 2, device_ctx(ctx, 0)->tile_rows);
+            }
+            row_begin = complete_end;
+        }
+        if (row_begin < n) {  // feed the consumption state back to the devices
+            if (!use_bitmap) {
+                bitmap.assign((n + 31) / 32, 0u);
+                for (size_t i = 0; i < n; i++)
+                    if (matched[i]) bitmap[i >> 5] |= 1u << (i & 31);
+                use_bitmap = true;
+            } else {  // entries consumed by this round = the members of the groups it appended
+                const uint64_t new_members = out->n_groups ? out->offsets[out->n_groups] : 0;
+                for (uint64_t q = old_members; q < new_members; q++) {
+                    const uint64_t i = out->members[q];
+                    bitmap[i >> 5] |= 1u << (i & 31);
+                }
+            }
+            rc = for_each_device(ctx, [&](int, vdf_ctx *d) {
+                int r = upload(d, d->matched, bitmap.data(), bitmap.size() * 4, d->stream);
+                if (r) return r;
+                VDF_HIP(d, hipStreamSynchronize(d->stream));  // `bitmap` is rewritten by the next round
+                return (int)VDF_OK;
+            });
+            if (rc) { vdf_groups_free(out); return rc; }
+        }
+    }
+    // statistics: sums over the devices; kernel time = the slowest device's
+    ctx->dev_stats.assign((size_t)G, vdf_search_stats{});
+    vdf_search_stats agg{};
+    for (int k = 0; k < G; k++) {
+        const vdf_search_stats &st = device_ctx(ctx, k)->stats;
+        ctx->dev_stats[(size_t)k] = st;
+        agg.pairs += st.pairs; agg.pairs_computed += st.pairs_computed; agg.n_hits += st.n_hits; agg.n_tiles += st.n_tiles;
+        agg.pairs_early_exit += st.pairs_early_exit;
+        agg.n_launches = std::max(agg.n_launches, st.n_launches);
+        agg.kernel_ms = std::max(agg.kernel_ms, st.kernel_ms);
+        agg.early_exit_bits = st.early_exit_bits;
+    }
+    ctx->stats = agg;
+    return vdf_groups_finish_self(out);
+}
+
+// search_with_references() with the sorted candidates resident on every device (up_hashes / up_dur) and device k holding
+// the references [ref_base[k], ref_base[k] + ref_cnt[k]) of the caller's order in up_ref_hashes / up_ref_dur: every
+// device searches its slice; per-device hit lists concatenate in device order = reference input order.
+int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> &ref_cnt, const std::vector<size_t> &ref_base,
+                         uint32_t tol_int, vdf_groups *out)
+{
+    const int G = device_count(ctx);
+    const uint64_t capacity0 = ctx->hit_capacity;
+    int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
+        d->r_n_hits = 0;
+        d->stats = vdf_search_stats{};
+        if (ref_cnt[(size_t)k] == 0) return (int)VDF_OK;
+        uint64_t capacity = capacity0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (d->host_hits.size() < capacity) d->host_hits.resize(capacity);
+            int r = search_refs_device_locked(d, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n_cand,
+                                              d->up_ref_hashes.as<uint64_t>(), d->up_ref_dur.as<uint32_t>(),
+                                              ref_cnt[(size_t)k], tol_int, (uint32_t)ref_base[(size_t)k], d->host_hits.data(),
+                                              capacity, &d->r_n_hits, d->stream);
+            if (r == VDF_E_OVERFLOW && attempt == 0) { capacity = d->r_n_hits; continue; }  // every hit is output: size exactly
+            return r;
+        }
+        return (int)VDF_E_OVERFLOW;
+    });
+    if (rc) return rc;
+    ctx->dev_stats.assign((size_t)G, vdf_search_stats{});
+    vdf_search_stats agg{};
+    for (int k = 0; k < G; k++) {
+        const vdf_search_stats &st = device_ctx(ctx, k)->stats;
+        ctx->dev_stats[(size_t)k] = st;
+        agg.pairs += st.pairs; agg.pairs_computed += st.pairs_computed; agg.n_hits += st.n_hits; agg.n_tiles += st.n_tiles;
+        agg.pairs_early_exit += st.pairs_early_exit;
+        agg.n_launches = std::max(agg.n_launches, st.n_launches);
+        agg.kernel_ms = std::max(agg.kernel_ms, st.kernel_ms);
+        agg.early_exit_bits = st.early_exit_bits;
+    }
+    ctx->stats = agg;
+    if (G == 1) return vdf_groups_from_ref_hits(device_ctx(ctx, 0)->host_hits.data(), device_ctx(ctx, 0)->r_n_hits, out);
+    std::vector<vdf_hit> all;
+    for (int k = 0; k < G; k++) {
+        const vdf_ctx *d = device_ctx(ctx, k);
+        all.insert(all.end(), d->host_hits.data(), d->host_hits.data() + d->r_n_hits);
+    }
+    return vdf_groups_from_ref_hits(all.data(), all.size(), out);
+}
+
+}  // namespace vdf_impl
+
+using namespace vdf_impl;
+
+extern "C" {
+
+int vdf_ctx_create(int device_id, vdf_ctx **out)
+{
+    if (!out) return VDF_E_INVAL;
+    return create_single(device_id, out, &g_create_error);
+}
+
 void vdf_ctx_destroy(vdf_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
-    delete ctx;
+    if (ctx->subs.empty()) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+    }
+    delete ctx;  // a multi-GPU parent joins its workers and destroys its sub-contexts (multi.cpp)
 }
 
 const char *vdf_last_error(const vdf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -651,20 +795,28 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
 
 uint32_t vdf_row_tile_size(void) { return vdf::kMfmaRowPad; }  // MFMA backend (default); the VALU backend uses 256 x rows-per-lane
 
+#define VDF_SINGLE_DEVICE_ONLY(ctx)                                                                                   \
+    if (!(ctx)->subs.empty())                                                                                         \
+        return fail((ctx), VDF_E_INVAL, "device-pointer entry points take a single-device context; a multi-GPU context " \
+                                        "offers the host-array calls and the *_shards calls")
+
 int vdf_hash_frames_u8_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                               uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out_hashes,
                               uint32_t *d_out_dontcare, void *stream)
 {
     if (!ctx) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_out_hashes,
                               d_out_dontcare, s);
 }
 
-int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
-                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
-                       uint32_t *out_dontcare)
+// Host frames -> hashes.  On a multi-GPU context the clips are split contiguously over the devices (clips are
+// independent: no communication); every device stages and hashes its share on its own host thread.
+static int hash_host_entry(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                           uint32_t h, size_t frame_stride, size_t clip_stride, int letterbox, uint64_t *out_hashes,
+                           uint32_t *out_crops, uint32_t *out_dontcare)
 {
     if (!ctx) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -673,34 +825,31 @@ int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint
     if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
     if (n_clips == 0) return VDF_OK;
     if (!frames || !out_hashes) return fail(ctx, VDF_E_INVAL, "null pointer");
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    // Only the first 16 frames of a clip travel to the device, packed tightly; batches bound the staging buffer.
-    const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
-    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, (512ull << 20) / cbytes));
-    VDF_HIP(ctx, ctx->frames.reserve(batch * cbytes));
-    VDF_HIP(ctx, ctx->out_hashes.reserve(batch * VDF_HASH_WORDS * 8));
-    VDF_HIP(ctx, ctx->out_dc.reserve(batch * 4));
-    for (size_t c0 = 0; c0 < n_clips; c0 += batch) {
-        const size_t nb = std::min(batch, n_clips - c0);
-        if (frame_stride == fbytes && clip_stride == cbytes) {
-            VDF_HIP(ctx, hipMemcpyAsync(ctx->frames.p, frames + c0 * clip_stride, nb * cbytes, hipMemcpyHostToDevice, s));
-        } else {
-            for (size_t c = 0; c < nb; c++)
-                VDF_HIP(ctx, hipMemcpy2DAsync(ctx->frames.as<uint8_t>() + c * cbytes, fbytes,
-                                              frames + (c0 + c) * clip_stride, frame_stride, fbytes, VDF_DCT_SIZE,
-                                              hipMemcpyHostToDevice, s));
-        }
-        int rc = hash_device_locked(ctx, ctx->frames.as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
-                                    ctx->out_hashes.as<uint64_t>(), out_dontcare ? ctx->out_dc.as<uint32_t>() : nullptr, s);
-        if (rc) return rc;
-        VDF_HIP(ctx, hipMemcpyAsync(out_hashes + c0 * VDF_HASH_WORDS, ctx->out_hashes.p, nb * VDF_HASH_WORDS * 8,
-                                    hipMemcpyDeviceToHost, s));
-        if (out_dontcare)
-            VDF_HIP(ctx, hipMemcpyAsync(out_dontcare + c0, ctx->out_dc.p, nb * 4, hipMemcpyDeviceToHost, s));
-        VDF_HIP(ctx, hipStreamSynchronize(s));
-    }
-    return VDF_OK;
+    const int G = device_count(ctx);
+    return for_each_device(ctx, [&](int k, vdf_ctx *d) {
+        const size_t base = n_clips / (size_t)G, rem = n_clips % (size_t)G;
+        const size_t lo = (size_t)k * base + std::min<size_t>((size_t)k, rem), cnt = base + ((size_t)k < rem ? 1 : 0);
+        if (cnt == 0) return (int)VDF_OK;
+        return hash_host_locked(d, frames + lo * clip_stride, cnt, w, h, frame_stride, clip_stride, letterbox,
+                                out_hashes + lo * VDF_HASH_WORDS, out_crops ? out_crops + 4 * lo : nullptr,
+                                out_dontcare ? out_dontcare + lo : nullptr);
+    });
+}
+
+int vdf_hash_frames_u8(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                       uint32_t *out_dontcare)
+{
+    return hash_host_entry(ctx, frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, 0, out_hashes, nullptr,
+                           out_dontcare);
+}
+
+int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip,
+                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
+                                 uint32_t *out_crops, uint32_t *out_dontcare)
+{
+    return hash_host_entry(ctx, frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, 1, out_hashes, out_crops,
+                           out_dontcare);
 }
 
 int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
@@ -744,42 +893,6 @@ int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, s
                                         stream ? (hipStream_t)stream : ctx->stream);
 }
 
-int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip,
-                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
-                                 uint32_t *out_crops, uint32_t *out_dontcare)
-{
-    if (!ctx) return VDF_E_INVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
-    if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
-    if (frame_stride < (size_t)w * h) return fail(ctx, VDF_E_INVAL, "frame_stride smaller than a frame");
-    if (n_clips == 0) return VDF_OK;
-    if (!frames || !out_hashes) return fail(ctx, VDF_E_INVAL, "null pointer");
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
-    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, (512ull << 20) / cbytes));
-    VDF_HIP(ctx, ctx->frames.reserve(batch * cbytes));
-    VDF_HIP(ctx, ctx->out_hashes.reserve(batch * VDF_HASH_WORDS * 8));
-    VDF_HIP(ctx, ctx->out_dc.reserve(batch * 4));
-    for (size_t c0 = 0; c0 < n_clips; c0 += batch) {
-        const size_t nb = std::min(batch, n_clips - c0);
-        for (size_t c = 0; c < nb; c++)
-            VDF_HIP(ctx, hipMemcpy2DAsync(ctx->frames.as<uint8_t>() + c * cbytes, fbytes, frames + (c0 + c) * clip_stride,
-                                          frame_stride, fbytes, VDF_DCT_SIZE, hipMemcpyHostToDevice, s));
-        int rc = letterbox_hash_device_locked(ctx, ctx->frames.as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
-                                              ctx->out_hashes.as<uint64_t>(),
-                                              out_dontcare ? ctx->out_dc.as<uint32_t>() : nullptr,
-                                              out_crops ? out_crops + 4 * c0 : nullptr, s);
-        if (rc) return rc;
-        VDF_HIP(ctx, hipMemcpyAsync(out_hashes + c0 * VDF_HASH_WORDS, ctx->out_hashes.p, nb * VDF_HASH_WORDS * 8,
-                                    hipMemcpyDeviceToHost, s));
-        if (out_dontcare) VDF_HIP(ctx, hipMemcpyAsync(out_dontcare + c0, ctx->out_dc.p, nb * 4, hipMemcpyDeviceToHost, s));
-        VDF_HIP(ctx, hipStreamSynchronize(s));
-    }
-    return VDF_OK;
-}
-
 int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, const uint64_t *ref_hashes, size_t n_ref,
                             const vdf_groups *groups, uint32_t *out_max)
 {
@@ -818,6 +931,7 @@ int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, cons
     return VDF_OK;
 }
 
+
 int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
                            uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
                            uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
@@ -825,37 +939,11 @@ int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_
 {
     if (!ctx || !n_hits || !overflow_row || (capacity && !hits)) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     ctx->stats = vdf_search_stats{};
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return search_core(ctx, 0, d_hashes, d_durations, n, d_hashes, d_durations, nullptr, n, tol_int, shard_index,
                        shard_count, row_begin, row_end, d_matched, 0, hits, capacity, n_hits, overflow_row, s);
-}
-
-static int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
-                                     size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
-                                     size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
-                                     uint64_t capacity, uint64_t *n_hits, hipStream_t s)
-{
-    ctx->stats = vdf_search_stats{};
-    *n_hits = 0;
-    if (n_ref == 0 || n_cand == 0) return VDF_OK;
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    // References arrive in the caller's order; tiles want neighbouring rows to share a duration window, so
-    // rows are visited through a stable duration-sorted permutation (reported indices stay the caller's).
-    std::vector<uint32_t> rdur(n_ref), perm(n_ref);
-    VDF_HIP(ctx, hipMemcpyAsync(rdur.data(), d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
-    VDF_HIP(ctx, hipStreamSynchronize(s));
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rdur[a] < rdur[b]; });
-    int rc = upload(ctx, ctx->perm, perm.data(), n_ref * 4, s);
-    if (rc) return rc;
-    uint32_t overflow_row = 0;
-    rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
-                     ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
-                     capacity, n_hits, &overflow_row, s);
-    if (rc) return rc;
-    if (*n_hits > capacity) return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size");
-    return VDF_OK;
 }
 
 int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
@@ -865,6 +953,7 @@ int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const ui
 {
     if (!ctx || !n_hits || (capacity && !hits)) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     return search_refs_device_locked(ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
                                      n_ref, tol_int, ref_index_base, hits, capacity, n_hits,
                                      stream ? (hipStream_t)stream : ctx->stream);
@@ -880,55 +969,17 @@ int vdf_search_self(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durati
     if (n == 0) return vdf_groups_finish_self(out);  // search_algorithm.rs:89-91
     if (!hashes || !durations) return fail(ctx, VDF_E_INVAL, "null pointer");
     if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    int rc = upload(ctx, ctx->up_hashes, hashes, n * VDF_HASH_WORDS * 8, s);
-    if (rc == VDF_OK) rc = upload(ctx, ctx->up_dur, durations, n * 4, s);
+    // the windows are binary searches over the durations: the arrays must be in Search::sort order (search_algorithm.rs:55-61)
+    if (!is_sorted_u32(durations, n)) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
+    // every device receives the whole database straight from the host arrays (no collective needed)
+    int rc = for_each_device(ctx, [&](int, vdf_ctx *d) {
+        VDF_HIP(d, hipSetDevice(d->device));
+        int r = upload(d, d->up_hashes, hashes, n * VDF_HASH_WORDS * 8, d->stream);
+        if (r == VDF_OK) r = upload(d, d->up_dur, durations, n * 4, d->stream);
+        return r;
+    });
     if (rc) return rc;
-
-    uint64_t capacity = ctx->hit_capacity;
-    std::vector<uint8_t> matched(n, 0);
-    std::vector<uint32_t> bitmap;
-    const uint32_t *d_matched = nullptr;
-    uint32_t row_begin = 0;
-    uint64_t span = n;  // rows per launch; shrinks after an overflow, grows back afterwards
-    while (row_begin < n) {
-        const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
-        if (ctx->host_hits.size() < capacity) ctx->host_hits.resize(capacity);
-        uint64_t n_hits = 0;
-        uint32_t overflow_row = 0xFFFFFFFFu;
-        rc = search_core(ctx, 0, ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), n,
-                         ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), nullptr, n, tol_int, 0, 1,
-                         row_begin, row_end, d_matched, 0, ctx->host_hits.data(), capacity, &n_hits, &overflow_row, s);
-        if (rc) { vdf_groups_free(out); return rc; }
-        const uint32_t complete_end = std::min(overflow_row, row_end);
-        rc = vdf_replay_self(n, ctx->host_hits.data(), std::min(n_hits, capacity), row_begin, complete_end,
-                             matched.data(), out);
-        if (rc) { vdf_groups_free(out); return fail(ctx, rc, "replay failed"); }
-        if (overflow_row == 0xFFFFFFFFu) {
-            row_begin = row_end;
-            span = std::min<uint64_t>(n, span * 4);
-        } else {
-            const uint64_t progress = complete_end - row_begin;
-            if (progress == 0) {
-                // Not even one row fit: give a single row the whole buffer (its hits are < n).
-                span = 1;
-                if (capacity < n) capacity = n;
-            } else {
-                span = std::max<uint64_t>(progress * 2, ctx->tile_rows);
-            }
-            row_begin = complete_end;
-        }
-        if (row_begin < n) {  // feed the consumption state back to the device
-            bitmap.assign((n + 31) / 32, 0u);
-            for (size_t i = 0; i < n; i++)
-                if (matched[i]) bitmap[i >> 5] |= 1u << (i & 31);
-            rc = upload(ctx, ctx->matched, bitmap.data(), bitmap.size() * 4, s);
-            if (rc) { vdf_groups_free(out); return rc; }
-            d_matched = ctx->matched.as<uint32_t>();
-        }
-    }
-    return vdf_groups_finish_self(out);
+    return search_self_resident(ctx, n, tol_int, out);
 }
 
 int vdf_search_refs(vdf_ctx *ctx, const uint64_t *cand_hashes, const uint32_t *cand_durations, size_t n_cand,
@@ -938,27 +989,28 @@ int vdf_search_refs(vdf_ctx *ctx, const uint64_t *cand_hashes, const uint32_t *c
     if (!ctx || !out) return VDF_E_INVAL;
     std::memset(out, 0, sizeof *out);
     if (n_cand == 0 || n_ref == 0) return vdf_groups_from_ref_hits(nullptr, 0, out);
-    if (!cand_hashes || !cand_durations || !ref_hashes || !ref_durations) return fail(ctx, VDF_E_INVAL, "null pointer");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    int rc = upload(ctx, ctx->up_hashes, cand_hashes, n_cand * VDF_HASH_WORDS * 8, s);
-    if (rc == VDF_OK) rc = upload(ctx, ctx->up_dur, cand_durations, n_cand * 4, s);
-    if (rc == VDF_OK) rc = upload(ctx, ctx->up_ref_hashes, ref_hashes, n_ref * VDF_HASH_WORDS * 8, s);
-    if (rc == VDF_OK) rc = upload(ctx, ctx->up_ref_dur, ref_durations, n_ref * 4, s);
-    if (rc) return rc;
-    uint64_t capacity = ctx->hit_capacity;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if (ctx->host_hits.size() < capacity) ctx->host_hits.resize(capacity);
-        uint64_t n_hits = 0;
-        rc = search_refs_device_locked(ctx, ctx->up_hashes.as<uint64_t>(), ctx->up_dur.as<uint32_t>(), n_cand,
-                                       ctx->up_ref_hashes.as<uint64_t>(), ctx->up_ref_dur.as<uint32_t>(), n_ref,
-                                       tol_int, 0, ctx->host_hits.data(), capacity, &n_hits, s);
-        if (rc == VDF_E_OVERFLOW && attempt == 0) { capacity = n_hits; continue; }  // every hit is output: size exactly
-        if (rc) return rc;
-        return vdf_groups_from_ref_hits(ctx->host_hits.data(), n_hits, out);
+    if (!cand_hashes || !cand_durations || !ref_hashes || !ref_durations) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n_cand >= 0xFFFFFFFFull || n_ref >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    if (!is_sorted_u32(cand_durations, n_cand))
+        return fail(ctx, VDF_E_INVAL, "candidate durations are not ascending: pass the candidates in Search::sort order");
+    const int G = device_count(ctx);
+    std::vector<size_t> cnt((size_t)G), base((size_t)G);
+    for (int k = 0; k < G; k++) {  // contiguous, order-preserving split of the references
+        const size_t b = n_ref / (size_t)G, rem = n_ref % (size_t)G;
+        base[(size_t)k] = (size_t)k * b + std::min<size_t>((size_t)k, rem);
+        cnt[(size_t)k] = b + ((size_t)k < rem ? 1 : 0);
     }
-    return fail(ctx, VDF_E_OVERFLOW, "hit buffer overflow");
+    int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
+        VDF_HIP(d, hipSetDevice(d->device));
+        int r = upload(d, d->up_hashes, cand_hashes, n_cand * VDF_HASH_WORDS * 8, d->stream);
+        if (r == VDF_OK) r = upload(d, d->up_dur, cand_durations, n_cand * 4, d->stream);
+        if (r == VDF_OK) r = upload(d, d->up_ref_hashes, ref_hashes + base[(size_t)k] * VDF_HASH_WORDS, cnt[(size_t)k] * VDF_HASH_WORDS * 8, d->stream);
+        if (r == VDF_OK) r = upload(d, d->up_ref_dur, ref_durations + base[(size_t)k], cnt[(size_t)k] * 4, d->stream);
+        return r;
+    });
+    if (rc) return rc;
+    return search_refs_resident(ctx, n_cand, cnt, base, tol_int, out);
 }
 
 }  // extern "C"

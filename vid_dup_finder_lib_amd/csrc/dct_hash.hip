@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void resize_generic_kernel(
 // plan_dct2(16) is Type2And3Butterfly16: split-radix steps (16 -> 8 + 4 + 4, 8 -> 4 + 2 + 2, 4 -> 2 + 1 + 1) in which
 // even outputs come from the sums v[n] + v[N-1-n] and odd outputs from the differences v[n] - v[N-1-n] rotated by
 // e^{i pi (2n+1) / 2N}; a constant or symmetric line then yields exact +-0.0 there (bit 0).  This is the same operation
-// sequence as oracle/vdf_oracle.c dct2_len16, with every product and sum rounded separately like Rust does
+// sequence as the CPU checker under oracle/ (dct2_len16), with every product and sum rounded separately like Rust does
 // (contraction off), so the coefficients - not just their signs - are bit-identical to the oracle's.
 // The 15 constants (twiddles + sqrt(1/2)) are wave-uniform and live in SGPR pairs; unused outputs fall to dead-code elimination.
 #pragma clang fp contract(off)

@@ -132,6 +132,15 @@ __global__ __launch_bounds__(256) void windows_tiles_kernel(
     }
 }
 
+// counters[5] != 0 <=> the candidate durations are not ascending (the device-pointer entry points cannot check on the host).
+__global__ __launch_bounds__(256) void check_sorted_kernel(const uint32_t *__restrict__ d, uint32_t n,
+                                                           unsigned long long *__restrict__ counters)
+{
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (size_t)gridDim.x * 256) bad |= d[i] > d[i + 1];
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) counters[5] = 1ull;
+}
+
 // Exclusive scan of tile_count[0..n) into tile_offset[0..n]; single workgroup of 1024 threads.
 __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t n,
                                                           uint32_t *__restrict__ tile_offset)
@@ -603,6 +612,8 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L, hipStream_t stream)
 {
     if (L.n_row_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(check_sorted_kernel, dim3(std::min<uint32_t>((n_cols + 255) / 256, 2048u)), dim3(256), 0, stream, col_dur,
+                       n_cols, L.counters);
     hipLaunchKernelGGL(windows_tiles_kernel, dim3(L.n_row_tiles), dim3(256), 0, stream, mode, col_dur, n_cols, row_dur,
                        row_perm, n_rows, row_begin, row_end, shard_index, shard_count, (uint32_t)L.tile_rows,
                        L.chunk_cols, L.row_lo, L.row_hi, L.tile_lo, L.tile_hi, L.tile_first, L.tile_count, L.counters);
@@ -721,6 +732,7 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
                        L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
                        L.hits, L.capacity, L.counters, L.overflow_row, base, L.xcd_stripe)
         switch (L.ablate) {
+#ifdef VDF_BENCH_ABLATE  // timing-experiment builds only (tools/build_variant.sh <name> -DVDF_BENCH_ABLATE): no hits reported
         case 1: VDF_MFMA_LAUNCH(1, 16); break;
         case 2: VDF_MFMA_LAUNCH(2, 16); break;
         case 3: VDF_MFMA_LAUNCH(3, 16); break;
@@ -728,6 +740,7 @@ hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles
         case 5: VDF_MFMA_LAUNCH(5, 16); break;
         case 6: VDF_MFMA_LAUNCH(6, 16); break;
         case 7: VDF_MFMA_LAUNCH(7, 16); break;
+#endif
         default:
             switch (L.prune_step) {  // smallest instantiated step >= the requested one
             case 0: case 1: case 2: case 3: case 4: case 5: case 6: VDF_MFMA_LAUNCH(0, 6); break;

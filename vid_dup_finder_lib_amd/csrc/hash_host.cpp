@@ -1,0 +1,179 @@
+// Host frames -> hashes on one device (the body of vdf_hash_frames_u8 / vdf_hash_frames_u8_letterbox).
+//
+// The caller's frames are ordinary (pageable) memory, any strides; only the first 16 frames of a clip are wanted
+// (video_hash.rs:53-61, dct_3d.rs:25).  The kernel side runs at several TB/s, so this path is the PCIe link's:
+//   caller memory --(host threads gather 16 frames per clip, tightly packed)--> pinned chunk A / B
+//                 --(hipMemcpyAsync on the copy stream)--> device batch buffer 0 / 1
+//                 --(hash kernels on the compute stream)--> device hashes --> pinned results --> caller arrays
+// Two pinned chunks: the DMA of chunk k runs while the threads fill chunk k + 1.  Two device batch buffers: the
+// kernels of batch b run while batch b + 1 streams in.  Results are copied out of pinned memory one batch late, so
+// nothing in the loop waits for the GPU except when a buffer is about to be reused.
+#include <algorithm>
+#include <cstring>
+
+#include "vdf_ctx.h"
+
+namespace vdf_impl {
+
+// A few persistent host threads for the gather into pinned memory (one memcpy thread moves ~10 GB/s; the link
+// takes ~56): created on first use, VDF_COPY_THREADS overrides the count.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    const std::function<void(int, int)> *job = nullptr;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool quit = false;
+
+    explicit CopyPool(int n)
+    {
+        for (int t = 0; t < n; t++)
+            threads.emplace_back([this, t, n] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void(int, int)> *f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_job.wait(lk, [&] { return quit || gen != seen; });
+                        if (quit) return;
+                        seen = gen;
+                        f = job;
+                    }
+                    (*f)(t, n);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(int, int)> &f)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        job = &f;
+        pending = (int)threads.size();
+        gen++;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv_job.notify_all();
+        for (auto &t : threads) t.join();
+    }
+};
+
+void destroy_copy_pool(vdf_ctx *ctx)
+{
+    delete ctx->copy_pool;
+    ctx->copy_pool = nullptr;
+}
+
+static CopyPool *pool_of(vdf_ctx *ctx)
+{
+    if (!ctx->copy_pool) {
+        int n = (int)std::thread::hardware_concurrency() / 2;
+        n = std::max(1, std::min(n, 8));
+        if (const char *s = std::getenv("VDF_COPY_THREADS")) {
+            const int v = std::atoi(s);
+            if (v >= 1 && v <= 64) n = v;
+        }
+        ctx->copy_pool = new CopyPool(n);
+    }
+    return ctx->copy_pool;
+}
+
+constexpr size_t kChunkBytes = 32ull << 20;   // pinned staging chunk (x 2)
+constexpr size_t kBatchBytes = 256ull << 20;  // device batch buffer (x 2)
+
+int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                     size_t clip_stride, int letterbox, uint64_t *out_hashes, uint32_t *out_crops, uint32_t *out_dontcare)
+{
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, kBatchBytes / cbytes));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, kChunkBytes / cbytes));  // clips per pinned chunk
+    const bool packed = frame_stride == fbytes && clip_stride == cbytes;
+    DevBuf *d_frames[2] = {&ctx->frames, &ctx->frames2}, *d_hash[2] = {&ctx->out_hashes, &ctx->out_hashes2},
+           *d_dc[2] = {&ctx->out_dc, &ctx->out_dc2};
+    const size_t n_batches = (n_clips + batch - 1) / batch;
+    for (int i = 0; i < (n_batches > 1 ? 2 : 1); i++) {
+        VDF_HIP(ctx, d_frames[i]->reserve(batch * cbytes));
+        VDF_HIP(ctx, d_hash[i]->reserve(batch * VDF_HASH_WORDS * 8));
+        VDF_HIP(ctx, d_dc[i]->reserve(batch * 4));
+        if (!ctx->pin_out[i].reserve(batch * (VDF_HASH_WORDS * 8 + 4))) return fail(ctx, VDF_E_OOM, "pinned result buffer");
+    }
+    for (int i = 0; i < 2; i++)
+        if (!ctx->pin[i].reserve(chunk * cbytes)) return fail(ctx, VDF_E_OOM, "pinned staging buffer");
+    CopyPool *pool = pool_of(ctx);
+    hipStream_t s = ctx->stream, cs = ctx->copy_stream;
+
+    auto copy_out = [&](size_t b) {  // results of batch b: pinned -> caller arrays (its ev_done has been waited for)
+        const size_t c0 = b * batch, nb = std::min(batch, n_clips - c0);
+        const uint8_t *src = ctx->pin_out[b & 1].as<uint8_t>();
+        std::memcpy(out_hashes + c0 * VDF_HASH_WORDS, src, nb * VDF_HASH_WORDS * 8);
+        if (out_dontcare) std::memcpy(out_dontcare + c0, src + batch * VDF_HASH_WORDS * 8, nb * 4);
+    };
+    size_t chunk_counter = 0;
+    for (size_t b = 0; b < n_batches; b++) {
+        const size_t c0 = b * batch, nb = std::min(batch, n_clips - c0);
+        const int slot = (int)(b & 1);
+        if (b >= 2) {  // the slot's previous batch (b - 2): kernels done, results landed in pinned memory
+            VDF_HIP(ctx, hipEventSynchronize(ctx->ev_done[slot]));
+            copy_out(b - 2);
+        }
+        // stage the batch chunk by chunk: threads fill pinned chunk p while the DMA of the other chunk is in flight
+        for (size_t q0 = 0; q0 < nb; q0 += chunk, chunk_counter++) {
+            const size_t nq = std::min(chunk, nb - q0);
+            const int p = (int)(chunk_counter & 1);
+            if (chunk_counter >= 2) VDF_HIP(ctx, hipEventSynchronize(ctx->ev_copy[p]));  // the DMA that last read this chunk
+            uint8_t *dst = ctx->pin[p].as<uint8_t>();
+            const uint8_t *src = frames + (c0 + q0) * clip_stride;
+            if (packed) {
+                const size_t total = nq * cbytes;
+                pool->run([&](int t, int n) {
+                    const size_t per = ((total + (size_t)n - 1) / (size_t)n + 4095) & ~(size_t)4095;
+                    const size_t lo = std::min(total, per * (size_t)t), hi = std::min(total, lo + per);
+                    if (hi > lo) std::memcpy(dst + lo, src + lo, hi - lo);
+                });
+            } else {
+                pool->run([&](int t, int n) {
+                    for (size_t c = (size_t)t; c < nq; c += (size_t)n)
+                        for (int f = 0; f < VDF_DCT_SIZE; f++)
+                            std::memcpy(dst + c * cbytes + (size_t)f * fbytes, src + c * clip_stride + (size_t)f * frame_stride, fbytes);
+                });
+            }
+            VDF_HIP(ctx, hipMemcpyAsync(d_frames[slot]->as<uint8_t>() + q0 * cbytes, dst, nq * cbytes, hipMemcpyHostToDevice, cs));
+            VDF_HIP(ctx, hipEventRecord(ctx->ev_copy[p], cs));
+        }
+        // kernels of this batch wait for its last chunk only (the copy stream is in order)
+        VDF_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_copy[(chunk_counter - 1) & 1], 0));
+        uint32_t *dc = out_dontcare ? d_dc[slot]->as<uint32_t>() : nullptr;
+        int rc;
+        if (letterbox)
+            rc = letterbox_hash_device_locked(ctx, d_frames[slot]->as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
+                                              d_hash[slot]->as<uint64_t>(), dc, out_crops ? out_crops + 4 * c0 : nullptr, s);
+        else
+            rc = hash_device_locked(ctx, d_frames[slot]->as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
+                                    d_hash[slot]->as<uint64_t>(), dc, s);
+        if (rc) return rc;
+        uint8_t *po = ctx->pin_out[slot].as<uint8_t>();
+        VDF_HIP(ctx, hipMemcpyAsync(po, d_hash[slot]->p, nb * VDF_HASH_WORDS * 8, hipMemcpyDeviceToHost, s));
+        if (dc) VDF_HIP(ctx, hipMemcpyAsync(po + batch * VDF_HASH_WORDS * 8, dc, nb * 4, hipMemcpyDeviceToHost, s));
+        VDF_HIP(ctx, hipEventRecord(ctx->ev_done[slot], s));
+        // the next batch's DMA into the other device buffer must not overtake the kernels that still read it
+        if (b + 1 < n_batches && b >= 1) VDF_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_done[(b + 1) & 1], 0));
+    }
+    for (size_t b = n_batches >= 2 ? n_batches - 2 : 0; b < n_batches; b++) {
+        VDF_HIP(ctx, hipEventSynchronize(ctx->ev_done[b & 1]));
+        copy_out(b);
+    }
+    return VDF_OK;
+}
+
+}  // namespace vdf_impl

@@ -1,0 +1,174 @@
+// The private definition of vdf_ctx (include/vdf.h keeps it opaque) and the internal entry points api.cpp and
+// multi.cpp share.  A context is either ONE device (stream, scratch buffers, tables) or a multi-GPU parent that owns
+// one single-device sub-context plus one host worker thread per listed device (multi.cpp).
+#pragma once
+#include <condition_variable>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "resize_tables.h"
+#include "vdf_internal.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Pinned host staging (hipHostMalloc); falls back to pageable memory if pinning fails.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        release();
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) {
+            pinned = true;
+        } else {
+            (void)hipGetLastError();
+            p = std::malloc(bytes);
+            pinned = false;
+            if (!p) return false;
+        }
+        cap = bytes;
+        return true;
+    }
+    void release()
+    {
+        if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+        p = nullptr; cap = 0; pinned = false;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct DeviceAxisTable {
+    DevBuf start, size, w;
+    vdf::HostAxisTable host;
+};
+
+struct DeviceMfmaTable {
+    DevBuf operand, bias;
+    vdf::MfmaAxisTable host;
+};
+
+namespace vdf_impl {
+struct Worker;     // one host thread bound to one device (multi.cpp)
+struct RcclState;  // communicators of a multi-GPU context (multi.cpp)
+struct CopyPool;   // host threads that gather caller frames into pinned staging (hash_host.cpp)
+}
+
+struct vdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // H2D staging of the next batch under the current batch's kernels (hash path)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    std::mutex mu;
+    std::string err;
+    uint64_t hit_capacity = 1ull << 24;
+    vdf_search_stats stats{};
+    uint32_t tile_rows = 256 * vdf::kDefaultRowsPerLane;
+    uint32_t chunk_cols = vdf::kDefaultChunkCols;
+    // search scratch
+    DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
+    DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
+    // hash scratch
+    DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables;
+    PinBuf pin[2], pin_out[2];
+    std::map<uint32_t, DeviceAxisTable *> axis_tables;
+    std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
+    int hash_no_persistent = 0, hash_wgs_per_cu = 3;
+    uint32_t mfma_chunk_cols = 0, mfma_group = 8192;  // 0 = pick the chunk width per search (search_core); VDF_MFMA_CHUNK_COLS overrides
+    DevBuf group_cmin, group_offset, group_blocks;
+    uint32_t mfma_xcd_stripe = 0;
+    uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
+    int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
+    int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
+    DevBuf exp_cols, exp_rows;
+    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
+    std::vector<vdf_hit> host_hits;
+    vdf_impl::CopyPool *copy_pool = nullptr;
+    // results of the last fan-out round on this device (multi-GPU parent reads them after the workers join)
+    uint64_t r_n_hits = 0;
+    uint32_t r_overflow = 0xFFFFFFFFu;
+    int r_rc = 0;
+
+    // ---- multi-GPU parent only ----
+    std::vector<vdf_ctx *> subs;                  // one single-device context per listed device (devices may repeat)
+    std::vector<vdf_impl::Worker *> workers;      // one host thread per sub-context
+    vdf_impl::RcclState *rccl = nullptr;
+    std::vector<vdf_search_stats> dev_stats;      // per-device statistics of the last search
+
+    ~vdf_ctx();
+};
+
+namespace vdf_impl {
+
+void set_create_error(const std::string &msg);  // what vdf_last_error(NULL) returns on this thread
+int fail(vdf_ctx *ctx, int code, const std::string &msg);
+int fail_hip(vdf_ctx *ctx, hipError_t e, const char *what);
+
+#define VDF_HIP(ctx, call)                                                      \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return vdf_impl::fail_hip((ctx), e__, #call);    \
+    } while (0)
+
+inline bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; }
+
+// ---- single-device building blocks (api.cpp); the caller holds the lock of the context it passes -----------------
+int create_single(int device_id, vdf_ctx **out, std::string *err);
+int upload(vdf_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, hipStream_t stream);
+// windows + tiles, distance kernel, hit download (sorted by (row, col)); mode 0 = self, 1 = references
+int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
+                const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
+                uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
+                const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream);
+int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
+                              size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations, size_t n_ref,
+                              uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits, uint64_t capacity,
+                              uint64_t *n_hits, hipStream_t s);
+int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
+                       uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out, uint32_t *d_dc,
+                       hipStream_t stream);
+// host frames -> hashes on ONE device: pinned, double-buffered staging (copy of batch k + 1 under the kernels of batch k)
+int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                     size_t clip_stride, int letterbox, uint64_t *out_hashes, uint32_t *out_crops, uint32_t *out_dontcare);
+// The greedy search() loop over a database that is already resident on every device of the context
+// (d_hashes(dev) / d_dur(dev) give each device's replica): overflow protocol, merge, replay.
+int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *out);
+int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> &ref_cnt, const std::vector<size_t> &ref_base,
+                         uint32_t tol_int, vdf_groups *out);
+int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                 uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out,
+                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream);
+void destroy_copy_pool(vdf_ctx *ctx);
+bool is_sorted_u32(const uint32_t *d, size_t n);
+
+// ---- multi-GPU parent (multi.cpp) ----------------------------------------------------------------------------
+// Runs f(k, device context) for every device: inline for a single-device context, on the workers otherwise.
+// Returns the first non-zero status (its message is copied to ctx->err).
+int for_each_device(vdf_ctx *ctx, const std::function<int(int, vdf_ctx *)> &f);
+inline int device_count(const vdf_ctx *ctx) { return ctx->subs.empty() ? 1 : (int)ctx->subs.size(); }
+inline vdf_ctx *device_ctx(vdf_ctx *ctx, int k) { return ctx->subs.empty() ? ctx : ctx->subs[k]; }
+void destroy_multi(vdf_ctx *ctx);  // joins the workers, destroys communicators and sub-contexts
+
+}  // namespace vdf_impl

@@ -34,24 +34,42 @@ def groups_to_arrays(g: VdfGroups):
     return offsets, members, refs
 
 
+def _ptr_array(ptrs: Sequence[int]):
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p) or None) for p in ptrs])
+
+
+def _size_array(sizes: Sequence[int]):
+    return (C.c_size_t * len(sizes))(*[int(x) for x in sizes])
+
+
 class Engine:
-    """One GPU context.  `device` defaults to LOCAL_RANK (one process per GPU) or 0.
+    """One context: one GPU (`device`, default LOCAL_RANK or 0), or - `devices=[...]` - ONE context over several GPUs
+    of the node (vdf_ctx_create_multi: the host-array calls fan out inside the library, the *_shards methods take
+    one device pointer per GPU).  A device may be listed twice to exercise the multi-GPU path on one GPU.
 
-    *_device methods take raw device pointers and a hipStream_t handle.  stream=0 means the context's own
-    non-blocking stream, which does NOT order against work queued elsewhere (e.g. torch's current stream): either
-    pass the stream that produced the buffers, or synchronise before the call."""
+    *_device methods take raw device pointers and a hipStream_t handle (single-GPU contexts only).  stream=0 means the
+    context's own non-blocking stream, which does NOT order against work queued elsewhere (e.g. torch's current
+    stream): either pass the stream that produced the buffers, or synchronise before the call."""
 
-    def __init__(self, device: Optional[int] = None):
+    def __init__(self, device: Optional[int] = None, devices: Optional[Sequence[int]] = None):
         self.lib = _capi.load()
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
         ctx = C.c_void_p()
-        rc = self.lib.vdf_ctx_create(int(device), C.byref(ctx))
+        if devices is not None:
+            devs = [int(d) for d in devices]
+            arr = (C.c_int * len(devs))(*devs)
+            rc = self.lib.vdf_ctx_create_multi(arr, len(devs), C.byref(ctx))
+            device = devs[0] if devs else 0
+        else:
+            if device is None:
+                device = int(os.environ.get("LOCAL_RANK", "0"))
+            rc = self.lib.vdf_ctx_create(int(device), C.byref(ctx))
         if rc != _capi.VDF_OK:
             msg = self.lib.vdf_last_error(None)
             raise VdfError(rc, (msg or b"").decode() or "vdf_ctx_create failed (is a GPU visible?)")
         self.ctx = ctx
         self.device = int(device)
+        self.n_devices = int(self.lib.vdf_ctx_device_count(ctx))
+        self.devices = [int(self.lib.vdf_ctx_device_at(ctx, k)) for k in range(self.n_devices)]
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -84,6 +102,43 @@ class Engine:
         s = VdfSearchStats()
         self._check(self.lib.vdf_ctx_last_search_stats(self.ctx, C.byref(s)))
         return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
+
+    def device_stats(self, slot: int) -> dict:
+        s = VdfSearchStats()
+        self._check(self.lib.vdf_ctx_device_search_stats(self.ctx, int(slot), C.byref(s)))
+        return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
+
+    # ------------------------------------------------------- multi-GPU contexts: device-resident shards
+    def search_self_shards(self, d_hash_shards: Sequence[int], d_dur_shards: Sequence[int], shard_n: Sequence[int],
+                           tol_int: int) -> List[List[int]]:
+        """search() over a sorted database cut into consecutive shards, shard k resident on the GPU of slot k (device
+        pointers); the library replicates it with one all-gather (RCCL over xGMI) and searches on all GPUs."""
+        g = VdfGroups()
+        self._check(self.lib.vdf_search_self_shards(self.ctx, _ptr_array(d_hash_shards), _ptr_array(d_dur_shards),
+                                                    _size_array(shard_n), int(tol_int), C.byref(g)))
+        try:
+            return [m for _, m in _groups_to_lists(g)]
+        finally:
+            self.lib.vdf_groups_free(C.byref(g))
+
+    def search_refs_shards(self, d_cand_hash_shards, d_cand_dur_shards, cand_shard_n, d_ref_hash_shards, d_ref_dur_shards,
+                           ref_shard_n, tol_int: int):
+        g = VdfGroups()
+        self._check(self.lib.vdf_search_refs_shards(self.ctx, _ptr_array(d_cand_hash_shards), _ptr_array(d_cand_dur_shards),
+                                                    _size_array(cand_shard_n), _ptr_array(d_ref_hash_shards),
+                                                    _ptr_array(d_ref_dur_shards), _size_array(ref_shard_n), int(tol_int),
+                                                    C.byref(g)))
+        try:
+            return _groups_to_lists(g)
+        finally:
+            self.lib.vdf_groups_free(C.byref(g))
+
+    def hash_frames_shards(self, d_frames: Sequence[int], n_clips: Sequence[int], frames_per_clip: int, w: int, h: int,
+                           d_out: Sequence[int], d_dontcare: Optional[Sequence[int]] = None):
+        fs = w * h
+        self._check(self.lib.vdf_hash_frames_u8_shards(self.ctx, _ptr_array(d_frames), _size_array(n_clips), frames_per_clip,
+                                                       w, h, fs, fs * frames_per_clip, _ptr_array(d_out),
+                                                       _ptr_array(d_dontcare) if d_dontcare is not None else None))
 
     # ------------------------------------------------------------------ hashing
     def hash_frames(self, frames: np.ndarray, want_dontcare: bool = False):
