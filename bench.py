@@ -114,6 +114,54 @@ def read_traffic(name):
         return None
 
 
+def search_roofline(backend, kernel_ms):
+    """roofline (+ companions) of the dominant search kernel from the library's per-step statistics:
+    kernel_ms = [(kernel_ms, n_launches, pairs, pairs_computed, n_hits, pairs_early_exit, early_exit_bits)] per step,
+    of ONE device (HIP-event time recorded by the library on the kernel's own stream)."""
+    k_ms = float(np.mean([k[0] / max(k[1], 1) for k in kernel_ms]))
+    k_pairs = float(np.mean([k[2] for k in kernel_ms]))  # pairs admitted on THIS rank per launch
+    k_comp = float(np.mean([k[3] for k in kernel_ms]))   # pairs the tiles evaluated (>= admitted)
+    stream_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
+    hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": stream_gbs / HBM_PEAK_GBS,
+                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream model of the reference loop: 128 B per pair "
+                         "against 8 TB/s (north_star target frac >= 0.5).  Tiles keep targets in registers and share "
+                         "candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per pair (see traffic)"}
+    if backend == "valu":
+        kname = "hamming_tile_kernel"
+        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname),
+                        traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
+                        kernel_ms=k_ms, pairs_per_launch=k_pairs)
+        valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        extra = {"valu": valu}
+        dtype = "u32 (xor + popcount over 32 dwords per hash)"
+    else:
+        kname = "hamming_mfma_kernel"
+        alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
+        ee_bits = int(kernel_ms[-1][6])
+        executed = (k_comp - k_early * (1.0 - ee_bits / 1024.0 if ee_bits else 0.0)) * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        # frac prices the MFMA work the kernel EXECUTED (blocks that take the exact early exit stop after ee_bits of the
+        # 1024 bit positions); the algorithmic 2048 FLOP per pair are reported beside it, never as the headline fraction
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": executed, "peak": MFMA_FP4_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": executed / MFMA_FP4_PEAK_TFLOPS,
+                    "algorithmic_achieved": alg_tflops, "algorithmic_frac": alg_tflops / MFMA_FP4_PEAK_TFLOPS,
+                    "traffic": read_traffic(kname),
+                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the committed "
+                                      "profile run of this workload; not measured in this run)",
+                    "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
+                    "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
+                                   "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
+                                           "exceed the tolerance cannot contain a hit and stops there (exact)"},
+                    "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
+                            "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
+                            "pair; integer results, bit-identical to XOR + popcount"}
+        extra = {"hbm_operand_stream_model": hbm_model}
+        dtype = "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)"
+    return roofline, extra, dtype
+
+
 def free_port():
     import socket
 
@@ -139,6 +187,109 @@ def self_launch(args):
     raise SystemExit(proc.returncode)
 
 
+def run_single_process(args):
+    """--single-process: all N GPUs from ONE process through the C ABI's multi-GPU context (vdf_ctx_create_multi: one
+    host thread + stream per device inside the library; database shards resident per GPU, replicated by the library's
+    own RCCL all-gather).  Same step, same metric, same JSON line as the multi-process form; torch only allocates the
+    buffers.  With fewer physical GPUs than --gpus the device list wraps (testing on one GPU)."""
+    import gc
+
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import distributed as vd
+    from vid_dup_finder_lib_amd import engine as ve
+
+    G = args.gpus
+    n_phys = max(torch.cuda.device_count(), 1)
+    devices = [k % n_phys for k in range(G)]
+    eng = vdf.Engine(devices=devices)
+    tol_int = ve.tolerance_int(args.tolerance)
+    n_total = int(round(args.n_hashes * G ** 0.5))
+    words = make_hashes(n_total, 20250613)
+    pairs = n_total * (n_total - 1) // 2
+    sw, sd, sizes = [], [], []
+    for k in range(G):
+        lo, hi = vd.split_range(n_total, k, G)
+        dev = torch.device("cuda", devices[k])
+        sw.append(torch.from_numpy(words[lo:hi].view(np.int64)).to(dev))
+        sd.append(torch.zeros(hi - lo, dtype=torch.int32, device=dev))
+        sizes.append(hi - lo)
+    pw, pd = [t.data_ptr() for t in sw], [t.data_ptr() for t in sd]
+
+    def sync_all():
+        for k in set(devices):
+            torch.cuda.synchronize(k)
+
+    per_dev, n_groups = [], None
+
+    def step():
+        nonlocal n_groups
+        groups = eng.search_self_shards(pw, pd, sizes, tol_int)
+        n_groups = len(groups)
+        per_dev.append([eng.device_stats(k) for k in range(G)])
+
+    for _ in range(args.warmup):
+        step()
+    per_dev.clear()
+    gc.collect()
+    gc.disable()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
+    # the roofline describes ONE device's kernel: the slowest slot of each step
+    slow = [max(st, key=lambda q: q["kernel_ms"]) for st in per_dev]
+    kernel_ms = [(q["kernel_ms"], q["n_launches"], q["pairs"], q["pairs_computed"], q["n_hits"], q["pairs_early_exit"],
+                  q["early_exit_bits"]) for q in slow]
+    roofline, extra, dtype = search_roofline(backend, kernel_ms)
+    out = {
+        "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
+        "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": G, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, all durations 0, all-pairs "
+                               "search_self at tolerance 350, planted near-duplicates every 1000th hash",
+                   "n_hashes": n_total, "hashes_per_gpu_shard": sizes[0], "pairs": pairs, "tolerance_int": tol_int,
+                   "parallelism": f"ONE process, vdf_ctx_create_multi over devices {devices}: shards resident per GPU, "
+                                  "RCCL all-gather inside the library, row tiles round-robin, one host replay"},
+        "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
+        "per_device_kernel_ms": [float(np.mean([st[k]["kernel_ms"] for st in per_dev])) for k in range(G)],
+        "per_device_pairs": [int(per_dev[-1][k]["pairs"]) for k in range(G)],
+    }
+    out.update(extra)
+    if args.hash_clips > 0:
+        nc = args.hash_clips
+        frames, outs = [], []
+        for k in range(G):
+            dev = torch.device("cuda", devices[k])
+            g = torch.Generator(device=dev)
+            g.manual_seed(20250617 + k)
+            frames.append(torch.randint(0, 256, (nc, 16, 64, 64), dtype=torch.uint8, device=dev, generator=g))
+            outs.append(torch.zeros((nc, 16), dtype=torch.int64, device=dev))
+        fp, op, ns = [t.data_ptr() for t in frames], [t.data_ptr() for t in outs], [nc] * G
+        sync_all()
+        for _ in range(max(args.warmup, 1)):
+            eng.hash_frames_shards(fp, ns, 16, 64, 64, op)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.hash_frames_shards(fp, ns, 16, 64, 64, op)  # returns when every device has finished
+        ms = (time.perf_counter() - t1) / args.steps * 1e3
+        h_gbs = nc * 16 / (ms * 1e-3) * BYTES_PER_FRAME / 1e9
+        out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": G * nc * 16 / (ms * 1e-3),
+                       "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": G, "ms_per_step": ms,
+                       "dtype": "u8 -> i8 MFMA fixed point (exact) -> f64 DCT",
+                       "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": h_gbs,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS, "traffic": None,
+                                    "note": "host wall time per call incl. launch + join of the per-device threads"}}
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +307,9 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 inside ONE process through vdf_ctx_create_multi (no torch.distributed)")
     args = ap.parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ and not args.single_process:
+    if args.single_process:
+        return run_single_process(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
 
     import torch
@@ -241,49 +394,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # ---- dominant kernel (HIP-event time recorded by the library on the kernel's own stream) ---------------
     backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
-    k_ms = float(np.mean([k[0] / max(k[1], 1) for k in kernel_ms]))
-    k_pairs = float(np.mean([k[2] for k in kernel_ms]))  # pairs admitted on THIS rank per launch
-    k_comp = float(np.mean([k[3] for k in kernel_ms]))   # pairs the tiles evaluated (>= admitted)
-    stream_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
-    hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": stream_gbs / HBM_PEAK_GBS,
-                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream model of the reference loop: 128 B per pair "
-                         "against 8 TB/s (north_star target frac >= 0.5).  Tiles keep targets in registers and share "
-                         "candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per pair (see traffic)"}
-    if backend == "valu":
-        kname = "hamming_tile_kernel"
-        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname),
-                        traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
-                        kernel_ms=k_ms, pairs_per_launch=k_pairs)
-        valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
-        valu["frac"] = valu["achieved"] / valu["peak"]
-        extra = {"valu": valu}
-        dtype = "u32 (xor + popcount over 32 dwords per hash)"
-    else:
-        kname = "hamming_mfma_kernel"
-        alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-        k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
-        ee_bits = int(kernel_ms[-1][6])
-        executed = (k_comp - k_early * (1.0 - ee_bits / 1024.0 if ee_bits else 0.0)) * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-        # frac prices the MFMA work the kernel EXECUTED (blocks that take the exact early exit stop after ee_bits of the
-        # 1024 bit positions); the algorithmic 2048 FLOP per pair are reported beside it, never as the headline fraction
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": executed, "peak": MFMA_FP4_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": executed / MFMA_FP4_PEAK_TFLOPS,
-                    "algorithmic_achieved": alg_tflops, "algorithmic_frac": alg_tflops / MFMA_FP4_PEAK_TFLOPS,
-                    "traffic": read_traffic(kname),
-                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the committed "
-                                      "profile run of this workload; not measured in this run)",
-                    "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
-                    "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
-                                   "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
-                                           "exceed the tolerance cannot contain a hit and stops there (exact)"},
-                    "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
-                            "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
-                            "pair; integer results, bit-identical to XOR + popcount"}
-        extra = {"hbm_operand_stream_model": hbm_model}
-        dtype = "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)"
+    roofline, extra, dtype = search_roofline(backend, kernel_ms)
     out = {
         "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
         "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,

@@ -103,3 +103,17 @@ def test_two_ranks_real_engine_match_oracle(tmp_path, capacity):
     want = orc.search_self_sorted(res["w"], res["d"], 350)
     assert res["groups"] == want and res["groups0"] == want
     assert res["refs"] == orc.search_refs_sorted(res["w"], res["d"], res["rw"], res["rd"], 300)
+
+
+def test_bench_single_process_multi_context():
+    """`bench.py --gpus 2 --single-process`: the C ABI's multi-GPU context (device list wraps onto GPU 0 here) finds the
+    same MatchGroups over the same database as the 1-GPU run; the two slots split the triangle evenly."""
+    n1 = 30000
+    n2 = int(round(n1 * 2 ** 0.5))
+    two = _bench(["--gpus", "2", "--single-process", "--n-hashes", str(n1)])
+    one = _bench(["--gpus", "1", "--n-hashes", str(n2)])
+    assert two["n_gpus"] == 2 and "vdf_ctx_create_multi" in two["config"]["parallelism"]
+    assert two["config"]["n_hashes"] == n2 and two["match_groups"] == one["match_groups"] > 0
+    p = two["per_device_pairs"]
+    assert sum(p) == two["config"]["pairs"] and abs(p[0] - p[1]) / sum(p) < 0.05
+    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0 and two["roofline"]["frac"] > 0

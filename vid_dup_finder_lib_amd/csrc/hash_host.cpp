@@ -88,8 +88,20 @@ static CopyPool *pool_of(vdf_ctx *ctx)
     return ctx->copy_pool;
 }
 
-constexpr size_t kChunkBytes = 32ull << 20;   // pinned staging chunk (x 2)
 constexpr size_t kBatchBytes = 256ull << 20;  // device batch buffer (x 2)
+
+static size_t chunk_bytes()
+{  // pinned staging chunk (x 2); VDF_HOST_CHUNK_MB for experiments
+    static const size_t v = [] {
+        size_t mb = 32;
+        if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) {
+            const long x = std::atol(s);
+            if (x >= 1 && x <= 1024) mb = (size_t)x;
+        }
+        return mb << 20;
+    }();
+    return v;
+}
 
 int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                      size_t clip_stride, int letterbox, uint64_t *out_hashes, uint32_t *out_crops, uint32_t *out_dontcare)
@@ -97,7 +109,11 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
     const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, kBatchBytes / cbytes));
+    const size_t kChunkBytes = chunk_bytes();
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, kChunkBytes / cbytes));  // clips per pinned chunk
+    // VDF_HOST_DIRECT=1 (experiments): packed input goes to the device with hipMemcpyAsync straight from the caller's
+    // pageable memory (the runtime stages it internally) instead of through the library's pinned chunks
+    static const bool direct_env = std::getenv("VDF_HOST_DIRECT") && std::atoi(std::getenv("VDF_HOST_DIRECT")) != 0;
     const bool packed = frame_stride == fbytes && clip_stride == cbytes;
     DevBuf *d_frames[2] = {&ctx->frames, &ctx->frames2}, *d_hash[2] = {&ctx->out_hashes, &ctx->out_hashes2},
            *d_dc[2] = {&ctx->out_dc, &ctx->out_dc2};
@@ -108,8 +124,8 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
         VDF_HIP(ctx, d_dc[i]->reserve(batch * 4));
         if (!ctx->pin_out[i].reserve(batch * (VDF_HASH_WORDS * 8 + 4))) return fail(ctx, VDF_E_OOM, "pinned result buffer");
     }
-    for (int i = 0; i < 2; i++)
-        if (!ctx->pin[i].reserve(chunk * cbytes)) return fail(ctx, VDF_E_OOM, "pinned staging buffer");
+    for (int i = 0; i < 2; i++)  // full-size chunks from the first call on: pinning memory is slow, do it once
+        if (!ctx->pin[i].reserve(std::max(kChunkBytes, chunk * cbytes))) return fail(ctx, VDF_E_OOM, "pinned staging buffer");
     CopyPool *pool = pool_of(ctx);
     hipStream_t s = ctx->stream, cs = ctx->copy_stream;
 
@@ -128,6 +144,11 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
             copy_out(b - 2);
         }
         // stage the batch chunk by chunk: threads fill pinned chunk p while the DMA of the other chunk is in flight
+        if (direct_env && packed) {
+            VDF_HIP(ctx, hipMemcpyAsync(d_frames[slot]->p, frames + c0 * clip_stride, nb * cbytes, hipMemcpyHostToDevice, cs));
+            VDF_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cs));
+            chunk_counter = 1;
+        } else
         for (size_t q0 = 0; q0 < nb; q0 += chunk, chunk_counter++) {
             const size_t nq = std::min(chunk, nb - q0);
             const int p = (int)(chunk_counter & 1);
