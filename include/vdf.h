@@ -250,14 +250,19 @@ int vdf_hash_frames_u8_shards(vdf_ctx *ctx, const uint8_t *const *d_frames, cons
  * The app hashes one file per rayon worker (vid_dup_finder_app/src/video_hash_filesystem_cache/
  * video_hash_filesystem_cache.rs:237-257 -> VideoHashBuilder::hash, video_hash_builder.rs:80-82,214-223).
  * vdf_hash_queue_submit may be called from any number of threads: the clips of concurrent callers are
- * hashed by ONE batched launch (the first caller of a batch waits up to max_wait_us for others or until
- * max_batch clips joined).  frames = 16 gray frames of w x h, tightly packed; blocks until the hash is
+ * hashed by batched launches (the first caller of a batch waits up to max_wait_us for others or until
+ * max_batch clips joined).  The queue keeps two batch slots per GPU of the context, each with pinned staging and a
+ * private context: while one batch is on the GPU the next one is already collecting (and may launch).
+ * frames = 16 gray frames of w x h, tightly packed; blocks until the hash is
  * there.  letterbox != 0 applies Cropdetect::Letterbox first (out_crop, nullable, gets the box). */
 typedef struct vdf_hash_queue vdf_hash_queue;
 int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_batch, uint32_t max_wait_us, int letterbox,
                           vdf_hash_queue **out);
 int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *out_hash, uint32_t *out_crop);
 int vdf_hash_queue_stats(vdf_hash_queue *q, uint64_t *n_batches, uint64_t *n_clips);
+/* The largest number of batches that were on the GPU(s) at the same time since the queue was created (>= 2 shows that a
+ * second batch was collected and launched while the first was still running). */
+int vdf_hash_queue_in_flight_max(vdf_hash_queue *q, uint32_t *out);
 void vdf_hash_queue_destroy(vdf_hash_queue *q);
 
 /* ---- the app's Sorting::Distance key (vid_dup_finder_app/src/app/search_output.rs:43-60) ----------

@@ -56,3 +56,40 @@ def test_single_caller_does_not_wait_for_a_full_batch(engine):
     with pytest.raises(ValueError):
         q.submit(frames[0][:, :16, :])
     q.close()
+
+
+def test_full_hd_callers_overlap_batches(engine):
+    """64 threads, one 1080p clip each (33 MB per clip: the staging copies dominate), 16 clips per batch: the queue's second
+    slot must collect - and launch - while the first batch is still on the GPU (in_flight_max >= 2), and every caller gets
+    exactly the batch API's hash."""
+    from vid_dup_finder_lib_amd.engine import HashQueue
+
+    rng = np.random.default_rng(3)
+    n, h, w = 64, 1080, 1920
+    base = rng.integers(0, 256, size=(4, 16, h, w), dtype=np.uint8)
+    frames = [np.roll(base[i % 4], shift=i, axis=2) for i in range(n)]  # 64 distinct clips without 2 GB of RNG output
+    want = np.concatenate([engine.hash_frames(np.stack(frames[i:i + 8])) for i in range(0, n, 8)])
+    q = HashQueue(engine, w, h, max_batch=16, max_wait_us=200000)
+    got = [None] * n
+    errs = []
+    start = threading.Barrier(n)
+
+    def worker(i):
+        try:
+            start.wait()
+            got[i] = q.submit(frames[i])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs and all(g is not None for g in got)
+    for i in range(n):
+        assert np.array_equal(got[i][0], want[i]), i
+    n_batches, n_clips = q.stats()
+    assert n_clips == n and n_batches <= n // 4
+    assert q.in_flight_max() >= 2
+    q.close()

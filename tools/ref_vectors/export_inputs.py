@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Flat little-endian copies of the committed fixture INPUTS for the Rust harness (ref_vectors.rs).
+hash_inputs.bin:   u32 n_cases, then per case: u32 name_len, name, u32 n_clips, n_frames, h, w, then n_clips*n_frames*h*w bytes.
+search_inputs.bin: u32 n, n*16 u64 hash words, n u32 durations, u32 n_ref, n_ref*16 u64, n_ref u32."""
+import os
+import struct
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tests", "golden")
+OUT = os.path.join(os.environ.get("VDF_VECTORS_DIR") or HERE, "inputs")
+os.makedirs(OUT, exist_ok=True)
+
+z = np.load(os.path.join(G, "hash_golden.npz"))
+names = sorted(k[: -len("_frames")] for k in z.files if k.endswith("_frames"))
+with open(os.path.join(OUT, "hash_inputs.bin"), "wb") as f:
+    f.write(struct.pack("<I", len(names)))
+    for name in names:
+        fr = np.ascontiguousarray(z[name + "_frames"], dtype=np.uint8)
+        nb = name.encode()
+        f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<IIII", *fr.shape))
+        f.write(fr.tobytes())
+s = np.load(os.path.join(G, "search_golden.npz"))
+with open(os.path.join(OUT, "search_inputs.bin"), "wb") as f:
+    for h, d in ((s["hashes"], s["durations"]), (s["ref_hashes"], s["ref_durations"])):
+        f.write(struct.pack("<I", len(d)))
+        f.write(np.ascontiguousarray(h, dtype="<u8").tobytes())
+        f.write(np.ascontiguousarray(d, dtype="<u4").tobytes())
+print("wrote", OUT, "cases:", names)

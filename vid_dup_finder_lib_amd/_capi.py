@@ -129,6 +129,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_void_p)]),
     "vdf_hash_queue_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdf_hash_queue_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vdf_hash_queue_in_flight_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "vdf_hash_queue_destroy": (None, [C.c_void_p]),
     "vdf_groups_max_distance": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(VdfGroups),
                                           C.c_void_p]),

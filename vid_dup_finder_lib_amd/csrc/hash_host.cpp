@@ -111,9 +111,11 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
     const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, kBatchBytes / cbytes));
     const size_t kChunkBytes = chunk_bytes();
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, kChunkBytes / cbytes));  // clips per pinned chunk
-    // VDF_HOST_DIRECT=1 (experiments): packed input goes to the device with hipMemcpyAsync straight from the caller's
-    // pageable memory (the runtime stages it internally) instead of through the library's pinned chunks
-    static const bool direct_env = std::getenv("VDF_HOST_DIRECT") && std::atoi(std::getenv("VDF_HOST_DIRECT")) != 0;
+    // Tightly packed input needs no gather: hipMemcpyAsync straight from the caller's pageable memory (the runtime stages
+    // it through its own pinned buffers) measured 54.5 GB/s against 53.7 for the library's pinned chunks - both at what
+    // the PCIe Gen5 x16 link delivers (tools/sweep_host_path.sh).  VDF_HOST_DIRECT=0 forces the library's staging;
+    // strided input (more than 16 frames per clip, padded frames) always takes it: only the wanted bytes cross the link.
+    static const bool direct_env = !(std::getenv("VDF_HOST_DIRECT") && std::atoi(std::getenv("VDF_HOST_DIRECT")) == 0);
     const bool packed = frame_stride == fbytes && clip_stride == cbytes;
     DevBuf *d_frames[2] = {&ctx->frames, &ctx->frames2}, *d_hash[2] = {&ctx->out_hashes, &ctx->out_hashes2},
            *d_dc[2] = {&ctx->out_dc, &ctx->out_dc2};

@@ -2,11 +2,16 @@
 //
 // The app hashes one file per rayon worker (vid_dup_finder_app/src/video_hash_filesystem_cache/
 // video_hash_filesystem_cache.rs:237-257 -> VideoHashBuilder::hash -> gen_hash, video_hash_builder.rs:214-223), which
-// would hand the GPU one clip per call.  A queue collects the clips of concurrent callers and runs ONE batched
-// launch: the first caller of a batch leads (waits up to max_wait_us for others to join or for the batch to fill,
-// runs the batch, publishes the results); the others block until their result is there.  Batches are serial:
-// GPU time per batch (microseconds to a few ms) is nothing next to decoding, the point is one launch per batch
-// instead of one per clip.  All clips of a queue have the same frame size (one queue per resolution).
+// would hand the GPU one clip per call.  The queue collects the clips of concurrent callers into batched launches.
+//
+// Slots: the queue owns two slots per GPU of the context (a multi-GPU context spreads the slots over its devices).  A
+// slot is one batch in the making: pinned staging for max_batch clips, a PRIVATE single-device context (own streams and
+// scratch, so batches of different slots run concurrently), and the state COLLECTING -> RUNNING -> DRAINING.  Arrivals
+// join the slot that is collecting; its first caller leads: it waits up to max_wait_us (from its own arrival) for others
+// or until the slot is full, closes the slot, hashes the batch, publishes the results.  The moment a slot closes the next
+// free slot starts collecting, so new arrivals copy their frames in - and may even start their own batch - while the
+// previous batch is still on the GPU (at 1080p a clip is 33 MB: the staging copies are the long part).  All clips of a
+// queue have the same frame size (one queue per resolution).
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -17,53 +22,75 @@
 
 #include "../../include/vdf.h"
 
-struct vdf_hash_queue {
-    vdf_ctx *ctx = nullptr;
-    uint32_t w = 0, h = 0, max_batch = 0, max_wait_us = 0;
-    int letterbox = 0;
-    size_t clip_bytes = 0;
+namespace {
+
+struct Slot {
+    vdf_ctx *ctx = nullptr;      // private context of this slot
     uint8_t *staging = nullptr;  // pinned host memory, max_batch clips of 16 frames
     bool pinned = false;
     std::vector<uint64_t> hashes;
     std::vector<uint32_t> crops;
-    std::mutex mu;
-    std::condition_variable cv;
     enum { COLLECTING, RUNNING, DRAINING } state = COLLECTING;
     uint32_t count = 0, ready = 0, remaining = 0;
     uint64_t gen = 0, done_gen = ~0ull;
     int batch_rc = VDF_OK;
+};
+
+}  // namespace
+
+struct vdf_hash_queue {
+    uint32_t w = 0, h = 0, max_batch = 0, max_wait_us = 0;
+    int letterbox = 0;
+    size_t clip_bytes = 0;
+    std::vector<Slot> slots;
+    size_t cur = 0;  // the slot new arrivals join
+    std::mutex mu;
+    std::condition_variable cv;
     uint64_t n_batches = 0, n_clips = 0;
+    uint32_t in_flight = 0, in_flight_max = 0;
 };
 
 extern "C" {
+
+void vdf_hash_queue_destroy(vdf_hash_queue *q)
+{
+    if (!q) return;
+    for (Slot &s : q->slots) {
+        if (s.staging) { if (s.pinned) (void)hipHostFree(s.staging); else std::free(s.staging); }
+        if (s.ctx) vdf_ctx_destroy(s.ctx);
+    }
+    delete q;
+}
 
 int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_batch, uint32_t max_wait_us, int letterbox,
                           vdf_hash_queue **out)
 {
     if (!ctx || !out || w == 0 || h == 0 || max_batch == 0) return VDF_E_INVAL;
+    *out = nullptr;
     vdf_hash_queue *q = new (std::nothrow) vdf_hash_queue();
     if (!q) return VDF_E_OOM;
-    q->ctx = ctx; q->w = w; q->h = h; q->max_batch = max_batch; q->max_wait_us = max_wait_us; q->letterbox = letterbox;
+    q->w = w; q->h = h; q->max_batch = max_batch; q->max_wait_us = max_wait_us; q->letterbox = letterbox;
     q->clip_bytes = (size_t)w * h * VDF_DCT_SIZE;
-    (void)hipSetDevice(vdf_ctx_device(ctx));
-    if (hipHostMalloc((void **)&q->staging, q->clip_bytes * max_batch, hipHostMallocDefault) == hipSuccess) {
-        q->pinned = true;
-    } else {
-        (void)hipGetLastError();
-        q->staging = (uint8_t *)std::malloc(q->clip_bytes * max_batch);
-        if (!q->staging) { delete q; return VDF_E_OOM; }
+    const int n_dev = vdf_ctx_device_count(ctx);
+    q->slots.resize((size_t)(2 * n_dev));
+    for (size_t k = 0; k < q->slots.size(); k++) {
+        Slot &s = q->slots[k];
+        const int dev = vdf_ctx_device_at(ctx, (int)(k % (size_t)n_dev));
+        int rc = vdf_ctx_create(dev, &s.ctx);
+        if (rc) { vdf_hash_queue_destroy(q); return rc; }
+        (void)hipSetDevice(dev);
+        if (hipHostMalloc((void **)&s.staging, q->clip_bytes * max_batch, hipHostMallocDefault) == hipSuccess) {
+            s.pinned = true;
+        } else {
+            (void)hipGetLastError();
+            s.staging = (uint8_t *)std::malloc(q->clip_bytes * max_batch);
+            if (!s.staging) { vdf_hash_queue_destroy(q); return VDF_E_OOM; }
+        }
+        s.hashes.resize((size_t)max_batch * VDF_HASH_WORDS);
+        s.crops.resize((size_t)max_batch * 4);
     }
-    q->hashes.resize((size_t)max_batch * VDF_HASH_WORDS);
-    q->crops.resize((size_t)max_batch * 4);
     *out = q;
     return VDF_OK;
-}
-
-void vdf_hash_queue_destroy(vdf_hash_queue *q)
-{
-    if (!q) return;
-    if (q->pinned) (void)hipHostFree(q->staging); else std::free(q->staging);
-    delete q;
 }
 
 // frames: 16 gray frames of w x h, tightly packed (the builder's output contract).  Blocks until hashed.
@@ -71,51 +98,65 @@ int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *ou
 {
     if (!q || !frames || !out_hash) return VDF_E_INVAL;
     std::unique_lock<std::mutex> lk(q->mu);
-    q->cv.wait(lk, [&] { return q->state == vdf_hash_queue::COLLECTING && q->count < q->max_batch; });
-    const uint32_t my = q->count++;
-    const uint64_t my_gen = q->gen;
+    // join the collecting slot; if it has closed (or is full), the next slot that is free to collect takes over
+    Slot *sp = nullptr;
+    q->cv.wait(lk, [&] {
+        for (size_t i = 0; i < q->slots.size(); i++) {
+            const size_t k = (q->cur + i) % q->slots.size();
+            Slot &c = q->slots[k];
+            if (c.state == Slot::COLLECTING && c.count < q->max_batch) { q->cur = k; sp = &c; return true; }
+        }
+        return false;
+    });
+    Slot &s = *sp;
+    const uint32_t my = s.count++;
+    const uint64_t my_gen = s.gen;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(q->max_wait_us);
     lk.unlock();
-    std::memcpy(q->staging + (size_t)my * q->clip_bytes, frames, q->clip_bytes);  // outside the lock: callers copy in parallel
+    std::memcpy(s.staging + (size_t)my * q->clip_bytes, frames, q->clip_bytes);  // outside the lock: callers copy in parallel
     lk.lock();
-    q->ready++;
+    s.ready++;
     if (my == 0) {
         // leader: give others until the deadline (counted from the first arrival) or until the batch is full
-        q->cv.wait_until(lk, deadline, [&] { return q->count == q->max_batch; });
-        q->state = vdf_hash_queue::RUNNING;                        // no more joins
-        q->cv.wait(lk, [&] { return q->ready == q->count; });      // every joined caller has finished its copy
-        const uint32_t n = q->count;
+        q->cv.wait_until(lk, deadline, [&] { return s.count == q->max_batch; });
+        s.state = Slot::RUNNING;                                   // no more joins here; arrivals move on to the next slot
+        q->cv.notify_all();
+        q->cv.wait(lk, [&] { return s.ready == s.count; });        // every joined caller has finished its copy
+        const uint32_t n = s.count;
+        q->in_flight++;
+        if (q->in_flight > q->in_flight_max) q->in_flight_max = q->in_flight;
         lk.unlock();
         int rc;
         if (q->letterbox)
-            rc = vdf_hash_frames_u8_letterbox(q->ctx, q->staging, n, VDF_DCT_SIZE, q->w, q->h, (size_t)q->w * q->h,
-                                              q->clip_bytes, q->hashes.data(), q->crops.data(), nullptr);
+            rc = vdf_hash_frames_u8_letterbox(s.ctx, s.staging, n, VDF_DCT_SIZE, q->w, q->h, (size_t)q->w * q->h,
+                                              q->clip_bytes, s.hashes.data(), s.crops.data(), nullptr);
         else
-            rc = vdf_hash_frames_u8(q->ctx, q->staging, n, VDF_DCT_SIZE, q->w, q->h, (size_t)q->w * q->h, q->clip_bytes,
-                                    q->hashes.data(), nullptr);
+            rc = vdf_hash_frames_u8(s.ctx, s.staging, n, VDF_DCT_SIZE, q->w, q->h, (size_t)q->w * q->h, q->clip_bytes,
+                                    s.hashes.data(), nullptr);
         lk.lock();
-        if (!q->letterbox) std::memset(q->crops.data(), 0, (size_t)n * 16);
-        q->batch_rc = rc;
-        q->done_gen = my_gen;
-        q->remaining = n;
-        q->state = vdf_hash_queue::DRAINING;
+        q->in_flight--;
+        if (!q->letterbox) std::memset(s.crops.data(), 0, (size_t)n * 16);
+        s.batch_rc = rc;
+        s.done_gen = my_gen;
+        s.remaining = n;
+        s.state = Slot::DRAINING;
         q->n_batches++;
         q->n_clips += n;
         q->cv.notify_all();
     } else {
         q->cv.notify_all();                                        // the leader may be waiting for count / ready
-        q->cv.wait(lk, [&] { return q->done_gen == my_gen && q->state == vdf_hash_queue::DRAINING; });
+        q->cv.wait(lk, [&] { return s.done_gen == my_gen && s.state == Slot::DRAINING; });
     }
-    const int rc = q->batch_rc;
+    const int rc = s.batch_rc;
     if (rc == VDF_OK) {
-        std::memcpy(out_hash, q->hashes.data() + (size_t)my * VDF_HASH_WORDS, VDF_HASH_WORDS * 8);
-        if (out_crop) std::memcpy(out_crop, q->crops.data() + (size_t)my * 4, 16);
+        std::memcpy(out_hash, s.hashes.data() + (size_t)my * VDF_HASH_WORDS, VDF_HASH_WORDS * 8);
+        if (out_crop) std::memcpy(out_crop, s.crops.data() + (size_t)my * 4, 16);
     }
-    if (--q->remaining == 0) {  // last one out reopens the queue
-        q->count = 0;
-        q->ready = 0;
-        q->gen++;
-        q->state = vdf_hash_queue::COLLECTING;
+    if (--s.remaining == 0) {  // last one out reopens the slot
+        s.count = 0;
+        s.ready = 0;
+        s.gen++;
+        s.state = Slot::COLLECTING;
         q->cv.notify_all();
     }
     return rc;
@@ -127,6 +168,14 @@ int vdf_hash_queue_stats(vdf_hash_queue *q, uint64_t *n_batches, uint64_t *n_cli
     std::lock_guard<std::mutex> lk(q->mu);
     if (n_batches) *n_batches = q->n_batches;
     if (n_clips) *n_clips = q->n_clips;
+    return VDF_OK;
+}
+
+int vdf_hash_queue_in_flight_max(vdf_hash_queue *q, uint32_t *out)
+{
+    if (!q || !out) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(q->mu);
+    *out = q->in_flight_max;
     return VDF_OK;
 }
 

@@ -381,6 +381,11 @@ class HashQueue:
         self.engine.lib.vdf_hash_queue_stats(self.q, C.byref(nb), C.byref(nc))
         return int(nb.value), int(nc.value)
 
+    def in_flight_max(self) -> int:
+        v = C.c_uint32(0)
+        self.engine.lib.vdf_hash_queue_in_flight_max(self.q, C.byref(v))
+        return int(v.value)
+
     def close(self):
         if getattr(self, "q", None):
             self.engine.lib.vdf_hash_queue_destroy(self.q)
