@@ -82,7 +82,10 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     vdf::SearchLaunch L{};
     const bool mfma = ctx->search_backend == 1;
-    L.tile_rows = mfma ? vdf::kMfmaRowPad : ctx->tile_rows;
+    // second-generation MFMA kernel: 512-row workgroups for search(); reference searches may take 256-row ones (a tile's
+    // candidate range is the union of its rows' duration windows: fewer rows, narrower union)
+    const bool gen2 = mfma && ctx->mfma_kernel == 2;
+    L.tile_rows = mfma ? (gen2 && mode == 1 ? ctx->mfma_refs_rows : vdf::kMfmaRowPad) : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     if (mfma && L.chunk_cols == 0) {
@@ -189,7 +192,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
 
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    if (mfma) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma(L, total_tiles, stream));
+    if (gen2) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma2(L, total_tiles, stream));
+    else if (mfma) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma(L, total_tiles, stream));
     else VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
     VDF_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     unsigned long long fin[8];
@@ -584,6 +588,8 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
         if (c >= 32 && c <= (1 << 22)) ctx->mfma_chunk_cols = (uint32_t)c;
     }
     if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
+    if (const char *s = std::getenv("VDF_MFMA_KERNEL")) { const int v = std::atoi(s); if (v == 1 || v == 2) ctx->mfma_kernel = v; }
+    if (const char *s = std::getenv("VDF_MFMA_REFS_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_refs_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_PRUNE_STEP")) ctx->mfma_prune_step = std::atoi(s);
     if (const char *s = std::getenv("VDF_MFMA_MIN_WGS")) { const long v = std::atol(s); if (v >= 1 && v <= (1 << 24)) ctx->mfma_min_wgs = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_GROUP")) {

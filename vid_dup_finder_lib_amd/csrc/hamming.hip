@@ -607,6 +607,257 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u * kRowTiles));
 }
 
+// ---- second-generation MFMA search kernel: branch-free main stream, flagged-block cleanup ------------------------
+// What the first kernel loses (profiles/r01_*): after the last MFMA of every 64 x 32 sub-tile the wave
+// drains the matrix pipe, runs the 19 dependent VALU ops of the early-exit test, branches, and refills its LDS pipeline -
+// and both waves of a SIMD (same workgroup, same barrier) reach that bubble together, so the pipe idles ~13 % of the time.
+// Here the main loop never branches and never waits for its own MFMAs:
+//   * a stage (kSub sub-tiles of 32 candidates) is cut into blocks (sub-tile, row tile) of K = CHK + 1 MFMAs that run
+//     one after the other, alternating between the wave's two row tiles: while block b accumulates into one accumulator
+//     set, the finished block b - 1 sits in the other and its test (max over 16 registers against the partial-distance
+//     bound, 8 v_max3 + a compare) issues in the shadow of block b's MFMAs.  Each B fragment is read from LDS twice
+//     (once per row tile: 1 ds_read_b128 per MFMA, half of what the LDS array sustains) instead of being held;
+//   * the test only sets a bit in a scalar mask.  Blocks whose bit is set (they may contain a pair within the
+//     tolerance: ~0.5 % on unrelated hashes) are recomputed over all 1024 bits by a cleanup pass after every pair of
+//     stages - operands straight from global memory, so it needs neither the LDS image nor the register-resident
+//     targets - which applies window / consumption bitmap / append exactly like the first kernel's slow path;
+//   * LDS reads run P fragments ahead in ONE stream across block boundaries, DMA pieces of the next stage are spread
+//     over the stage, everything pinned with sched_group_barrier.
+// Exactness is unchanged: a block is skipped only if every pair in it is already more than `tol` apart after 64 K bits.
+template <int N>
+struct IntC { static constexpr int value = N; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float max16(const v16f &c)
+{  // a tree, not a chain: five independent v_max3 first
+    const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+    const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+}
+
+template <int CHK, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
+    const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
+    uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
+    const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
+    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ group_offset, const uint32_t *__restrict__ group_cmin, uint32_t n_groups,
+    uint32_t group_size, uint32_t shard_index, uint32_t shard_count, uint32_t n_row_tiles, uint32_t chunk_cols,
+    uint32_t tol, const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits,
+    unsigned long long capacity, unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row,
+    uint32_t block_base)
+{
+    constexpr int K = CHK < 15 ? CHK + 1 : 16;            // k-steps of the main stream (64 bit positions each)
+    constexpr uint32_t kSub = WAVES >= 8 ? 4 : 2;         // 32-candidate sub-tiles per LDS stage
+    constexpr uint32_t kColStep = 32 * kSub;
+    constexpr int NBLK = 2 * (int)kSub;                   // blocks per stage and wave: (sub-tile, row tile)
+    constexpr int NM = NBLK * K;                          // MFMAs per stage and wave
+    constexpr int P = 4, NB = P + 2;                      // LDS fragments in flight / fragment buffers
+    constexpr uint32_t kTileRows = 64 * WAVES;
+    constexpr int kDmaPerWave = (int)(kColStep * 32 / (64 * WAVES));  // 1 KB LDS-DMA pieces per wave and stage
+    constexpr int kDmaEvery = NM / kDmaPerWave;
+    static_assert(kDmaEvery >= 2, "stage too short for its DMA pieces");
+    constexpr int kTestAt = 2;                            // the previous block's test issues under MFMAs kTestAt .. kTestAt + 3 of a block
+    static_assert(K >= kTestAt + 4, "block too short to hide the previous block's test");
+    const uint32_t bid = blockIdx.x + block_base;
+    __shared__ __attribute__((aligned(16))) uint4 s_b0[kColStep * 32];
+    __shared__ __attribute__((aligned(16))) uint4 s_b1[kColStep * 32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c31 = lane & 31;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // scalar: LDS-DMA targets (M0) need no VALU
+
+    // workgroup -> (group, chunk, row tile in group): chunk-major inside a group (as the first kernel)
+    const_u32_ptr goff = (const_u32_ptr)(uintptr_t)group_offset;
+    uint32_t gl = 0, gh = n_groups;
+    while (gh - gl > 1) {
+        const uint32_t mid = (gl + gh) >> 1;
+        if (goff[mid] <= bid) gl = mid; else gh = mid;
+    }
+    const uint32_t idx = bid - goff[gl];
+    const uint32_t per_group = (group_size + shard_count - 1) / shard_count;
+    const uint32_t g0 = gl * group_size;
+    const uint32_t t0 = g0 + (shard_index + shard_count - g0 % shard_count) % shard_count;
+    const uint32_t t = t0 + (idx % per_group) * shard_count;
+    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + idx / per_group;
+    if (t >= n_row_tiles || t >= g0 + group_size) return;
+    {
+        const uint32_t f = ((const_u32_ptr)(uintptr_t)tile_first)[t], cnt = ((const_u32_ptr)(uintptr_t)tile_count)[t];
+        if (chunk < f || chunk >= f + cnt) return;
+    }
+    const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
+    const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
+    const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
+    const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
+    if (c_begin >= c_end) return;
+
+    // targets: 2 row tiles of 32 per wave, all 16 k-steps in registers
+    const uint32_t row0 = t * kTileRows + wave * 64;
+    v4i a[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++) {
+        const uint32_t p = row0 + 32 * rt + c31;
+        uint32_t src = p;
+        if (p < n_rows && row_perm) src = row_perm[p];
+        const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;  // rows >= n_rows read the zero padding
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const uint4 v = rp[s];
+            a[rt][s] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        }
+    }
+    const float tol_f = (float)min(tol, 1024u);
+    const float thresh = 1024.0f - 2.0f * tol_f;
+    const float thresh_chk = 64.0f * (float)K - 2.0f * tol_f;  // partial dot >= this <=> partial distance <= tol
+
+    // LDS-DMA staging, identical to the first kernel: slot (col << 5 | q) holds chunk q ^ col of that column
+    const uint32_t cb0 = c_begin & ~(kColStep - 1);
+    constexpr uint32_t kColsPerRound = 2 * WAVES;
+    constexpr int kOffsets = 32 / kColsPerRound;
+    static_assert(kOffsets >= 1 && (kOffsets & (kOffsets - 1)) == 0, "piece addressing");
+    const uint32_t c0 = 2 * wave + g;
+    uint32_t lane_off[kOffsets];
+#pragma unroll
+    for (int j = 0; j < kOffsets; j++) lane_off[j] = c0 * 512u + ((((lane & 31) ^ c0) << 4) ^ (16u * kColsPerRound * j));
+    auto stage_rsrc = [&](uint32_t cb) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512), 0, kColStep * 512u, 0x00020000);
+    };
+    auto load_piece = [&](__amdgpu_buffer_rsrc_t rs, uint4 *dst, int i) __attribute__((always_inline)) {
+        auto *lds = (__attribute__((address_space(3))) void *)&dst[64 * WAVES * i + 64 * wave];
+        const int voff = (int)lane_off[i & (kOffsets - 1)], soff = (int)(512u * kColsPerRound * (uint32_t)i);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
+    };
+
+    v16f acc[2] = {v16f{}, v16f{}};
+    uint32_t n_early = 0;  // blocks that stopped after K steps
+
+    // One stage: NBLK blocks of K MFMAs over the candidates in `cur`; DMA of the next stage into `nxt`.
+    // Returns the mask of blocks that need the full evaluation (bit = block index).
+    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) -> uint32_t {
+        const __amdgpu_buffer_rsrc_t rs_next = stage_rsrc(cb + kColStep < c_end ? cb + kColStep : cb);
+        uint32_t flags = 0;
+        uint4 fq[NB];
+        auto frag = [&](int i) __attribute__((always_inline)) {  // fragment of stream position i: block i / K, step i % K
+            const uint32_t sub = (uint32_t)((i / K) >> 1), s = (uint32_t)(i % K);
+            return cur[((32u * sub + c31) << 5) | ((s + 16u * g) ^ c31)];
+        };
+#pragma unroll
+        for (int i = 0; i < P; i++) fq[i] = frag(i);
+        __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+        // The source order below IS the schedule: one slot = one MFMA + the LDS read P fragments ahead + at most one DMA
+        // piece + a quarter of the previous block's test; sched_barrier(0) between slots keeps the machine scheduler from
+        // moving anything across (left alone it sinks every read next to its MFMA and bunches the VALU work).
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f;
+        static_for<0, NM>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int blk = i / K, s = i % K, rt = blk & 1;
+            const uint4 bv = fq[i % NB];
+            const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
+            const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
+            if constexpr (s == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, v16f{}, 4, 4, 0, 127, 0, 127);
+            else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
+            if constexpr (i + P < NM) fq[(i + P) % NB] = frag(i + P);
+            if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) load_piece(rs_next, nxt, i / kDmaEvery);
+            // the block that finished kTestAt MFMAs ago sits in the other accumulator set: max over its 16 registers as a
+            // tree, two or three v_max3 per slot
+            if constexpr (blk >= 1) {
+                const v16f &c = acc[rt ^ 1];
+                if constexpr (s == kTestAt) {
+                    m0 = fmaxf(fmaxf(c[0], c[1]), c[2]); m1 = fmaxf(fmaxf(c[3], c[4]), c[5]); m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+                } else if constexpr (s == kTestAt + 1) {
+                    m3 = fmaxf(fmaxf(c[9], c[10]), c[11]); m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+                } else if constexpr (s == kTestAt + 2) {
+                    m5 = fmaxf(fmaxf(m0, m1), m2); m3 = fmaxf(fmaxf(m3, m4), c[15]);
+                } else if constexpr (s == kTestAt + 3) {
+                    if (__builtin_amdgcn_ballot_w64(fmaxf(m5, m3) >= thresh_chk) != 0ull) flags |= 1u << (blk - 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        {   // the last block of the stage has nothing of its own stage to hide behind
+            const float pm = max16(acc[(NBLK - 1) & 1]);
+            if (__builtin_amdgcn_ballot_w64(pm >= thresh_chk) != 0ull) flags |= 1u << (NBLK - 1);
+        }
+        // blocks of sub-tiles at or beyond the end of the chunk hold nothing
+        uint32_t valid = 0;
+#pragma unroll
+        for (uint32_t sub = 0; sub < kSub; sub++)
+            if (cb + 32u * sub < c_end) valid |= 3u << (2 * sub);
+        flags &= valid;
+        n_early += (uint32_t)__builtin_popcount(valid & ~flags);
+        __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
+        return flags;
+    };
+
+    // Full evaluation of the flagged blocks (rare).  bit = half * NBLK + block; operands from global memory.
+    auto cleanup = [&](uint32_t bits, uint32_t cb) __attribute__((always_inline)) {
+        while (bits) {
+            const uint32_t bi = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t half = bi / NBLK, blk = bi % NBLK, sub = blk >> 1, rt = blk & 1;
+            const uint32_t col0 = cb + half * kColStep + 32u * sub;
+            const uint32_t p = row0 + 32 * rt + c31;
+            uint32_t src = p;
+            if (p < n_rows && row_perm) src = row_perm[p];
+            const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;
+            const uint4 *cp = col_exp + (size_t)(col0 + c31) * 32 + 16 * g;  // padded: never past the buffer
+            v16f d = {};
+#pragma unroll 4
+            for (int s = 0; s < 16; s++) {
+                const uint4 av = rp[s], bv = cp[s];
+                const v8i ar = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
+                const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
+                d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, d, 4, 4, 0, 127, 0, 127);
+            }
+            const uint32_t j = col0 + c31;
+            bool col_ok = j >= c_begin && j < c_end;
+            if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (col_ok && d[r] >= thresh) {
+                    const uint32_t pr = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const uint32_t lo = row_lo[pr], hi = row_hi[pr];
+                    if (j >= lo && j < hi) {
+                        const uint32_t sr = row_perm ? row_perm[pr] : pr;
+                        bool ok = true;
+                        if (self_mode && matched) ok = ((matched[sr >> 5] >> (sr & 31)) & 1u) == 0u;
+                        if (ok) {
+                            const unsigned long long at = atomicAdd(&counters[0], 1ull);
+                            if (at < capacity) {
+                                vdf_hit hp; hp.row = row_index_base + sr; hp.col = j;
+                                hits[at] = hp;
+                            } else {
+                                atomicMin(overflow_row, row_index_base + sr);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < kDmaPerWave; i++) load_piece(stage_rsrc(cb0), s_b0, i);
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int s = 0; s < 16; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
+    __syncthreads();
+    for (uint32_t cb = cb0; cb < c_end; cb += 2 * kColStep) {
+        uint32_t flags = run_stage(cb, s_b0, s_b1);
+        flags |= run_stage(cb + kColStep, s_b1, s_b0) << NBLK;  // past the end of the chunk: all blocks masked out
+        if (flags) cleanup(flags, cb);
+    }
+    if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kTileRows);
+    if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u));
+}
+
 hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,
                                 const uint32_t *row_perm, uint32_t n_rows, uint32_t row_begin, uint32_t row_end,
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L, hipStream_t stream)
@@ -716,6 +967,38 @@ hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad,
     hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, kMaxBlocksPerLaunch)), dim3(256), 0, stream, packed, n, n_pad,
                        reinterpret_cast<uint4 *>(expanded));
     return hipGetLastError();
+}
+
+hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)
+{
+    if (total_tiles == 0) return hipSuccess;
+    if (L.tile_rows != 512 && L.tile_rows != 256) return hipErrorInvalidValue;
+    for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
+        const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
+#define VDF_MFMA2_LAUNCH(CK, WV)                                                                                    \
+    hipLaunchKernelGGL((hamming_mfma2_kernel<CK, WV>), dim3(nb), dim3(64 * WV), 0, stream,                           \
+                       reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,           \
+                       reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
+                       L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
+                       L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
+                       L.hits, L.capacity, L.counters, L.overflow_row, base)
+#define VDF_MFMA2_STEPS(WV)                                                                                         \
+    switch (L.prune_step) { /* smallest instantiated step >= the requested one */                                   \
+    case 0: case 1: case 2: case 3: case 4: case 5: case 6: VDF_MFMA2_LAUNCH(6, WV); break;                          \
+    case 7: case 8: VDF_MFMA2_LAUNCH(8, WV); break;                                                                  \
+    case 9: case 10: VDF_MFMA2_LAUNCH(10, WV); break;                                                                \
+    case 11: VDF_MFMA2_LAUNCH(11, WV); break;                                                                        \
+    case 12: VDF_MFMA2_LAUNCH(12, WV); break;                                                                        \
+    case 13: VDF_MFMA2_LAUNCH(13, WV); break;                                                                        \
+    default: VDF_MFMA2_LAUNCH(16, WV); break;                                                                        \
+    }
+        if (L.tile_rows == 512) { VDF_MFMA2_STEPS(8) } else { VDF_MFMA2_STEPS(4) }
+#undef VDF_MFMA2_STEPS
+#undef VDF_MFMA2_LAUNCH
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)

@@ -64,6 +64,7 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
 constexpr uint32_t kMfmaRowPad = 32 * VDF_ROW_TILES * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
+hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream + cleanup; tile_rows 512 or 256
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
                                      const unsigned long long *members, const uint32_t *ref_hashes,
                                      const long long *ref_index, uint32_t n_groups, uint32_t *out, hipStream_t stream);
