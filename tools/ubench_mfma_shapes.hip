@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const uint4 *__restrict__ da
                 acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bb, acc1, 4, 4, 0, 127, 0, 127);
             }
             m = fmaxf(m, fmaxf(acc0[0], acc1[5]));
+        } else if constexpr (SHAPE == 2) {  // the same 32 MFMAs as two SEQUENTIAL dependent chains (one accumulator at a time)
+            v16f acc0 = {}, acc1 = {};
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const v8i bb = {b[s & 7].x, b[s & 7].y, b[s & 7].z, b[s & 7].w, 0, 0, 0, 0};
+                const v8i a0 = {a[s].x, a[s].y, a[s].z, a[s].w, 0, 0, 0, 0};
+                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, bb, acc0, 4, 4, 0, 127, 0, 127);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const v8i bb = {b[s & 7].x, b[s & 7].y, b[s & 7].z, b[s & 7].w, 0, 0, 0, 0};
+                const v8i a1 = {a[16 + s].x, a[16 + s].y, a[16 + s].z, a[16 + s].w, 0, 0, 0, 0};
+                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, bb, acc1, 4, 4, 0, 127, 0, 127);
+            }
+            m = fmaxf(m, fmaxf(acc0[0], acc1[5]));
         } else {
             v4f acc[4][2] = {};
 #pragma unroll
@@ -83,9 +98,10 @@ int main(int argc, char **argv)
     hipMemcpy(d, h.data(), n_vec * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++)
-        for (int shape = 0; shape < 2; shape++) {
+        for (int shape = 0; shape < 3; shape++) {
             auto launch = [&](uint32_t n) {
                 if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(n_wg), dim3(256), 0, 0, d, n, o);
+                else if (shape == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(n_wg), dim3(256), 0, 0, d, n, o);
                 else hipLaunchKernelGGL(mfma_loop<1>, dim3(n_wg), dim3(256), 0, 0, d, n, o);
             };
             launch(iters / 10);
@@ -97,7 +113,7 @@ int main(int argc, char **argv)
             const double units_per_simd = 2.0 * iters;  // 2 waves per SIMD, one 64 x 32 x 1024 unit per iteration
             const double pairs = (double)n_cu * 4 * units_per_simd * 64.0 * 32.0 / (ms * 1e-3);
             printf("rep %d shape %s: %.1f ms  %.1f ns per 1024-cycle unit (%.3f GHz-equivalent)  -> %.3e Hamming pairs/s chip-wide\n",
-                   rep, shape == 0 ? "32x32x64 " : "16x16x128", ms, ms * 1e6 / units_per_simd, 1024.0 / (ms * 1e6 / units_per_simd), pairs);
+                   rep, shape == 0 ? "32x32x64 interleaved" : shape == 2 ? "32x32x64 sequential " : "16x16x128           ", ms, ms * 1e6 / units_per_simd, 1024.0 / (ms * 1e6 / units_per_simd), pairs);
         }
     return 0;
 }

@@ -28,7 +28,7 @@ vdf_ctx::~vdf_ctx()
         delete kv.second;
     }
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
-                     &hits, &perm, &matched, &exp_cols, &exp_rows, &group_cmin, &group_offset, &group_blocks, &up_hashes,
+                     &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
                      &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables};
     for (DevBuf *b : all) b->release();
@@ -162,18 +162,31 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         L.group_blocks = ctx->group_blocks.as<uint32_t>();
         L.group_cmin = ctx->group_cmin.as<uint32_t>();
         L.group_offset = ctx->group_offset.as<uint32_t>();
-        // expand both operands to +-1 fp4 (512 B per hash); rows share the column copy in self mode
+        // expand both operands to fp4 nibbles (512 B per hash); rows share the column copy in self mode.  The second-
+        // generation kernel takes {0, 1} nibbles plus popcount arrays, the first one +-1 nibbles.
+        const int mode01 = gen2 ? 1 : 0;
+        const uint32_t k_steps = (uint32_t)(L.prune_step < 15 ? L.prune_step + 1 : 16);  // k-steps of the tested prefix
         const uint32_t col_pad = (uint32_t)((n_cols + vdf::kMfmaRowPad - 1) / vdf::kMfmaRowPad * vdf::kMfmaRowPad) + vdf::kMfmaColPad;
         VDF_HIP(ctx, ctx->exp_cols.reserve((size_t)col_pad * 512));
-        VDF_HIP(ctx, vdf::launch_expand_fp4(L.col_hashes, (uint32_t)n_cols, col_pad, ctx->exp_cols.p, stream));
+        if (gen2) VDF_HIP(ctx, ctx->pop_cols.reserve((size_t)col_pad * 12));
+        VDF_HIP(ctx, vdf::launch_expand_fp4(L.col_hashes, (uint32_t)n_cols, col_pad, ctx->exp_cols.p, mode01, k_steps,
+                                            gen2 ? ctx->pop_cols.as<float>() : nullptr, stream));
         L.col_exp = ctx->exp_cols.p;
+        L.col_pop3 = gen2 ? ctx->pop_cols.as<float>() : nullptr;
+        L.col_pad = col_pad;
         if (d_row_hashes == d_col_hashes) {
             L.row_exp = ctx->exp_cols.p;
+            L.row_pop3 = L.col_pop3;
+            L.row_pad = col_pad;
         } else {
-            const uint32_t row_pad = (uint32_t)padded_rows;
+            const uint32_t row_pad = (uint32_t)((padded_rows + 127) / 128 * 128);
             VDF_HIP(ctx, ctx->exp_rows.reserve((size_t)row_pad * 512));
-            VDF_HIP(ctx, vdf::launch_expand_fp4(L.row_hashes, (uint32_t)n_rows, row_pad, ctx->exp_rows.p, stream));
+            if (gen2) VDF_HIP(ctx, ctx->pop_rows.reserve((size_t)row_pad * 12));
+            VDF_HIP(ctx, vdf::launch_expand_fp4(L.row_hashes, (uint32_t)n_rows, row_pad, ctx->exp_rows.p, mode01, k_steps,
+                                                gen2 ? ctx->pop_rows.as<float>() : nullptr, stream));
             L.row_exp = ctx->exp_rows.p;
+            L.row_pop3 = gen2 ? ctx->pop_rows.as<float>() : nullptr;
+            L.row_pad = row_pad;
         }
     }
     // counters[0..2] = 0, overflow_row = UINT32_MAX
@@ -186,10 +199,29 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
                                 hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipMemcpyAsync(&unsorted, L.counters + 5, 8, hipMemcpyDeviceToHost, stream));
+    unsigned long long admitted = 0;
+    VDF_HIP(ctx, hipMemcpyAsync(&admitted, L.counters + 2, 8, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
     // the windows are binary searches over the candidate durations (search_algorithm.rs:93-117,173-185 rely on Search::sort)
     if (unsorted) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
+    if (gen2) {
+        // Queue of suspect pairs the stream cannot rule out (16-byte entries).  Unrelated hashes put ~2.3e-6 of the admitted
+        // pairs there at the 4-sigma test point; slots are handed out in chunks of 8 per wave, so every wave may strand
+        // a few.  Sized generously from the admitted pairs; if it still overflows, the hit-buffer overflow protocol takes
+        // over (rows below the smallest row that lost a suspect are complete).
+        const uint64_t want = (uint64_t)((double)admitted * 6e-6) + (uint64_t)total_tiles * 8 * 8 + std::max<uint64_t>(capacity, 1ull << 20);
+        L.cand_capacity = (uint32_t)std::min<uint64_t>(want, 0x40000000ull);
+        const void *before = ctx->cand.p;
+        VDF_HIP(ctx, ctx->cand.reserve((size_t)L.cand_capacity * 16));
+        if (ctx->cand.p != before) ctx->cand_dirty = SIZE_MAX;  // fresh allocation: fill all of it
+        // only the slots the previous launch may have touched need the empty pattern (0xFF) again
+        const size_t fill = ctx->cand_dirty == SIZE_MAX ? ctx->cand.cap / 16 * 16 : std::min<size_t>((size_t)L.cand_capacity, ctx->cand_dirty) * 16;
+        if (fill) VDF_HIP(ctx, hipMemsetAsync(ctx->cand.p, 0xFF, fill, stream));
+        ctx->cand_dirty = 0;
+        L.cand = ctx->cand.p;
+        L.cand_head = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 6);
+    }
 
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     if (gen2) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma2(L, total_tiles, stream));
@@ -202,6 +234,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     float ms = 0.f;
     VDF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
 
+    if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6] & 0xFFFFFFFFull, L.cand_capacity);  // slots this launch used
     const uint64_t produced = fin[0];
     const uint64_t stored = std::min<uint64_t>(produced, capacity);
     if (stored) {

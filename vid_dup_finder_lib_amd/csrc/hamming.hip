@@ -332,15 +332,26 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 // packed [n][32] u32  ->  expanded [n_pad][32 chunks][16 B]: chunk d = the 32 nibbles of packed dword d
 // (nibble q <-> bit q).  Rows n .. n_pad are zero (fp4 +0.0: dot 0, never inside a window).
+// mode01 = 0: bit 0 -> 0x2 (+1.0), bit 1 -> 0xA (-1.0): dot = 1024 - 2 hamming (first kernel).
+// mode01 = 1: bit 0 -> 0x0 (0.0), bit 1 -> 0x2 (+1.0): dot = popcount(a & b), hamming = pop(a) + pop(b) - 2 dot.  Same exact
+//   integers, but three quarters of the products are zero and nothing is negative: measured 10 % less time per MFMA at
+//   the chip's power cap (tools/ubench_mfma_energy.hip), which is what bounds this kernel.  The popcounts the threshold
+//   then needs are written here: pop[h] over all 1024 bits, popk[h] over the bits the first k_steps k-steps of the kernel
+//   cover (k-step s multiplies packed dwords s and 16 + s: the two halves of the wave take chunks s and 16 + s),
+//   and popkT = popk transposed inside groups of 128 hashes ([group][h & 31][(h >> 5) & 3]) so that a lane fetches the
+//   values of its column in the four 32-column sub-tiles of a stage with one 16-byte load.
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ packed, uint32_t n,
-                                                        uint32_t n_pad, uint4 *__restrict__ expanded)
+                                                        uint32_t n_pad, uint4 *__restrict__ expanded, int mode01,
+                                                        uint32_t k_steps, float *__restrict__ pop,
+                                                        float *__restrict__ popk, float *__restrict__ popkT)
 {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)n_pad * 32;
          idx += (size_t)gridDim.x * 256) {  // (hash, dword), grid-stride: the grid is capped under HIP's 2^32 limit
-    const uint32_t hsh = (uint32_t)(idx >> 5);
+    const uint32_t hsh = (uint32_t)(idx >> 5), dw = (uint32_t)idx & 31u;
     uint4 out = {0u, 0u, 0u, 0u};
+    uint32_t w = 0;
     if (hsh < n) {
-        const uint32_t w = packed[idx];
+        w = packed[idx];
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -348,11 +359,21 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
             x = (x | (x << 12)) & 0x000F000Fu;
             x = (x | (x << 6)) & 0x03030303u;
             x = (x | (x << 3)) & 0x11111111u;
-            o[j] = (x << 3) | 0x22222222u;                // bit 0 -> 0x2 (+1.0), bit 1 -> 0xA (-1.0)
+            o[j] = mode01 ? (x << 1) : ((x << 3) | 0x22222222u);
         }
         out = make_uint4(o[0], o[1], o[2], o[3]);
     }
     expanded[idx] = out;
+    if (pop) {  // the 32 dwords of a hash sit in 32 consecutive lanes (n_pad is a multiple of 128: no partial waves)
+        uint32_t pc = (uint32_t)__builtin_popcount(w), pk = (dw & 15u) < k_steps ? pc : 0u;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { pc += (uint32_t)__shfl_xor((int)pc, o, 32); pk += (uint32_t)__shfl_xor((int)pk, o, 32); }
+        if (dw == 0) {
+            pop[hsh] = (float)pc;
+            popk[hsh] = (float)pk;
+            popkT[(size_t)(hsh >> 7) * 128 + (hsh & 31u) * 4 + ((hsh >> 5) & 3u)] = (float)pk;
+        }
+    }
     }
 }
 
@@ -607,22 +628,28 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u * kRowTiles));
 }
 
-// ---- second-generation MFMA search kernel: branch-free main stream, flagged-block cleanup ------------------------
-// What the first kernel loses (profiles/r01_*): after the last MFMA of every 64 x 32 sub-tile the wave
-// drains the matrix pipe, runs the 19 dependent VALU ops of the early-exit test, branches, and refills its LDS pipeline -
-// and both waves of a SIMD (same workgroup, same barrier) reach that bubble together, so the pipe idles ~13 % of the time.
-// Here the main loop never branches and never waits for its own MFMAs:
-//   * a stage (kSub sub-tiles of 32 candidates) is cut into blocks (sub-tile, row tile) of K = CHK + 1 MFMAs that run
-//     one after the other, alternating between the wave's two row tiles: while block b accumulates into one accumulator
-//     set, the finished block b - 1 sits in the other and its test (max over 16 registers against the partial-distance
-//     bound, 8 v_max3 + a compare) issues in the shadow of block b's MFMAs.  Each B fragment is read from LDS twice
-//     (once per row tile: 1 ds_read_b128 per MFMA, half of what the LDS array sustains) instead of being held;
-//   * the test only sets a bit in a scalar mask.  Blocks whose bit is set (they may contain a pair within the
-//     tolerance: ~0.5 % on unrelated hashes) are recomputed over all 1024 bits by a cleanup pass after every pair of
-//     stages - operands straight from global memory, so it needs neither the LDS image nor the register-resident
-//     targets - which applies window / consumption bitmap / append exactly like the first kernel's slow path;
-//   * LDS reads run P fragments ahead in ONE stream across block boundaries, DMA pieces of the next stage are spread
-//     over the stage, everything pinned with sched_group_barrier.
+// ---- second-generation MFMA search kernel ----------------------------------------------------------------------
+// Two findings of round 2 shape it (profiles/r02_*, DESIGN.md "Hamming search"):
+//  (1) The first kernel does not run at the matrix pipe's issue rate but at the chip's POWER cap: a stream with 87 % pipe
+//      utilisation and one with 81 % take the same wall time, the chip just holds a lower clock.  What decides pairs/s is
+//      the energy per pair, and that depends on the operand VALUES: with hash bits encoded as {0, 1} instead of {-1, +1}
+//      (dot = popcount(a & b); three quarters of the products are zero, nothing is negative) the same MFMA stream takes
+//      10 % less time; the unscaled opcode (v_mfma_f32_32x32x64_f8f6f4, no E8M0 scale operands) another 1 %
+//      (tools/ubench_mfma_energy.hip).  With pa, pb the popcounts:  hamming = pa + pb - 2 dot.  The row term goes in as
+//      the C operand of a block's first MFMA (acc = dot - paK / 2, a persistent register vector per row tile), the
+//      column term into a per-lane threshold ((pbK - tol) / 2: the C layout has one column per lane), so the test is still
+//      one max over the accumulators and one compare: partial distance <= tol <=> acc >= (pbK - tol) / 2.  All values are
+//      half-integers below 2^11: exact in f32.
+//  (2) Once the clock is no longer the limit the pipe's idle cycles count again, so the stream is branch-free: a stage
+//      (kSub sub-tiles of 32 candidates) is cut into blocks (sub-tile, row tile) of K = CHK + 1 MFMAs that run one after
+//      the other, alternating between the wave's two row tiles; while block b accumulates into one accumulator set the
+//      finished block b - 1 sits in the other and its test (8 v_max3 + a compare) issues in the shadow of block b's MFMAs.
+//      Each B fragment is read from LDS twice (once per row tile: 1 ds_read_b128 per MFMA, half of what the LDS array
+//      sustains).  The test only sets a bit in a scalar mask; flagged blocks (they may contain a pair within the
+//      tolerance: ~0.3 % on unrelated hashes) are evaluated over all 1024 bits at the end of the stage - operands from
+//      the LDS image and the target registers - where window / consumption bitmap / append are applied as in the first
+//      kernel's slow path.  LDS reads run P fragments ahead in ONE stream across block boundaries; sched_barrier(0)
+//      between slots makes the source order the schedule.
 // Exactness is unchanged: a block is skipped only if every pair in it is already more than `tol` apart after 64 K bits.
 template <int N>
 struct IntC { static constexpr int value = N; };
@@ -635,11 +662,66 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-__device__ __forceinline__ float max16(const v16f &c)
-{  // a tree, not a chain: five independent v_max3 first
-    const float m0 = fmaxf(fmaxf(c[0], c[1]), c[2]), m1 = fmaxf(fmaxf(c[3], c[4]), c[5]), m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
-    const float m3 = fmaxf(fmaxf(c[9], c[10]), c[11]), m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
-    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+// Second pass of the second-generation MFMA search.  A block of the stream that cannot be ruled out after K k-steps
+// (~0.3 % on unrelated hashes) names its suspects: per lane (= candidate column) the 16-bit mask of accumulator registers
+// (= target rows) whose partial distance is still within the tolerance - typically ONE pair of the block's 1024.  The
+// stream appends them to a queue (slots come in per-wave chunks, so appending costs no round trip) and moves on; this
+// kernel evaluates each suspect pair exactly - XOR + popcount over all 16 words of the PACKED hashes, as
+// VideoHash::hamming_distance does (video_hash.rs:311-317) - and applies window / consumption bitmap / append like the
+// reference's loop (search_algorithm.rs:150-156, :67-74).  One lane per queue entry.
+struct CandEntry {
+    uint32_t row_base;  // position (tile order) of the row of accumulator register 0 for this lane group; 0xFFFFFFFF = empty slot
+    uint32_t col;
+    uint32_t mask;      // bit r set: register r, i.e. row row_base + (r & 3) + 8 (r >> 2)
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void resolve_candidates_kernel(
+    const CandEntry *__restrict__ cand, const uint32_t *__restrict__ cand_head, uint32_t cand_capacity,
+    const uint32_t *__restrict__ row_hashes, const uint32_t *__restrict__ row_perm, uint32_t n_rows, uint32_t row_index_base,
+    const uint32_t *__restrict__ col_hashes, uint32_t n_cols, const uint32_t *__restrict__ row_lo,
+    const uint32_t *__restrict__ row_hi, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
+    vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ overflow_row)
+{
+    const uint32_t n = min(*cand_head, cand_capacity);
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const CandEntry ce = cand[e];
+        if (ce.row_base == 0xFFFFFFFFu || ce.col >= n_cols) continue;
+        if (matched && ((matched[ce.col >> 5] >> (ce.col & 31)) & 1u)) continue;
+        const uint4 *cp = reinterpret_cast<const uint4 *>(col_hashes + (size_t)ce.col * 32);
+        uint4 cw[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cw[q] = cp[q];
+        uint32_t m = ce.mask;
+        while (m) {
+            const uint32_t r = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t p = ce.row_base + (r & 3) + 8 * (r >> 2);
+            if (p >= n_rows) continue;
+            const uint32_t lo = row_lo[p], hi = row_hi[p];
+            if (ce.col < lo || ce.col >= hi) continue;
+            const uint32_t src = row_perm ? row_perm[p] : p;
+            if (self_mode && matched && ((matched[src >> 5] >> (src & 31)) & 1u)) continue;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(row_hashes + (size_t)src * 32);
+            uint32_t d = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint4 v = rp[q];
+                d += __builtin_popcount(v.x ^ cw[q].x) + __builtin_popcount(v.y ^ cw[q].y) +
+                     __builtin_popcount(v.z ^ cw[q].z) + __builtin_popcount(v.w ^ cw[q].w);
+            }
+            if (d <= tol) {
+                const unsigned long long at = atomicAdd(&counters[0], 1ull);
+                if (at < capacity) {
+                    vdf_hit hp; hp.row = row_index_base + src; hp.col = ce.col;
+                    hits[at] = hp;
+                } else {
+                    atomicMin(overflow_row, row_index_base + src);
+                }
+            }
+        }
+    }
 }
 
 template <int CHK, int WAVES>
@@ -652,17 +734,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     uint32_t group_size, uint32_t shard_index, uint32_t shard_count, uint32_t n_row_tiles, uint32_t chunk_cols,
     uint32_t tol, const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits,
     unsigned long long capacity, unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row,
-    uint32_t block_base)
+    uint32_t block_base, const float *__restrict__ row_pop3, uint32_t row_pad, const float *__restrict__ col_pop3,
+    uint32_t col_pad, CandEntry *__restrict__ cand, uint32_t cand_capacity, uint32_t *__restrict__ cand_head)
 {
     constexpr int K = CHK < 15 ? CHK + 1 : 16;            // k-steps of the main stream (64 bit positions each)
     constexpr uint32_t kSub = WAVES >= 8 ? 4 : 2;         // 32-candidate sub-tiles per LDS stage
     constexpr uint32_t kColStep = 32 * kSub;
     constexpr int NBLK = 2 * (int)kSub;                   // blocks per stage and wave: (sub-tile, row tile)
     constexpr int NM = NBLK * K;                          // MFMAs per stage and wave
-    constexpr int P = 4, NB = P + 2;                      // LDS fragments in flight / fragment buffers
+#ifndef VDF_M2_P
+#define VDF_M2_P 4
+#endif
+    constexpr int P = VDF_M2_P, NB = P + 1;               // LDS fragments in flight / fragment buffers
     constexpr uint32_t kTileRows = 64 * WAVES;
     constexpr int kDmaPerWave = (int)(kColStep * 32 / (64 * WAVES));  // 1 KB LDS-DMA pieces per wave and stage
-    constexpr int kDmaEvery = NM / kDmaPerWave;
+#ifndef VDF_M2_DMA_EVERY
+#define VDF_M2_DMA_EVERY (NM / kDmaPerWave)
+#endif
+    constexpr int kDmaEvery = VDF_M2_DMA_EVERY < NM / kDmaPerWave ? VDF_M2_DMA_EVERY : NM / kDmaPerWave;  // slots between DMA pieces
     static_assert(kDmaEvery >= 2, "stage too short for its DMA pieces");
     constexpr int kTestAt = 2;                            // the previous block's test issues under MFMAs kTestAt .. kTestAt + 3 of a block
     static_assert(K >= kTestAt + 4, "block too short to hide the previous block's test");
@@ -696,9 +785,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
     if (c_begin >= c_end) return;
 
-    // targets: 2 row tiles of 32 per wave, all 16 k-steps in registers
+    // targets: 2 row tiles of 32 per wave, the K streamed k-steps in registers (the cleanup fetches the rest on demand:
+    // 24 VGPRs less at K = 13); their C-operand vectors -paK / 2 (C layout: register r of lane group g <-> row
+    // (r & 3) + 8 (r >> 2) + 4 g)
+    const float tol_f = (float)min(tol, 1024u);
+    const float *row_popk = row_pop3 + row_pad;
+    const float *col_popkT = col_pop3 + 2 * (size_t)col_pad;
     const uint32_t row0 = t * kTileRows + wave * 64;
-    v4i a[2][16];
+    v4i a[2][K];
+    v16f rowc[2];
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
         const uint32_t p = row0 + 32 * rt + c31;
@@ -706,15 +801,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         if (p < n_rows && row_perm) src = row_perm[p];
         const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;  // rows >= n_rows read the zero padding
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
+        for (int s = 0; s < K; s++) {
             const uint4 v = rp[s];
             a[rt][s] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t pr = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const uint32_t sr = (pr < n_rows && row_perm) ? row_perm[pr] : pr;
+            rowc[rt][r] = -0.5f * row_popk[sr];
+        }
     }
-    const float tol_f = (float)min(tol, 1024u);
-    const float thresh = 1024.0f - 2.0f * tol_f;
-    const float thresh_chk = 64.0f * (float)K - 2.0f * tol_f;  // partial dot >= this <=> partial distance <= tol
-
     // LDS-DMA staging, identical to the first kernel: slot (col << 5 | q) holds chunk q ^ col of that column
     const uint32_t cb0 = c_begin & ~(kColStep - 1);
     constexpr uint32_t kColsPerRound = 2 * WAVES;
@@ -733,14 +830,63 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         const int voff = (int)lane_off[i & (kOffsets - 1)], soff = (int)(512u * kColsPerRound * (uint32_t)i);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
     };
+    // per-lane thresholds (pbK - tol) / 2 of the lane's column in the kSub sub-tiles of the stage starting at cb
+    auto load_thr = [&](uint32_t cb, float (&out)[kSub]) __attribute__((always_inline)) {
+        const float *q = col_popkT + (size_t)(cb >> 7) * 128 + c31 * 4 + ((cb >> 5) & 3u);
+        if constexpr (kSub == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(q);
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(q);
+            out[0] = v.x; out[1] = v.y;
+        }
+    };
 
     v16f acc[2] = {v16f{}, v16f{}};
     uint32_t n_early = 0;  // blocks that stopped after K steps
+    float thr[kSub], thr_next[kSub];
+
+    // A flagged block names its suspect pairs (rare path, ~0.3 % of the blocks): per lane the mask of accumulator registers
+    // still within the tolerance; lanes with a non-empty mask and a column inside this workgroup's range append one entry
+    // to the candidate queue.  Slots come in chunks of kCandChunk per wave (one returning atomic per chunk, not per entry; a wave sees ~12 suspects in
+    // its 512 x 65536 share of unrelated hashes, so small chunks strand little),
+    // the entries are fire-and-forget stores; resolve_candidates_kernel evaluates them exactly.
+    constexpr uint32_t kCandChunk = 8;
+    uint32_t q_next = 0, q_end = 0;  // this wave's slots [q_next, q_end)
+    auto emit = [&](const v16f &c, float thrv, uint32_t rows_first, uint32_t col_first) __attribute__((always_inline)) {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) mask |= (c[r] >= thrv) ? (1u << r) : 0u;
+        const uint32_t j = col_first + c31;
+        if (j < c_begin || j >= c_end) mask = 0;  // the neighbouring chunk's workgroup owns those columns
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mask != 0u);
+        if (bal == 0ull) return;
+        const uint32_t need = (uint32_t)__builtin_popcountll(bal);
+        if (q_next + need > q_end) {  // new chunk (the rest of the old one stays empty: slots are pre-filled with 0xFF)
+            const uint32_t take = (need + kCandChunk - 1) / kCandChunk * kCandChunk;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cand_head, take);
+            q_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            q_end = q_next + take;
+        }
+        const uint32_t slot = q_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (mask != 0u) {
+            if (slot < cand_capacity) {
+                CandEntry ce; ce.row_base = rows_first + 4 * g; ce.col = j; ce.mask = mask; ce.pad = 0;
+                *reinterpret_cast<uint4 *>(&cand[slot]) = *reinterpret_cast<const uint4 *>(&ce);
+            } else {  // queue full: the caller's overflow protocol restarts from the smallest row that lost a suspect
+                const uint32_t p = rows_first + 4 * g + (uint32_t)(__builtin_ctz(mask) & 3) + 8 * (uint32_t)(__builtin_ctz(mask) >> 2);
+                if (p < n_rows) atomicMin(overflow_row, row_index_base + (row_perm ? row_perm[p] : p));
+            }
+        }
+        q_next += need;
+    };
 
     // One stage: NBLK blocks of K MFMAs over the candidates in `cur`; DMA of the next stage into `nxt`.
-    // Returns the mask of blocks that need the full evaluation (bit = block index).
-    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) -> uint32_t {
-        const __amdgpu_buffer_rsrc_t rs_next = stage_rsrc(cb + kColStep < c_end ? cb + kColStep : cb);
+    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) {
+        const uint32_t cb_next = cb + kColStep < c_end ? cb + kColStep : cb;
+        const __amdgpu_buffer_rsrc_t rs_next = stage_rsrc(cb_next);
+        load_thr(cb_next, thr_next);  // lands long before the barrier that ends this stage
         uint32_t flags = 0;
         uint4 fq[NB];
         auto frag = [&](int i) __attribute__((always_inline)) {  // fragment of stream position i: block i / K, step i % K
@@ -749,7 +895,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         };
 #pragma unroll
         for (int i = 0; i < P; i++) fq[i] = frag(i);
-        __builtin_amdgcn_sched_group_barrier(0x100, P, 0);
+        __builtin_amdgcn_sched_barrier(0);
         // The source order below IS the schedule: one slot = one MFMA + the LDS read P fragments ahead + at most one DMA
         // piece + a quarter of the previous block's test; sched_barrier(0) between slots keeps the machine scheduler from
         // moving anything across (left alone it sinks every read next to its MFMA and bunches the VALU work).
@@ -760,8 +906,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             const uint4 bv = fq[i % NB];
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
             const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
-            if constexpr (s == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, v16f{}, 4, 4, 0, 127, 0, 127);
-            else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
+            // scale operands 0 / 0: the compiler selects the unscaled opcode (same values as scales 2^0, probed)
+            if constexpr (s == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, rowc[rt], 4, 4, 0, 0, 0, 0);
+            else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 0, 0, 0);
             if constexpr (i + P < NM) fq[(i + P) % NB] = frag(i + P);
             if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) load_piece(rs_next, nxt, i / kDmaEvery);
             // the block that finished kTestAt MFMAs ago sits in the other accumulator set: max over its 16 registers as a
@@ -775,14 +922,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
                 } else if constexpr (s == kTestAt + 2) {
                     m5 = fmaxf(fmaxf(m0, m1), m2); m3 = fmaxf(fmaxf(m3, m4), c[15]);
                 } else if constexpr (s == kTestAt + 3) {
-                    if (__builtin_amdgcn_ballot_w64(fmaxf(m5, m3) >= thresh_chk) != 0ull) flags |= 1u << (blk - 1);
+                    if (__builtin_amdgcn_ballot_w64(fmaxf(m5, m3) >= thr[(blk - 1) >> 1]) != 0ull) {
+                        flags |= 1u << (blk - 1);
+#ifndef VDF_MFMA2_NO_CLEANUP  // timing experiment only: suspects are dropped (no hits reported)
+                        emit(c, thr[(blk - 1) >> 1], row0 + 32u * (uint32_t)(rt ^ 1), cb + 32u * (uint32_t)((blk - 1) >> 1));
+#endif
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         {   // the last block of the stage has nothing of its own stage to hide behind
-            const float pm = max16(acc[(NBLK - 1) & 1]);
-            if (__builtin_amdgcn_ballot_w64(pm >= thresh_chk) != 0ull) flags |= 1u << (NBLK - 1);
+            const v16f &c = acc[(NBLK - 1) & 1];
+            m0 = fmaxf(fmaxf(c[0], c[1]), c[2]); m1 = fmaxf(fmaxf(c[3], c[4]), c[5]); m2 = fmaxf(fmaxf(c[6], c[7]), c[8]);
+            m3 = fmaxf(fmaxf(c[9], c[10]), c[11]); m4 = fmaxf(fmaxf(c[12], c[13]), c[14]);
+            const float pm = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
+            if (__builtin_amdgcn_ballot_w64(pm >= thr[kSub - 1]) != 0ull) {
+                flags |= 1u << (NBLK - 1);
+#ifndef VDF_MFMA2_NO_CLEANUP
+                emit(c, thr[kSub - 1], row0 + 32u * (uint32_t)((NBLK - 1) & 1), cb + 32u * (kSub - 1));
+#endif
+            }
         }
         // blocks of sub-tiles at or beyond the end of the chunk hold nothing
         uint32_t valid = 0;
@@ -791,68 +951,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             if (cb + 32u * sub < c_end) valid |= 3u << (2 * sub);
         flags &= valid;
         n_early += (uint32_t)__builtin_popcount(valid & ~flags);
-        __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
-        return flags;
-    };
-
-    // Full evaluation of the flagged blocks (rare).  bit = half * NBLK + block; operands from global memory.
-    auto cleanup = [&](uint32_t bits, uint32_t cb) __attribute__((always_inline)) {
-        while (bits) {
-            const uint32_t bi = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1;
-            const uint32_t half = bi / NBLK, blk = bi % NBLK, sub = blk >> 1, rt = blk & 1;
-            const uint32_t col0 = cb + half * kColStep + 32u * sub;
-            const uint32_t p = row0 + 32 * rt + c31;
-            uint32_t src = p;
-            if (p < n_rows && row_perm) src = row_perm[p];
-            const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;
-            const uint4 *cp = col_exp + (size_t)(col0 + c31) * 32 + 16 * g;  // padded: never past the buffer
-            v16f d = {};
-#pragma unroll 4
-            for (int s = 0; s < 16; s++) {
-                const uint4 av = rp[s], bv = cp[s];
-                const v8i ar = {(int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0};
-                const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
-                d = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, d, 4, 4, 0, 127, 0, 127);
-            }
-            const uint32_t j = col0 + c31;
-            bool col_ok = j >= c_begin && j < c_end;
-            if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
+        __syncthreads();  // waits for the DMA and the threshold load (vmcnt) and for every wave to be done with `cur`
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (col_ok && d[r] >= thresh) {
-                    const uint32_t pr = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    const uint32_t lo = row_lo[pr], hi = row_hi[pr];
-                    if (j >= lo && j < hi) {
-                        const uint32_t sr = row_perm ? row_perm[pr] : pr;
-                        bool ok = true;
-                        if (self_mode && matched) ok = ((matched[sr >> 5] >> (sr & 31)) & 1u) == 0u;
-                        if (ok) {
-                            const unsigned long long at = atomicAdd(&counters[0], 1ull);
-                            if (at < capacity) {
-                                vdf_hit hp; hp.row = row_index_base + sr; hp.col = j;
-                                hits[at] = hp;
-                            } else {
-                                atomicMin(overflow_row, row_index_base + sr);
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     };
 
 #pragma unroll
     for (int i = 0; i < kDmaPerWave; i++) load_piece(stage_rsrc(cb0), s_b0, i);
+    load_thr(cb0, thr_next);
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int s = 0; s < 16; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
+        for (int s = 0; s < K; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
     __syncthreads();
+#pragma unroll
+    for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     for (uint32_t cb = cb0; cb < c_end; cb += 2 * kColStep) {
-        uint32_t flags = run_stage(cb, s_b0, s_b1);
-        flags |= run_stage(cb + kColStep, s_b1, s_b0) << NBLK;  // past the end of the chunk: all blocks masked out
-        if (flags) cleanup(flags, cb);
+        run_stage(cb, s_b0, s_b1);
+        if (cb + kColStep >= c_end) break;
+        run_stage(cb + kColStep, s_b1, s_b0);
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kTileRows);
     if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u));
@@ -960,12 +1077,15 @@ hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long
     return hipGetLastError();
 }
 
-hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream)
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, int mode01, uint32_t k_steps,
+                             float *pop3 /* nullable: [3][n_pad] = pop, popk, popkT */, hipStream_t stream)
 {
     if (n_pad == 0) return hipSuccess;
+    if (pop3 && (n_pad % 128u)) return hipErrorInvalidValue;
     const size_t total = (size_t)n_pad * 32;
     hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, kMaxBlocksPerLaunch)), dim3(256), 0, stream, packed, n, n_pad,
-                       reinterpret_cast<uint4 *>(expanded));
+                       reinterpret_cast<uint4 *>(expanded), mode01, k_steps, pop3, pop3 ? pop3 + n_pad : nullptr,
+                       pop3 ? pop3 + 2 * (size_t)n_pad : nullptr);
     return hipGetLastError();
 }
 
@@ -981,7 +1101,8 @@ hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tile
                        reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
                        L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
                        L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
-                       L.hits, L.capacity, L.counters, L.overflow_row, base)
+                       L.hits, L.capacity, L.counters, L.overflow_row, base, L.row_pop3, L.row_pad, L.col_pop3, L.col_pad,                   \
+                       reinterpret_cast<CandEntry *>(L.cand), L.cand_capacity, L.cand_head)
 #define VDF_MFMA2_STEPS(WV)                                                                                         \
     switch (L.prune_step) { /* smallest instantiated step >= the requested one */                                   \
     case 0: case 1: case 2: case 3: case 4: case 5: case 6: VDF_MFMA2_LAUNCH(6, WV); break;                          \
@@ -998,7 +1119,11 @@ hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tile
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    // second pass: exact evaluation of the suspect pairs
+    hipLaunchKernelGGL(resolve_candidates_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const CandEntry *>(L.cand),
+                       L.cand_head, L.cand_capacity, L.row_hashes, L.row_perm, L.n_rows, L.row_index_base, L.col_hashes, L.n_cols,
+                       L.row_lo, L.row_hi, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters, L.overflow_row);
+    return hipGetLastError();
 }
 
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)

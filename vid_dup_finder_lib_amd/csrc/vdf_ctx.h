@@ -103,7 +103,8 @@ struct vdf_ctx {
     uint32_t mfma_refs_rows = 256;  // rows per workgroup of reference searches with kernel 2 (VDF_MFMA_REFS_ROWS: 256 | 512)
     int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
-    DevBuf exp_cols, exp_rows;
+    DevBuf exp_cols, exp_rows, pop_cols, pop_rows, cand;
+    size_t cand_dirty = SIZE_MAX;  // slots of the candidate queue the last launch may have written (SIZE_MAX: never initialised)
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads
     std::vector<vdf_hit> host_hits;
     vdf_impl::CopyPool *copy_pool = nullptr;

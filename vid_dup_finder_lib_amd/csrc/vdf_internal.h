@@ -25,6 +25,12 @@ struct SearchLaunch {
     uint32_t n_cols;
     // fp4-expanded copies for the MFMA backend ([n_pad][512 B], zero padded); null for the VALU backend
     const void *row_exp, *col_exp;
+    // second-generation kernel ({0, 1} encoding): popcounts of rows / columns as floats: [pop | popk | popkT] x n_pad
+    const float *row_pop3 = nullptr, *col_pop3 = nullptr;
+    uint32_t row_pad = 0, col_pad = 0;
+    void *cand = nullptr;                 // candidate queue of the second-generation kernel (16-byte entries, pre-filled with 0xFF)
+    uint32_t cand_capacity = 0;
+    uint32_t *cand_head = nullptr;        // next free slot (advanced in per-wave chunks)
     // windows + tiles (device scratch, filled by launch_windows_tiles)
     uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
@@ -62,7 +68,10 @@ hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hip
 #define VDF_ROW_TILES 2  // 32-row MFMA tiles per wave (build-time experiment knob)
 #endif
 constexpr uint32_t kMfmaRowPad = 32 * VDF_ROW_TILES * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
-hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, hipStream_t stream);
+// mode01 = 1: {0, 1} nibbles + popcount arrays pop3 = [pop | popk | popkT] of n_pad floats each (second-generation kernel);
+// mode01 = 0: +-1 nibbles (first kernel), pop3 = nullptr
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, int mode01, uint32_t k_steps,
+                             float *pop3, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream + cleanup; tile_rows 512 or 256
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
