@@ -964,6 +964,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
 #pragma unroll
         for (int s = 0; s < K; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
     __syncthreads();
+#ifdef VDF_M2_SETPRIO  // experiment: static priority for the second-dispatched half of the workgroup (waves w and w + 4 share a SIMD)
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(VDF_M2_SETPRIO);
+#endif
 #pragma unroll
     for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     for (uint32_t cb = cb0; cb < c_end; cb += 2 * kColStep) {
