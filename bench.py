@@ -137,7 +137,8 @@ def search_roofline(backend, kernel_ms):
         extra = {"valu": valu}
         dtype = "u32 (xor + popcount over 32 dwords per hash)"
     else:
-        kname = "hamming_mfma_kernel"
+        gen2 = os.environ.get("VDF_MFMA_KERNEL", "2") != "1"
+        kname = "hamming_mfma2_kernel" if gen2 else "hamming_mfma_kernel"
         alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
         k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
         ee_bits = int(kernel_ms[-1][6])
@@ -154,11 +155,14 @@ def search_roofline(backend, kernel_ms):
                     "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
                                    "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
                                            "exceed the tolerance cannot contain a hit and stops there (exact)"},
-                    "note": "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; "
+                    "note": ("exact {0,1} fp4 Gram matrix (v_mfma_f32_32x32x64_f8f6f4): hamming = pop(a) + pop(b) - 2 dot; suspects of "
+                             "blocks that cannot be ruled out are evaluated exactly by resolve_candidates_kernel (inside kernel_ms); "
+                             if gen2 else "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; ") +
                             "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
                             "pair; integer results, bit-identical to XOR + popcount"}
         extra = {"hbm_operand_stream_model": hbm_model}
-        dtype = "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)"
+        dtype = ("fp4 e2m1 ({0,1}) x fp4 -> f32 accumulate (exact half-integers < 2^11)" if gen2
+                 else "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)")
     return roofline, extra, dtype
 
 
@@ -504,7 +508,7 @@ def main():
                               "match_groups": len(g10r), "planted_pairs": int(len(src10)),
                               "hbm_operand_stream_frac": p10 / dt10 * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
         if backend != "valu":
-            out["ten_million"]["roofline"] = {"bound": "mfma", "kernel": "hamming_mfma_kernel",
+            out["ten_million"]["roofline"] = {"bound": "mfma", "kernel": roofline["kernel"],
                                               "achieved": ex10 * FLOP_PER_PAIR / k10 / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
                                               "unit": "TFLOP/s", "frac": ex10 * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                                               "algorithmic_frac": s10["pairs_computed"] * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,

@@ -7,14 +7,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --ten-million 0 --no-valu"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/bench_under_profiler.json 2> /dev/null
-B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed"
+B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --ten-million 0 --no-valu"
 H1="python3 $R/tools/bench_hash.py --steps 1"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hash -- $H1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_hash -- $H1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq_search -- $B1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq_search2 -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq_hash -- $H1 > /dev/null 2>&1
 ls $O

@@ -61,6 +61,9 @@ for k in summary.get("fetch_search", {}):
     if k.startswith("hamming_tile_kernel"):
         t["hamming_tile_kernel"] = traffic("fetch_search", "write_search", k, 1,
                                            "candidates arrive through scalar-cache line fills (64-B requests): no x2 correction applied")
+    if k.startswith("hamming_mfma2_kernel"):
+        t["hamming_mfma2_kernel"] = traffic("fetch_search", "write_search", k, 2,
+                                            "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
     if k.startswith("hamming_mfma_kernel"):
         t["hamming_mfma_kernel"] = traffic("fetch_search", "write_search", k, 2,
                                            "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
@@ -68,5 +71,12 @@ for k in summary.get("fetch_hash", {}):
     if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
         t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
                                                     "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
+old = {}
+try:
+    old = json.load(open(os.path.join(out, "pmc_traffic.json")))
+except Exception:
+    pass
+old.update({k: v for k, v in t.items() if v})
+t = old
 json.dump(t, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(t, indent=1))

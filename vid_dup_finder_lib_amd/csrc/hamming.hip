@@ -794,8 +794,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     const uint32_t row0 = t * kTileRows + wave * 64;
     v4i a[2][K];
     v16f rowc[2];
+    uint32_t live[2];  // bit r: the row of accumulator register r has a non-empty window in this launch (suspects of other rows are noise)
 #pragma unroll
     for (int rt = 0; rt < 2; rt++) {
+        live[rt] = 0;
         const uint32_t p = row0 + 32 * rt + c31;
         uint32_t src = p;
         if (p < n_rows && row_perm) src = row_perm[p];
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             const uint32_t pr = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
             const uint32_t sr = (pr < n_rows && row_perm) ? row_perm[pr] : pr;
             rowc[rt][r] = -0.5f * row_popk[sr];
+            if (row_hi[pr] > row_lo[pr]) live[rt] |= 1u << r;  // the window arrays are padded to whole tiles
         }
     }
     // LDS-DMA staging, identical to the first kernel: slot (col << 5 | q) holds chunk q ^ col of that column
@@ -853,10 +856,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     // the entries are fire-and-forget stores; resolve_candidates_kernel evaluates them exactly.
     constexpr uint32_t kCandChunk = 8;
     uint32_t q_next = 0, q_end = 0;  // this wave's slots [q_next, q_end)
-    auto emit = [&](const v16f &c, float thrv, uint32_t rows_first, uint32_t col_first) __attribute__((always_inline)) {
+    auto emit = [&](const v16f &c, float thrv, uint32_t live_rows, uint32_t rows_first, uint32_t col_first) __attribute__((always_inline)) {
         uint32_t mask = 0;
 #pragma unroll
         for (int r = 0; r < 16; r++) mask |= (c[r] >= thrv) ? (1u << r) : 0u;
+        mask &= live_rows;
         const uint32_t j = col_first + c31;
         if (j < c_begin || j >= c_end) mask = 0;  // the neighbouring chunk's workgroup owns those columns
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(mask != 0u);
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
                     if (__builtin_amdgcn_ballot_w64(fmaxf(m5, m3) >= thr[(blk - 1) >> 1]) != 0ull) {
                         flags |= 1u << (blk - 1);
 #ifndef VDF_MFMA2_NO_CLEANUP  // timing experiment only: suspects are dropped (no hits reported)
-                        emit(c, thr[(blk - 1) >> 1], row0 + 32u * (uint32_t)(rt ^ 1), cb + 32u * (uint32_t)((blk - 1) >> 1));
+                        emit(c, thr[(blk - 1) >> 1], live[rt ^ 1], row0 + 32u * (uint32_t)(rt ^ 1), cb + 32u * (uint32_t)((blk - 1) >> 1));
 #endif
                     }
                 }
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             if (__builtin_amdgcn_ballot_w64(pm >= thr[kSub - 1]) != 0ull) {
                 flags |= 1u << (NBLK - 1);
 #ifndef VDF_MFMA2_NO_CLEANUP
-                emit(c, thr[kSub - 1], row0 + 32u * (uint32_t)((NBLK - 1) & 1), cb + 32u * (kSub - 1));
+                emit(c, thr[kSub - 1], live[(NBLK - 1) & 1], row0 + 32u * (uint32_t)((NBLK - 1) & 1), cb + 32u * (kSub - 1));
 #endif
             }
         }
