@@ -44,7 +44,14 @@ def test_cpp_selftest_runs_without_gpu():
 
 
 @pytest.mark.gpu
-def test_cpp_search_matches_oracle(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0"])
+def test_cpp_search_matches_oracle(tmp_path, devices, monkeypatch):
+    """devices = "0,0": the compiled C++ caller goes through ONE multi-GPU context (two slots on GPU 0), as a Rust caller of
+    search() would with VDF_DEVICES set."""
+    if devices:
+        monkeypatch.setenv("VDF_DEVICES", devices)
+    else:
+        monkeypatch.delenv("VDF_DEVICES", raising=False)
     exe = _build()
     rng = np.random.default_rng(42)
     words, dur = hg.planted_set(rng, 1500, n_clusters=40, durations="windowed")

@@ -147,10 +147,18 @@ __device__ __forceinline__ void dct16_pruned(const double (&v)[16], double (&out
     out[7] = ev[2] + (-od[2]); out[8] = in2[4]; out[9] = ev[2] - (-od[2]);
 }
 
-constexpr int kPadY = 17;  // [t][kx][y] rows padded to 17 doubles
+constexpr int kPadY = 17;  // [t][ky][x] rows padded to 17 doubles: pass-y writes and pass-x reads are conflict-free
+// Second-pass output [t][10 kx + ky] with a t-stride of 106 doubles: the pass-x writes (16-lane groups over consecutive
+// (t, ky)) and the pass-t reads (lane = 10 kx + ky, consecutive doubles) are both free of bank conflicts; strides 100..131
+// were enumerated against the bank model of MI355X_MICROARCH.md (only 106 and 122 are clean).  Overwriting the first-pass
+// rows in place (round 1) cost 48-72 conflict cycles per clip in pass t (17 % of the kernel's LDS-active cycles).
+constexpr int kStrideT = 106;
 
 struct DctShared {
-    double b[16 * 10 * kPadY];  // first-pass output [t][k1][n2]; the second pass overwrites row (t, k1) in place with [k2]
+    union {                         // the second-pass output overlays the first-pass rows (a barrier separates the last read of b
+        double b[16 * 10 * kPadY];  // first-pass output [t][ky][x]                 from the first write of c): 26 KB per workgroup
+        double c[16 * kStrideT];    // second-pass output [t][10 kx + ky]           instead of 40, i.e. 6 instead of 4 workgroups per CU
+    };                              //                                               for the DCT-bound 16 x 16 input path
     uint32_t words[32];         // the 1024 hash bits, OR-assembled from per-kt ballots
     uint32_t dc[4];
     // Resized clip as CENTRED bytes (pix - 128 as i8), one dword per (t, g, x): byte r = pixel (y = 4 g + r, x).
@@ -188,15 +196,20 @@ __device__ __forceinline__ void dct_hash_block(DctShared &sh, const_f64_ptr cosv
     }
     __syncthreads();
     // pass x: thread (t, ky), 160 lines
+    double ox[10];
     if (tid < 160) {
-        double v[16], o[10];
+        double v[16];
 #pragma unroll
         for (int x = 0; x < 16; x++) v[x] = sh.b[tid * kPadY + x];
-        dct16_pruned(v, o, cm);
-#pragma unroll
-        for (int kx = 0; kx < 10; kx++) sh.b[tid * kPadY + kx] = o[kx];  // own row: all reads are done
+        dct16_pruned(v, ox, cm);
     } else if (tid >= 192 && tid < 224) {
         sh.words[tid - 192] = 0u;  // idle lanes clear the ballot words (previous clip's words were read two barriers ago)
+    }
+    __syncthreads();  // every row of b has been read: c may overwrite it
+    if (tid < 160) {
+        const uint32_t t = tid / 10, ky = tid - 10 * t;
+#pragma unroll
+        for (int kx = 0; kx < 10; kx++) sh.c[t * kStrideT + 10 * kx + ky] = ox[kx];
     }
     __syncthreads();
     // pass t + sign + pack: thread rem = 10 kx + ky (100 threads) reads its 16 t-values once and produces the ten
@@ -206,11 +219,10 @@ __device__ __forceinline__ void dct_hash_block(DctShared &sh, const_f64_ptr cosv
     if (wave < 2) {
         const uint32_t rem = tid;  // < 128; lanes with rem >= 100 idle
         const bool live = rem < 100;
-        const uint32_t kx = rem / 10, ky = rem - kx * 10;
-        const uint32_t at = live ? ky * kPadY + kx : 0;
+        const uint32_t at = live ? rem : 0;
         double v[16], o[10];
 #pragma unroll
-        for (int t = 0; t < 16; t++) v[t] = sh.b[t * 10 * kPadY + at];
+        for (int t = 0; t < 16; t++) v[t] = sh.c[t * kStrideT + at];
         dct16_pruned(v, o, cm);
         unsigned long long piece = 0;
 #pragma unroll

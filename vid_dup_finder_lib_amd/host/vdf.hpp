@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 #include <optional>
@@ -36,7 +37,7 @@ struct TooFewEntries : std::runtime_error {  // match_group.rs:15-16
     TooFewEntries() : std::runtime_error("too few entries") {}
 };
 
-// ---- one GPU context -------------------------------------------------------------------------------------
+// ---- a context: one GPU, or ONE context over several GPUs of the node ---------------------------------------
 class Context {
 public:
     explicit Context(int device = 0)
@@ -45,10 +46,32 @@ public:
         if (vdf_ctx_create(device, &c) != VDF_OK) throw Error(Error::Device, vdf_last_error(nullptr));
         ctx_.reset(c, vdf_ctx_destroy);
     }
+    // search() / search_with_references() / hashing then use every listed GPU from the one call (vdf_ctx_create_multi)
+    explicit Context(const std::vector<int> &devices)
+    {
+        vdf_ctx *c = nullptr;
+        if (vdf_ctx_create_multi(devices.data(), (int)devices.size(), &c) != VDF_OK) throw Error(Error::Device, vdf_last_error(nullptr));
+        ctx_.reset(c, vdf_ctx_destroy);
+    }
+    int device_count() const { return vdf_ctx_device_count(ctx_.get()); }
     vdf_ctx *get() const { return ctx_.get(); }
+    // VDF_DEVICES="0,1,2,3": the default context spans those GPUs (one process, vdf_ctx_create_multi); default: device 0
     static Context &default_context()
     {
-        static Context c(0);
+        static Context c = [] {
+            std::vector<int> devs;
+            if (const char *e = std::getenv("VDF_DEVICES")) {
+                const char *p = e;
+                while (*p) {
+                    char *end = nullptr;
+                    const long v = std::strtol(p, &end, 10);
+                    if (end == p) break;
+                    devs.push_back((int)v);
+                    p = (*end == ',') ? end + 1 : end;
+                }
+            }
+            return devs.empty() ? Context(0) : Context(devs);
+        }();
         return c;
     }
 
