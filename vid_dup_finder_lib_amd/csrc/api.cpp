@@ -85,7 +85,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     // second-generation MFMA kernel: 512-row workgroups for search(); reference searches may take 256-row ones (a tile's
     // candidate range is the union of its rows' duration windows: fewer rows, narrower union)
     const bool gen2 = mfma && ctx->mfma_kernel == 2;
-    L.tile_rows = mfma ? (gen2 && mode == 1 ? ctx->mfma_refs_rows : vdf::kMfmaRowPad) : ctx->tile_rows;
+    L.tile_rows = mfma ? (gen2 ? (mode == 1 ? ctx->mfma_refs_rows : ctx->mfma_self_rows) : vdf::kMfmaRowPad) : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     if (mfma && L.chunk_cols == 0) {
@@ -622,6 +622,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     }
     if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_MFMA_KERNEL")) { const int v = std::atoi(s); if (v == 1 || v == 2) ctx->mfma_kernel = v; }
+    if (const char *s = std::getenv("VDF_MFMA_SELF_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_self_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_REFS_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_refs_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_PRUNE_STEP")) ctx->mfma_prune_step = std::atoi(s);
     if (const char *s = std::getenv("VDF_MFMA_MIN_WGS")) { const long v = std::atol(s); if (v >= 1 && v <= (1 << 24)) ctx->mfma_min_wgs = (uint32_t)v; }

@@ -847,6 +847,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
 
     v16f acc[2] = {v16f{}, v16f{}};
     uint32_t n_early = 0;  // blocks that stopped after K steps
+    const bool hi_half = wave >= WAVES / 2;
+    (void)hi_half;
     float thr[kSub], thr_next[kSub];
 
     // A flagged block names its suspect pairs (rare path, ~0.3 % of the blocks): per lane the mask of accumulator registers
@@ -913,8 +915,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             // scale operands 0 / 0: the compiler selects the unscaled opcode (same values as scales 2^0, probed)
             if constexpr (s == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, rowc[rt], 4, 4, 0, 0, 0, 0);
             else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 0, 0, 0);
+#ifndef VDF_M2_ABL_NOLDS  // ablation: no LDS fragment reads in the stream (the first P fragments are reused)
             if constexpr (i + P < NM) fq[(i + P) % NB] = frag(i + P);
+#endif
+#ifdef VDF_M2_ABL_NODMA  // ablation: no LDS-DMA in the stream (every stage multiplies the first stage's image)
+#elif defined(VDF_M2_DMA_STAGGER)  // experiment: the two waves of a SIMD (w and w + WAVES / 2) issue their DMA pieces half a period apart
+            if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) { if (!hi_half) load_piece(rs_next, nxt, i / kDmaEvery); }
+            if constexpr ((i % kDmaEvery) == 1 + kDmaEvery / 2 && (i / kDmaEvery) < kDmaPerWave) { if (hi_half) load_piece(rs_next, nxt, i / kDmaEvery); }
+#else
             if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) load_piece(rs_next, nxt, i / kDmaEvery);
+#endif
             // the block that finished kTestAt MFMAs ago sits in the other accumulator set: max over its 16 registers as a
             // tree, two or three v_max3 per slot
             if constexpr (blk >= 1) {
@@ -955,7 +965,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             if (cb + 32u * sub < c_end) valid |= 3u << (2 * sub);
         flags &= valid;
         n_early += (uint32_t)__builtin_popcount(valid & ~flags);
+#ifndef VDF_M2_ABL_NOBARRIER  // ablation (with NODMA): no barrier between stages
         __syncthreads();  // waits for the DMA and the threshold load (vmcnt) and for every wave to be done with `cur`
+#endif
 #pragma unroll
         for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     };
