@@ -194,8 +194,10 @@ int vdf_search_refs(vdf_ctx *ctx, const uint64_t *cand_hashes, const uint32_t *c
  *   entries are skipped both as targets and as candidates (exactly the `matched` flag).
  *   hits (HOST buffer, capacity entries) receives the pairs sorted by (row, col); *n_hits is the
  *   number produced by the device (may exceed capacity); *overflow_row is the smallest row that
- *   lost a hit, or UINT32_MAX.  Rows below *overflow_row are complete.
- *   Returns VDF_OK also when the buffer overflowed: check *overflow_row. */
+ *   lost a hit (or, on the matrix-core backend, a suspect pair that could not be queued for the exact
+ *   second pass: only possible with very dense near-duplicates), or UINT32_MAX.  Rows below
+ *   *overflow_row are complete.
+ *   Returns VDF_OK also when a buffer overflowed: check *overflow_row. */
 int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
                            uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
                            uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
