@@ -42,6 +42,27 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert ei.value.code == -3  # VDF_E_HIP
 
 
+def test_multi_context_fails_loudly_without_gpu_and_rejects_bad_lists():
+    import ctypes as C
+
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import _capi
+
+    lib = _capi.load()
+    ctx = C.c_void_p()
+    assert lib.vdf_ctx_create_multi(None, 0, C.byref(ctx)) == _capi.VDF_E_INVAL and not ctx.value
+    arr = (C.c_int * 2)(0, 0)
+    assert lib.vdf_ctx_create_multi(arr, 0, C.byref(ctx)) == _capi.VDF_E_INVAL
+    assert lib.vdf_ctx_device_count(None) == 0 and lib.vdf_ctx_device_at(None, 0) == -1
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vdf.VdfError) as ei:
+        vdf.Engine(devices=[0, 0])
+    assert ei.value.code == -3 and "device list entry 0" in str(ei.value)  # VDF_E_HIP, with the slot that failed
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "vid_dup_finder_lib_amd")
     for dirpath, _, files in os.walk(pkg):
