@@ -262,3 +262,26 @@ def test_chunk_boundary_65536(engine):
     got = engine.search_self_sorted(words, dur, 350)
     want = orc.search_self_sorted(words, dur, 350)
     assert got == want
+
+
+@pytest.mark.parametrize("cand_capacity", [8, 64, 1000])
+def test_suspect_queue_overflow_goes_through_the_overflow_protocol(cand_capacity, monkeypatch):
+    """The matrix-core backend queues suspect pairs for an exact second pass.  With a queue far too small for dense
+    near-duplicates (forced here) a launch drops suspects and reports the smallest row that lost one through overflow_row;
+    the caller-side protocol (vdf_search_self) must still return exactly the reference's groups."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_CAND_CAPACITY", str(cand_capacity))
+    monkeypatch.setenv("VDF_SEARCH_BACKEND", "mfma")
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(cand_capacity)
+        words, dur = hg.planted_set(rng, 2500, n_clusters=25, max_copies=40, max_flips=120, durations="windowed")
+        w, d, _ = hg.sort_by_duration(words, dur)
+        assert eng.search_self_sorted(w, d, 350) == orc.search_self_sorted(w, d, 350)
+        assert eng.last_stats()["n_launches"] > 1
+        pick = rng.choice(len(d), size=64, replace=False)
+        # references have no consumption, every hit is output: the library reruns the launch with a larger queue
+        assert eng.search_refs_sorted(w, d, w[pick], d[pick], 300) == orc.search_refs_sorted(w, d, w[pick], d[pick], 300)
+    finally:
+        eng.close()

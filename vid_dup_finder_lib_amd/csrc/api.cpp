@@ -210,8 +210,10 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         // pairs there at the 4-sigma test point; slots are handed out in chunks of 8 per wave, so every wave may strand
         // a few.  Sized generously from the admitted pairs; if it still overflows, the hit-buffer overflow protocol takes
         // over (rows below the smallest row that lost a suspect are complete).
-        const uint64_t want = (uint64_t)((double)admitted * 6e-6) + (uint64_t)total_tiles * 8 * 8 + std::max<uint64_t>(capacity, 1ull << 20);
+        const uint64_t want = ((uint64_t)((double)admitted * 6e-6) + (uint64_t)total_tiles * 8 * 8 + std::max<uint64_t>(capacity, 1ull << 20)) * ctx->cand_scale;
         L.cand_capacity = (uint32_t)std::min<uint64_t>(want, 0x40000000ull);
+        if (ctx->cand_capacity_override)  // VDF_CAND_CAPACITY (tests: forces the overflow path)
+            L.cand_capacity = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cand_capacity_override * ctx->cand_scale, 0x40000000ull);
         const void *before = ctx->cand.p;
         VDF_HIP(ctx, ctx->cand.reserve((size_t)L.cand_capacity * 16));
         if (ctx->cand.p != before) ctx->cand_dirty = SIZE_MAX;  // fresh allocation: fill all of it
@@ -220,7 +222,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         if (fill) VDF_HIP(ctx, hipMemsetAsync(ctx->cand.p, 0xFF, fill, stream));
         ctx->cand_dirty = 0;
         L.cand = ctx->cand.p;
-        L.cand_head = reinterpret_cast<uint32_t *>(ctx->counters.as<unsigned long long>() + 6);
+        L.cand_head = ctx->counters.as<unsigned long long>() + 6;
     }
 
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
@@ -234,7 +236,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     float ms = 0.f;
     VDF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
 
-    if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6] & 0xFFFFFFFFull, L.cand_capacity);  // slots this launch used
+    if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6], L.cand_capacity);  // slots this launch used
     const uint64_t produced = fin[0];
     const uint64_t stored = std::min<uint64_t>(produced, capacity);
     if (stored) {
@@ -568,15 +570,24 @@ int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rdur[a] < rdur[b]; });
     int rc = upload(ctx, ctx->perm, perm.data(), n_ref * 4, s);
     if (rc) return rc;
-    uint32_t overflow_row = 0;
-    rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
-                     ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
-                     capacity, n_hits, &overflow_row, s);
-    if (rc) return rc;
-    if (*n_hits > capacity) return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size");
+    // Every hit is part of the output here (consume = false).  The hit buffer is the caller's to size (VDF_E_OVERFLOW with the
+    // required size); the suspect queue of the matrix-core backend is the library's: if a launch dropped suspects, run it
+    // again with a larger queue.
+    for (int attempt = 0;; attempt++) {
+        uint32_t overflow_row = 0;
+        ctx->stats = vdf_search_stats{};
+        rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
+                         ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
+                         capacity, n_hits, &overflow_row, s);
+        if (rc) { ctx->cand_scale = 1; return rc; }
+        if (*n_hits > capacity) { ctx->cand_scale = 1; return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size"); }
+        if (overflow_row == 0xFFFFFFFFu) break;  // complete
+        if (attempt >= 12) { ctx->cand_scale = 1; return fail(ctx, VDF_E_OVERFLOW, "suspect queue overflow"); }
+        ctx->cand_scale *= 4;
+    }
+    ctx->cand_scale = 1;
     return VDF_OK;
 }
-
 
 int create_single(int device_id, vdf_ctx **out, std::string *err)
 {
@@ -622,6 +633,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     }
     if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_MFMA_KERNEL")) { const int v = std::atoi(s); if (v == 1 || v == 2) ctx->mfma_kernel = v; }
+    if (const char *s = std::getenv("VDF_CAND_CAPACITY")) { const long v = std::atol(s); if (v >= 8 && v <= 0x40000000l) ctx->cand_capacity_override = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_SELF_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_self_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_REFS_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_refs_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_PRUNE_STEP")) ctx->mfma_prune_step = std::atoi(s);
@@ -760,13 +772,13 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         d->stats = vdf_search_stats{};
         if (ref_cnt[(size_t)k] == 0) return (int)VDF_OK;
         uint64_t capacity = capacity0;
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = 0; attempt < 6; attempt++) {
             if (d->host_hits.size() < capacity) d->host_hits.resize(capacity);
             int r = search_refs_device_locked(d, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n_cand,
                                               d->up_ref_hashes.as<uint64_t>(), d->up_ref_dur.as<uint32_t>(),
                                               ref_cnt[(size_t)k], tol_int, (uint32_t)ref_base[(size_t)k], d->host_hits.data(),
                                               capacity, &d->r_n_hits, d->stream);
-            if (r == VDF_E_OVERFLOW && attempt == 0) { capacity = d->r_n_hits; continue; }  // every hit is output: size exactly
+            if (r == VDF_E_OVERFLOW && d->r_n_hits > capacity) { capacity = d->r_n_hits; continue; }  // every hit is output: size up
             return r;
         }
         return (int)VDF_E_OVERFLOW;

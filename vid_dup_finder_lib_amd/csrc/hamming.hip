@@ -677,14 +677,14 @@ struct CandEntry {
 };
 
 __global__ __launch_bounds__(256) void resolve_candidates_kernel(
-    const CandEntry *__restrict__ cand, const uint32_t *__restrict__ cand_head, uint32_t cand_capacity,
+    const CandEntry *__restrict__ cand, const unsigned long long *__restrict__ cand_head, uint32_t cand_capacity,
     const uint32_t *__restrict__ row_hashes, const uint32_t *__restrict__ row_perm, uint32_t n_rows, uint32_t row_index_base,
     const uint32_t *__restrict__ col_hashes, uint32_t n_cols, const uint32_t *__restrict__ row_lo,
     const uint32_t *__restrict__ row_hi, uint32_t tol, const uint32_t *__restrict__ matched, int self_mode,
     vdf_hit *__restrict__ hits, unsigned long long capacity, unsigned long long *__restrict__ counters,
     uint32_t *__restrict__ overflow_row)
 {
-    const uint32_t n = min(*cand_head, cand_capacity);
+    const uint32_t n = (uint32_t)min(*cand_head, (unsigned long long)cand_capacity);
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const CandEntry ce = cand[e];
         if (ce.row_base == 0xFFFFFFFFu || ce.col >= n_cols) continue;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     uint32_t tol, const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits,
     unsigned long long capacity, unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row,
     uint32_t block_base, const float *__restrict__ row_pop3, uint32_t row_pad, const float *__restrict__ col_pop3,
-    uint32_t col_pad, CandEntry *__restrict__ cand, uint32_t cand_capacity, uint32_t *__restrict__ cand_head)
+    uint32_t col_pad, CandEntry *__restrict__ cand, uint32_t cand_capacity, unsigned long long *__restrict__ cand_head)
 {
     constexpr int K = CHK < 15 ? CHK + 1 : 16;            // k-steps of the main stream (64 bit positions each)
     constexpr uint32_t kSub = WAVES >= 8 ? 4 : 2;         // 32-candidate sub-tiles per LDS stage
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     // its 512 x 65536 share of unrelated hashes, so small chunks strand little),
     // the entries are fire-and-forget stores; resolve_candidates_kernel evaluates them exactly.
     constexpr uint32_t kCandChunk = 8;
-    uint32_t q_next = 0, q_end = 0;  // this wave's slots [q_next, q_end)
+    unsigned long long q_next = 0, q_end = 0;  // this wave's slots [q_next, q_end); 64 bit: the head keeps counting past a full queue
     auto emit = [&](const v16f &c, float thrv, uint32_t live_rows, uint32_t rows_first, uint32_t col_first) __attribute__((always_inline)) {
         uint32_t mask = 0;
 #pragma unroll
@@ -870,12 +870,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         const uint32_t need = (uint32_t)__builtin_popcountll(bal);
         if (q_next + need > q_end) {  // new chunk (the rest of the old one stays empty: slots are pre-filled with 0xFF)
             const uint32_t take = (need + kCandChunk - 1) / kCandChunk * kCandChunk;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cand_head, take);
-            q_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(cand_head, (unsigned long long)take);
+            q_next = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
             q_end = q_next + take;
         }
-        const uint32_t slot = q_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        const unsigned long long slot = q_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (mask != 0u) {
             if (slot < cand_capacity) {
                 CandEntry ce; ce.row_base = rows_first + 4 * g; ce.col = j; ce.mask = mask; ce.pad = 0;

@@ -100,6 +100,8 @@ struct vdf_ctx {
     uint32_t mfma_xcd_stripe = 0;
     uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
     int mfma_kernel = 2;            // 1 = first kernel (test inside the stream), 2 = branch-free stream + flagged-block cleanup (VDF_MFMA_KERNEL)
+    uint64_t cand_scale = 1;              // grows (x4) while a reference search retries after a suspect-queue overflow
+    uint32_t cand_capacity_override = 0;  // VDF_CAND_CAPACITY: suspect-queue entries (0 = sized from the admitted pairs)
     uint32_t mfma_self_rows = 512;  // rows per workgroup of search() with kernel 2 (VDF_MFMA_SELF_ROWS: 256 | 512)
     uint32_t mfma_refs_rows = 256;  // rows per workgroup of reference searches with kernel 2 (VDF_MFMA_REFS_ROWS: 256 | 512)
     int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)

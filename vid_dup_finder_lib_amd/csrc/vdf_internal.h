@@ -30,7 +30,7 @@ struct SearchLaunch {
     uint32_t row_pad = 0, col_pad = 0;
     void *cand = nullptr;                 // candidate queue of the second-generation kernel (16-byte entries, pre-filled with 0xFF)
     uint32_t cand_capacity = 0;
-    uint32_t *cand_head = nullptr;        // next free slot (advanced in per-wave chunks)
+    unsigned long long *cand_head = nullptr;  // next free slot (advanced in per-wave chunks; keeps counting past a full queue)
     // windows + tiles (device scratch, filled by launch_windows_tiles)
     uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]

@@ -277,13 +277,13 @@ class Engine:
                            d_ref_durations: int, n_ref: int, tol_int: int, ref_index_base: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
         """(hits [k,2] u32 sorted by (ref, cand), n_hits).  Grows the buffer once if it was too small."""
-        for _ in range(2):
+        for _ in range(6):
             hits = self._hit_buffer(capacity)
             n_hits = C.c_uint64(0)
             rc = self.lib.vdf_search_refs_device(self.ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes,
                                                  d_ref_durations, n_ref, int(tol_int), ref_index_base,
                                                  hits.ctypes.data, capacity, C.byref(n_hits), stream or None)
-            if rc == _capi.VDF_E_OVERFLOW:
+            if rc == _capi.VDF_E_OVERFLOW and int(n_hits.value) > capacity:
                 capacity = int(n_hits.value)
                 continue
             self._check(rc)
