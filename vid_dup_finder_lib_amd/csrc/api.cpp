@@ -713,9 +713,11 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
         } else {
             const uint64_t progress = complete_end - row_begin;
             if (progress == 0) {
-                // Not even one row fit: give a single row the whole buffer (its hits are < n).
+                // Not even one row fit: give a single row the whole buffer (its hits are < n), and a larger suspect queue
+                // (a row of a dense cluster has as many suspects as the cluster has members).
                 span = 1;
                 if (capacity < n) capacity = n;
+                for (int k = 0; k < G; k++) device_ctx(ctx, k)->cand_scale = std::min<uint64_t>(device_ctx(ctx, k)->cand_scale * 4, 1ull << 24);
             } else {
                 span = std::max<uint64_t>(progress * 2, device_ctx(ctx, 0)->tile_rows);
             }
@@ -747,6 +749,7 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     ctx->dev_stats.assign((size_t)G, vdf_search_stats{});
     vdf_search_stats agg{};
     for (int k = 0; k < G; k++) {
+        device_ctx(ctx, k)->cand_scale = 1;
         const vdf_search_stats &st = device_ctx(ctx, k)->stats;
         ctx->dev_stats[(size_t)k] = st;
         agg.pairs += st.pairs; agg.pairs_computed += st.pairs_computed; agg.n_hits += st.n_hits; agg.n_tiles += st.n_tiles;
