@@ -93,3 +93,34 @@ def test_full_hd_callers_overlap_batches(engine):
     assert n_clips == n and n_batches <= n // 4
     assert q.in_flight_max() >= 2
     q.close()
+
+
+def test_queue_on_a_multi_gpu_context_spreads_its_slots():
+    """A queue created on a multi-GPU context gets two slots per listed device (here: device 0 twice = 4 slots)."""
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd.engine import HashQueue
+
+    eng = vdf.Engine(devices=[0, 0])
+    try:
+        rng = np.random.default_rng(5)
+        n = 40
+        frames = rng.integers(0, 256, size=(n, 16, 72, 96), dtype=np.uint8)
+        want = eng.hash_frames(frames)
+        q = HashQueue(eng, 96, 72, max_batch=4, max_wait_us=50000)
+        got = [None] * n
+        start = threading.Barrier(n)
+
+        def worker(i):
+            start.wait()
+            got[i] = q.submit(frames[i])
+
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=120)
+        assert all(g is not None and np.array_equal(g[0], want[i]) for i, g in enumerate(got))
+        assert q.stats()[1] == n
+        q.close()
+    finally:
+        eng.close()
