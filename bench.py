@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--ten-million", type=int, default=10_000_000,
                     help="size of the north_star target leg (all-pairs at one GPU; 0 = skip; only at --gpus 1)")
     ap.add_argument("--no-valu", dest="valu_leg", action="store_false", help="skip the XOR+popcount backend leg")
+    ap.add_argument("--no-refs", dest="refs_leg", action="store_false", help="skip the search_with_references leg")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 inside ONE process through vdf_ctx_create_multi (no torch.distributed)")
     args = ap.parse_args()
@@ -514,6 +515,36 @@ def main():
                                               "algorithmic_frac": s10["pairs_computed"] * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
                                               "traffic": None}
         del w10, d10
+
+    # ---- search_with_references at the BASELINE configs[4] shape (hash-less half): 1 M candidates x 100 k references,
+    # log-uniform durations, +-5 % windows; half of the references are near-copies of candidates.  1 GPU, rank 0.
+    if rank == 0 and world == 1 and args.refs_leg:
+        n_c, n_r = 1_000_000, 100_000
+        rr = np.random.default_rng(20250615)
+        cw = make_hashes(n_c, 20250615, planted_every=10**9)
+        cdur = np.sort(np.floor(np.exp(rr.uniform(np.log(5), np.log(7200), size=n_c))).astype(np.uint32))
+        src_i = rr.choice(n_c, size=n_r // 2, replace=False)
+        rw = np.concatenate([cw[src_i], make_hashes(n_r - n_r // 2, 20250616, planted_every=10**9)])
+        rdur = np.concatenate([cdur[src_i], np.floor(np.exp(rr.uniform(np.log(5), np.log(7200), size=n_r - n_r // 2))).astype(np.uint32)])
+        pr = rr.permutation(n_r)
+        rw, rdur = rw[pr], rdur[pr]
+        tt = [torch.from_numpy(a).to(dev) for a in (cw.view(np.int64), cdur.view(np.int32), rw.view(np.int64), rdur.view(np.int32))]
+        torch.cuda.synchronize()
+        kms, wall = [], []
+        for i in range(args.steps + 1):
+            t1 = time.perf_counter()
+            hr, nh = eng.search_refs_device(tt[0].data_ptr(), tt[1].data_ptr(), n_c, tt[2].data_ptr(), tt[3].data_ptr(), n_r, tol_int,
+                                            stream=stream)
+            if i:
+                wall.append(time.perf_counter() - t1)
+                kms.append(eng.last_stats()["kernel_ms"])
+        sr = eng.last_stats()
+        out["refs_c5_shape"] = {"workload": "search_with_references, 1 M candidates x 100 k references (BASELINE configs[4] without the "
+                                            "hashing half), log-uniform durations, +-5 % windows, half of the references planted",
+                                "pairs": sr["pairs"], "pairs_computed": sr["pairs_computed"],
+                                "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "kernel_ms": float(np.mean(kms)),
+                                "ms": float(np.mean(wall)) * 1e3, "hits": int(nh), "pairs_per_s": sr["pairs"] / float(np.mean(wall))}
+        del tt
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM; clips are independent, so every rank hashes its
     # own args.hash_clips clips with no communication (weak scaling) and the job rate is the sum -----------------

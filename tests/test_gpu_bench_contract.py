@@ -35,6 +35,8 @@ def test_bench_emits_the_contract_line(backend):
     assert h["unit"] == "frames/s" and h["roofline"]["bound"] == "hbm" and h["cpu_baseline"]["kind"] == "port"
     assert d["match_groups"] > 0 and d["windowed"]["pairs"] > 0 and d["windowed"]["steps"] == 1
     assert d["windowed"]["waste_ratio"] >= 1.0
+    rf = d["refs_c5_shape"]
+    assert rf["hits"] == 50000 and 1.0 <= rf["waste_ratio"] < 1.5 and rf["kernel_ms"] > 0
     t = d["ten_million"]  # the north_star's target leg (here at a test size)
     assert t["n_hashes"] == 200000 and t["pairs"] == 200000 * 199999 // 2 and t["match_groups"] >= t["planted_pairs"] - 1
     if backend == "mfma":

@@ -22,7 +22,7 @@ def _bench(extra, env_extra=None):
     env = dict(os.environ, **(env_extra or {}))
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--hash-clips", "2000",
-                          "--hash-hd-clips", "0", "--ten-million", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu"] + extra,
+                          "--hash-hd-clips", "0", "--ten-million", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs"] + extra,
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

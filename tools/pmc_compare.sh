@@ -1,6 +1,6 @@
 # PMC view of the search kernels: pipe busy vs active cycles, clock, waits.  Usage: bash tools/pmc_r02l.sh <outdir> [variants...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; shift; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --ten-million 0 --no-valu"
+B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --ten-million 0 --no-valu --no-refs"
 for v in "$@"; do IFS=: read lib k <<< "$v"
   cp $R/tools/_libvdf_$lib.so $R/vid_dup_finder_lib_amd/libvdf_hip.so
   export VDF_MFMA_KERNEL=$k

@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --ten-million 0 --no-valu"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --ten-million 0 --no-valu --no-refs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/bench_under_profiler.json 2> /dev/null
-B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --ten-million 0 --no-valu"
+B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --ten-million 0 --no-valu --no-refs"
 H1="python3 $R/tools/bench_hash.py --steps 1"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
