@@ -598,6 +598,25 @@ def main():
                                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
             del hd, out_h
+            # a pitch that is not a multiple of the 128-byte line: the linear-stream kernel (LDS-DMA of whole chunks)
+            nq = 4000
+            sd = torch.randint(0, 256, (nq, 16, 270, 480), dtype=torch.uint8, device=dev, generator=g)
+            out_h = torch.zeros((nq, 16), dtype=torch.int64, device=dev)
+            eng.hash_frames_device(sd.data_ptr(), nq, 16, 480, 270, out_h.data_ptr(), stream=stream)
+            barrier()
+            ev0.record()
+            for _ in range(args.steps):
+                eng.hash_frames_device(sd.data_ptr(), nq, 16, 480, 270, out_h.data_ptr(), stream=stream)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms_sd = ev0.elapsed_time(ev1) / args.steps
+            gbs = nq * 16 * (480 * 270 + 8) / (ms_sd * 1e-3) / 1e9
+            out["hash"]["pitch_480x270"] = {"workload": f"{nq} clips of 16 x 270 x 480 u8 per GPU", "ms_per_step": ms_sd,
+                                            "frames_per_s_per_gpu": nq * 16 / (ms_sd * 1e-3),
+                                            "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
+                                                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+            del sd, out_h
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)

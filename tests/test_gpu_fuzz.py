@@ -121,13 +121,15 @@ def test_hash_fuzz_large_frames(seed):
     h, w = int(rng.integers(129, 900)), int(rng.integers(17, 1500))
     if seed % 4 == 0:
         w = (w + 127) // 128 * 128  # line-aligned pitch
+    elif seed % 4 == 1:
+        w = max(256, w // 16 * 16)  # multiple of 16: the linear-stream kernel unless it is also a multiple of 128
     frames = rng.integers(0, 256, size=(2, 16, h, w), dtype=np.uint8)
     if seed % 3 == 0:
         frames = (frames // 16 * 16 + rng.integers(0, 3, size=(2, 16, 1, 1))).astype(np.uint8)  # banded content
     want, coefs = orc.hash_clips_with_coefs(frames)
     care = np.abs(coefs) >= 1e-6
     wb = np.unpackbits(want.view(np.uint8), bitorder="little").reshape(2, 1024)[:, :1000]
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 5):
         os.environ["VDF_RESIZE_MODE"] = str(mode)
         try:
             eng = vdf.Engine(0)
@@ -136,7 +138,7 @@ def test_hash_fuzz_large_frames(seed):
         try:
             got = eng.hash_frames(frames)
         except vdf.VdfError as e:
-            assert mode in (2, 4) and e.code == -2, (mode, h, w, str(e))
+            assert mode in (2, 4, 5) and e.code == -2, (mode, h, w, str(e))
             continue
         finally:
             eng.close()

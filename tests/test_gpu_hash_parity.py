@@ -120,6 +120,60 @@ def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 5])
+@pytest.mark.parametrize("h,w,n", [(270, 480, 3), (129, 272, 45), (240, 320, 40), (288, 352, 3), (480, 720, 3), (540, 960, 2),
+                                   (200, 1360, 2), (333, 1440, 2), (130, 496, 3), (1080, 1520, 1), (191, 464, 3),
+                                   (360, 600, 3), (480, 854, 2), (240, 426, 40), (300, 500, 3), (256, 333, 3), (768, 1366, 1),
+                                   (360, 640, 3), (432, 768, 2), (720, 1280, 1)])
+def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
+    """Tightly packed frames whose every frame starts on a 16-byte boundary go through the linear-stream kernel (LDS-DMA of
+    whole chunks, operands read back from LDS) when the width is not a multiple of the 128-byte line, or is one and still
+    fits 64-row chunks: 480 / 272 / 320 / 352 / 464 wide = two workgroups per CU with 64-row chunks; 496 / 720 / 960 = the
+    large-LDS form with 64-row chunks, 1360 / 1440 / 1520 with 32-row chunks (two of the four waves multiply); 600 / 500 /
+    854 / 426 / 333 / 1366 wide = LDS operand reads that are only 8 / 4 / 2 / 1-byte aligned; 640 / 768 = line-aligned
+    widths the kernel also takes, 1280 only when forced (mode 5); 45 and 40 clips = more frames than resident workgroups,
+    so the persistent loop crosses frame boundaries; 270 / 129 / 333 / 191 rows = partial last chunks and partial blocks."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(5000 + h * 7 + w)
+        frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+        _check(eng, frames)
+    finally:
+        eng.close()
+
+
+def test_linear_stream_kernel_publishes_its_partial_sums():
+    """Regression: the per-frame partial sums of waves 1..3 cross a barrier that sits on the persistent loop's back edge, and
+    the compiler emitted that barrier without the LDS wait; wave 0 then read stale sums in about one launch in ten when two
+    workgroups shared a CU and the LDS pipe was busy (widths that are not a multiple of 16).  Fresh engines, 640 frames per
+    launch, every launch must reproduce the scalar kernel's hashes."""
+    import os
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(422)
+    frames = rng.integers(0, 256, size=(40, 16, 240, 422), dtype=np.uint8)
+
+    def run(mode, calls):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+        try:
+            return [eng.hash_frames(frames) for _ in range(calls)]
+        finally:
+            eng.close()
+
+    want = run(1, 1)[0]
+    for rep in range(12):
+        for got in run(0, 2):
+            assert np.array_equal(got, want), rep
+
+
 def test_full_hd_clip_matches_oracle(engine):
     """1080p (the size real decoders hand over): 68 row blocks, 15 windows of 128 bytes, all four waves busy."""
     rng = np.random.default_rng(1080)

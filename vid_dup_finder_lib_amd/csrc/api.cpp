@@ -397,7 +397,10 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         // Resize on the matrix cores (exact i8 x i8 -> i32): small frames fuse the DCT into the same kernel.
         // frames taller than two 64-row groups go to the per-frame kernel; its whole-line form is the default
         const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && (h + 63) / 64 <= 2);
-        const bool wide = !fused && ctx->resize_mode != 2;
+        // tightly packed frames whose pitch is not a multiple of the 128-byte line stream linearly through LDS
+        const bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
+                              vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->resize_mode == 5);
+        const bool wide = !fused && !streamed && ctx->resize_mode != 2;
         DeviceMfmaTable *mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
         DeviceMfmaTable *mv = mfma_table(ctx, h, wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, &rc);
@@ -420,8 +423,13 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
                 return VDF_OK;
             }
             VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-            VDF_HIP(ctx, vdf::launch_resize_mfma_frames(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
-                                                        ctx->small.as<uint8_t>(), wide, stream));
+            if (streamed) {
+                VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_clips, w, h, frame_stride, clip_stride, a,
+                                                                   ctx->small.as<uint8_t>(), stream));
+            } else {
+                VDF_HIP(ctx, vdf::launch_resize_mfma_frames(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
+                                                            ctx->small.as<uint8_t>(), wide, stream));
+            }
             VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips,
                                               ctx->cos_table.as<double>(), d_out, d_dc, stream));
             return VDF_OK;
@@ -621,7 +629,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     }
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
-        if (m >= 0 && m <= 4) ctx->resize_mode = m;
+        if (m >= 0 && m <= 5) ctx->resize_mode = m;
     }
     if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
         if (!std::strcmp(s, "valu")) ctx->search_backend = 0;

@@ -751,6 +751,259 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wide_kernel(const uint8
     }
 }
 
+static MfmaResizeTables make_tables(const MfmaResizeArgs &a);
+
+// 16 operand bytes of one lane from LDS at an address that is only ALIGN-aligned (row * W + x with W % 16 != 0): the
+// compiler picks ds_read_b128, ds_read2_b64, or one unaligned ds_read_b128
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+template <int ALIGN>
+__device__ __forceinline__ v4i lds_pixels16(const uint8_t *p)
+{
+    if constexpr (ALIGN == 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    } else if constexpr (ALIGN == 8) {
+        const u32x4_a8 v = *reinterpret_cast<const u32x4_a8 *>(p);
+        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    } else {
+        const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(p);
+        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+}
+
+
+// ---- large frames whose pitch is not a multiple of the 128-byte line ------------------------------------------
+// With W % 128 != 0 every row-shaped wave load above (16 x 64 B or 8 x 128 B) straddles lines: 480 x 270 read at 4.5 TB/s
+// while the same bytes read linearly stream at 6.2 (tools/ubench_rowload.hip).  Here the global side IS linear: a
+// persistent workgroup copies its frames chunk by chunk (16 nb rows = 16 nb W contiguous bytes) into LDS with LDS-DMA,
+// 1 KB per wave instruction, and the MFMA operands are read back from LDS at (row, x), where the pitch costs nothing.
+// Chunks are double buffered: the DMA of chunk s + 1 is in flight while the waves run the products of chunk s, wave m
+// taking 16-row block m of the chunk (the vertical partial sums of the waves are added through LDS at the end of a
+// frame, as in the kernels above).  Nothing inside the loop waits on a global load: the horizontal table lives in LDS,
+// the two vertical fragments of the NEXT chunk are requested before its DMA, and the frame's result is written after
+// the next barrier - so the only vmcnt wait is the one in front of the barrier that hands a chunk over.
+// The buffer resource is sized to the frame, so the last DMA of a frame cannot read past it (no CAREFUL variant).
+// The two pixel buffers and the table are separate arrays so the compiler knows a DMA into one does not alias reads of
+// the others.  Bit-identical to the other kernels (same products, same order of the exact integer sums).
+template <int BUF_BYTES, int TAB_TILES, int ALIGN>
+__global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+                                                                       uint32_t H, size_t frame_stride,
+                                                                       size_t clip_stride, uint32_t n_frames,
+                                                                       MfmaResizeTables T, uint32_t nb,
+                                                                       uint8_t *__restrict__ small)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_TILES * 2 * 64];
+    __shared__ __attribute__((aligned(16))) uint4 s_px0[BUF_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) uint4 s_px1[BUF_BYTES / 16];
+    __shared__ int32_t s_part[3][64][4];  // 256 hi + lo of waves 1..3 (the sums are exact in i32, as in finalize4)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
+    // ALIGN == 0: rows are re-pitched on the way in.  LDS holds them at a pitch of Wp = W rounded up to 16 bytes (every operand
+    // read is an aligned ds_read_b128 again) and each DMA lane fetches the 16 global bytes that belong at its LDS position:
+    // position P = row * Wp + x  <-  frame byte row * W + x.  The global side stays a linear sweep (a row's tail lanes
+    // run into the next row), only byte-misaligned, which the texture path handles.
+    constexpr bool kPad = ALIGN == 0;
+    const uint32_t Wp = kPad ? (W + 15u) & ~15u : W;
+    const uint32_t magic = kPad ? (uint32_t)((0x100000000ull + Wp - 1) / Wp) : 0u;  // row = P / Wp for P < 2^16
+    const int32_t bias_h = T.bias_h[r16];
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    for (uint32_t i = tid; i < (uint32_t)T.n_kt * 128u; i += 256u) {
+        const v4i v = T.bh[i];
+        s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    }
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+
+    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
+        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
+        const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
+        for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
+            auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
+            if constexpr (kPad) {
+                const uint32_t P = off + 16u * lane, row = __umulhi(P, magic);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + P - row * (Wp - W)), 0, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(16u * lane), (int)(start + off), 0, 0);
+            }
+        }
+    };
+    // vertical fragments of the 64-row group that holds this wave's block of chunk c
+    auto load_av = [&](uint32_t c, v4i &h, v4i &l) __attribute__((always_inline)) {
+        uint32_t rg = (c * nb + wave) >> 2;
+        rg = rg < (uint32_t)T.n_rg ? rg : (uint32_t)T.n_rg - 1u;
+        h = T.av[(rg * 2 + 0) * 64 + lane];
+        l = T.av[(rg * 2 + 1) * 64 + lane];
+    };
+
+    uint32_t F = blockIdx.x, c = 0;  // the chunk whose products run next
+    v4i acc_vh = zero4, acc_vl = zero4, pend_vh = zero4, pend_vl = zero4;
+    bool out_pending = false;
+    uint32_t out_F = 0;
+    auto write_pending = [&]() __attribute__((always_inline)) {  // after a barrier: wave 0 adds the partial sums of the frame that ended
+        if (out_pending && wave == 0) {
+            v4i vh = pend_vh, vl = pend_vl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                vl[r] += bias_v[r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) vl[r] += s_part[w][lane][r];
+            }
+            const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+            uint8_t *dst = small + (size_t)out_F * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        }
+        out_pending = false;
+    };
+    auto step = [&](const uint4 *cur, uint4 *nxt, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        __syncthreads();  // chunk (F, c) has landed in `cur` (vmcnt) and every wave is done with `nxt`
+        write_pending();
+        uint32_t Fn = F, cn = c + 1;
+        if (cn == n_chunks) { cn = 0; Fn = F + gridDim.x; }
+        if (Fn < n_frames) {
+            load_av(cn, avh_n, avl_n);
+            issue_dma(Fn, cn, nxt);
+        }
+        const uint32_t rows = min(rpc, H - c * rpc);
+        if (16u * wave < rows) {
+            v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + (16u * wave + r16) * Wp + 16u * g;
+            auto tile = [&](int kt) __attribute__((always_inline)) {
+                const v4i a = lds_pixels16<kPad ? 16 : ALIGN>(base + 64 * kt) ^ x80;
+                const uint4 th = s_tab[(kt * 2 + 0) * 64 + lane], tl = s_tab[(kt * 2 + 1) * 64 + lane];
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
+            };
+            int kt = 0;
+            for (; kt + 1 < T.n_kt; kt += 2) { tile(kt); tile(kt + 1); }  // two tiles' LDS reads in flight per wait
+            if (kt < T.n_kt) tile(kt);
+            const int val = (int)finalize4(ah, al, T.prec_h);
+            const uint32_t mb = (c * nb + wave) & 3u;  // block of the 64-row group: bytes 4 mb .. 4 mb + 3 of the operand
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) b[m] = mb == (uint32_t)m ? val : 0;
+            acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, acc_vh, 0, 0, 0);
+            acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
+        }
+        if (c + 1 == n_chunks) {  // frame complete: partial sums to LDS, the result is written after the next barrier
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
+                // The barrier that publishes these words is the one at the top of the next step, across the loop's back
+                // edge, and the compiler emitted it with a vmcnt wait only (seen in the ISA; wave 0 then read stale partial
+                // sums once in ~20 launches when two workgroups shared a CU): retire the LDS writes here.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            pend_vh = acc_vh; pend_vl = acc_vl;
+            acc_vh = zero4; acc_vl = zero4;
+            out_pending = true;
+            out_F = F;
+        }
+        F = Fn; c = cn;
+    };
+    v4i av0h = zero4, av0l = zero4, av1h = zero4, av1l = zero4;
+    if (F < n_frames) {
+        load_av(0, av0h, av0l);
+        issue_dma(F, 0, s_px0);
+    }
+    while (F < n_frames) {
+        step(s_px0, s_px1, av0h, av0l, av1h, av1l);
+        if (!(F < n_frames)) break;
+        step(s_px1, s_px0, av1h, av1l, av0h, av0l);
+    }
+    __syncthreads();
+    write_pending();
+}
+
+// LDS budget of the three instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide), M and L = one
+// workgroup per CU with the table of frames up to 1024 / 1536 wide and the rest of the 160 KB in the two chunk buffers
+constexpr int kStreamBufS = 30 * 1024 + 64, kStreamTabS = 8;
+constexpr int kStreamBufM = 62 * 1024 + 64, kStreamTabM = 16;
+constexpr int kStreamBufL = 52 * 1024 + 64, kStreamTabL = 24;
+
+static uint32_t stream_blocks_per_chunk(uint32_t w, int buf_bytes)
+{
+    for (uint32_t nb = 4; nb >= 1; nb--)
+        if ((size_t)((16u * nb * w + 1023u) & ~1023u) + 64u <= (size_t)buf_bytes) return nb;
+    return 0;
+}
+
+// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = L; *nb = 16-row blocks per chunk
+static int stream_class(uint32_t w, uint32_t *nb)
+{
+    const int n_kt = (int)((w + 63) / 64);
+    w = (w + 15u) & ~15u;  // the LDS row pitch at most (widths that are a multiple of 4 but not of 8 are re-pitched to this)
+    if (n_kt <= kStreamTabS && stream_blocks_per_chunk(w, kStreamBufS) == 4) { *nb = 4; return 1; }
+    if (n_kt <= kStreamTabM) { *nb = stream_blocks_per_chunk(w, kStreamBufM); return 2; }
+    *nb = stream_blocks_per_chunk(w, kStreamBufL);
+    return (n_kt <= kStreamTabL && *nb >= 2) ? 3 : 0;
+}
+
+// Tightly packed frames, every frame starting on a 16-byte boundary (the DMA moves 16 bytes per lane).  Widths that are a
+// multiple of the 128-byte line gain only while a chunk holds a whole 64-row group (measured: 640 and 768 wide +12 %,
+// 1024 and 1280 wide level with the whole-line kernel); aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                            bool aligned_too)
+{
+    if (w < 256 || (uint64_t)w * h >= (1ull << 31) || frame_stride != (size_t)w * h) return false;
+    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
+    uint32_t nb = 0;
+    const int cls = stream_class(w, &nb);
+    if (cls == 0) return false;
+    return w % 128 != 0 || nb == 4 || aligned_too;
+}
+
+template <int BUF, int TAB>
+static void launch_stream_aligned(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
+                                  size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
+                                  uint32_t nb, uint8_t *small)
+{
+    // Widths that are not a multiple of 16 (measured, GB/s of frame bytes): a multiple of 8 reads its operands with
+    // ds_read2_b64 at the frame's own pitch (600 wide: 5.7 TB/s; re-pitched 5.4); a multiple of 4 is re-pitched by the DMA
+    // (500 wide: 5.4 against 4.8 with ds_read2_b32 x 2); anything else keeps its pitch and reads unaligned ds_read_b128
+    // (854 wide: 4.4-5.0; 426: 5.5) because LDS-DMA drops the low two address bits of a global address.
+    if (w % 16 == 0)
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 16>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, n_frames, T, nb, small);
+    else if (w % 8 == 0)
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 8>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, n_frames, T, nb, small);
+    else if (w % 4 == 0)
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, n_frames, T, nb, small);
+    else
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, n_frames, T, nb, small);
+}
+
+hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
+                                            size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
+                                            uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    uint32_t nb = 0;
+    const int cls = stream_class(w, &nb);
+    if (n_clips * 16 > 0xFFFFFFFFull || cls == 0) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16);
+    if (cls == 1)
+        launch_stream_aligned<kStreamBufS, kStreamTabS>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
+                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    else if (cls == 2)
+        launch_stream_aligned<kStreamBufM, kStreamTabM>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    else
+        launch_stream_aligned<kStreamBufL, kStreamTabL>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_generic(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                  size_t clip_stride, ResizeAxisTable th, ResizeAxisTable tv, int need_h, int need_v,
                                  int32_t y_first, int32_t tmp_rows, uint8_t *small, hipStream_t stream)

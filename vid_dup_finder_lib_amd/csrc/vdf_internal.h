@@ -104,6 +104,13 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
 hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                      size_t frame_stride, size_t clip_stride, const uint8_t *buf_end,
                                      const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream);
+// linear-stream form for tightly packed frames whose width is a multiple of 16 but not of the 128-byte line
+// (a.av in kMfmaLayoutVertical order); resize_stream_eligible says whether a call qualifies
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                            bool aligned_too);
+hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
+                                            size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
+                                            uint8_t *small, hipStream_t stream);
 // ---- letterbox crop detection + cropped resize -------------------------------------------
 struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
     uint32_t x0, y0, w, h;
