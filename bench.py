@@ -594,7 +594,7 @@ def main():
             gbs = nh * 16 * (1920 * 1080 + 8) / (ms_hd * 1e-3) / 1e9
             out["hash"]["full_hd"] = {"workload": f"{nh} clips of 16 x 1080 x 1920 u8 per GPU", "ms_per_step": ms_hd,
                                       "frames_per_s_per_gpu": nh * 16 / (ms_hd * 1e-3),
-                                      "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_wide_kernel",
+                                      "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
                                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                    "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
             del hd, out_h

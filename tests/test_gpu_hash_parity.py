@@ -124,14 +124,16 @@ def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
 @pytest.mark.parametrize("h,w,n", [(270, 480, 3), (129, 272, 45), (240, 320, 40), (288, 352, 3), (480, 720, 3), (540, 960, 2),
                                    (200, 1360, 2), (333, 1440, 2), (130, 496, 3), (1080, 1520, 1), (191, 464, 3),
                                    (360, 600, 3), (480, 854, 2), (240, 426, 40), (300, 500, 3), (256, 333, 3), (768, 1366, 1),
-                                   (360, 640, 3), (432, 768, 2), (720, 1280, 1)])
+                                   (360, 640, 3), (432, 768, 2), (720, 1280, 1), (1080, 1920, 1), (300, 1984, 1), (300, 2000, 1),
+                                   (900, 1600, 1), (576, 1024, 1)])
 def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     """Tightly packed frames whose every frame starts on a 16-byte boundary go through the linear-stream kernel (LDS-DMA of
     whole chunks, operands read back from LDS) when the width is not a multiple of the 128-byte line, or is one and still
     fits 64-row chunks: 480 / 272 / 320 / 352 / 464 wide = two workgroups per CU with 64-row chunks; 496 / 720 / 960 = the
     large-LDS form with 64-row chunks, 1360 / 1440 / 1520 with 32-row chunks (two of the four waves multiply); 600 / 500 /
     854 / 426 / 333 / 1366 wide = LDS operand reads that are only 8 / 4 / 2 / 1-byte aligned; 640 / 768 = line-aligned
-    widths the kernel also takes, 1280 only when forced (mode 5); 45 and 40 clips = more frames than resident workgroups,
+    widths the kernel also takes; wider than 1024 = the horizontal table in band form (only the K tiles an output's taps
+    reach), 32- or 48-row chunks; 2000 wide = too wide, falls back to the whole-line kernel; 45 and 40 clips = more frames than resident workgroups,
     so the persistent loop crosses frame boundaries; 270 / 129 / 333 / 191 rows = partial last chunks and partial blocks."""
     import vid_dup_finder_lib_amd as vdf
 

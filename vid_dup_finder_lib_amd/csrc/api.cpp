@@ -304,10 +304,12 @@ DeviceMfmaTable *mfma_table(vdf_ctx *ctx, uint32_t in_size, int layout, hipStrea
     if (t->host.ok) {
         r = upload(ctx, t->operand, t->host.operand.data(), t->host.operand.size(), stream);
         if (r == VDF_OK) r = upload(ctx, t->bias, t->host.bias.data(), t->host.bias.size() * 4, stream);
+        if (r == VDF_OK && !t->host.band_meta.empty())
+            r = upload(ctx, t->meta, t->host.band_meta.data(), t->host.band_meta.size() * 4, stream);
         if (r == VDF_OK && hipStreamSynchronize(stream) != hipSuccess) r = fail(ctx, VDF_E_HIP, "table upload failed");
     }
     if (r != VDF_OK) {
-        t->operand.release(); t->bias.release();
+        t->operand.release(); t->bias.release(); t->meta.release();
         delete t;
         *rc = r;
         return nullptr;
@@ -397,11 +399,17 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         // Resize on the matrix cores (exact i8 x i8 -> i32): small frames fuse the DCT into the same kernel.
         // frames taller than two 64-row groups go to the per-frame kernel; its whole-line form is the default
         const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && (h + 63) / 64 <= 2);
-        // tightly packed frames whose pitch is not a multiple of the 128-byte line stream linearly through LDS
-        const bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
-                              vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->resize_mode == 5);
+        // tightly packed frames stream linearly through LDS where that is the faster form (resize_stream_eligible)
+        bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
+                        vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->resize_mode == 5);
+        DeviceMfmaTable *mh = nullptr;
+        if (streamed && vdf::resize_stream_wants_band(w)) {  // wide frames: the horizontal table in band form
+            mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontalBand, stream, &rc);
+            if (rc) return rc;
+            if (!mh->host.ok) { streamed = false; mh = nullptr; }
+        }
         const bool wide = !fused && !streamed && ctx->resize_mode != 2;
-        DeviceMfmaTable *mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
+        if (!mh) mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
         DeviceMfmaTable *mv = mfma_table(ctx, h, wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, &rc);
         if (rc) return rc;
@@ -415,6 +423,10 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             a.prec_v = mv->host.precision;
             a.n_kt = mh->host.n_tiles;
             a.n_rg = mv->host.n_tiles;
+            if (!mh->host.band_meta.empty()) {
+                a.band_meta = mh->meta.as<int32_t>();
+                a.band_stride = mh->host.band_stride;
+            }
             a.no_persistent = ctx->hash_no_persistent;
             a.persistent_wgs_per_cu = ctx->hash_wgs_per_cu;
             if (fused) {

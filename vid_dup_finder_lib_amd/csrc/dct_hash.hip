@@ -12,6 +12,7 @@
 // per axis that are consumed, sign test, __ballot pack: ballot of wave-word w IS hash word w).
 #include <algorithm>
 
+#include "resize_tables.h"
 #include "vdf_internal.h"
 
 namespace vdf {
@@ -299,6 +300,8 @@ struct MfmaResizeTables {
     const int32_t *bias_h;  // [16]
     const int32_t *bias_v;  // [16]
     int32_t prec_h, prec_v, n_kt, n_rg;
+    const int32_t *band_meta;  // bh in band form (linear-stream kernel, wide frames): kt_lo[16], nt[16]
+    int32_t band_stride;
 };
 
 template <bool CAREFUL>
@@ -785,7 +788,7 @@ __device__ __forceinline__ v4i lds_pixels16(const uint8_t *p)
 // The buffer resource is sized to the frame, so the last DMA of a frame cannot read past it (no CAREFUL variant).
 // The two pixel buffers and the table are separate arrays so the compiler knows a DMA into one does not alias reads of
 // the others.  Bit-identical to the other kernels (same products, same order of the exact integer sums).
-template <int BUF_BYTES, int TAB_TILES, int ALIGN>
+template <int BUF_BYTES, int TAB_TILES, int ALIGN, bool BAND>
 __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                        uint32_t H, size_t frame_stride,
                                                                        size_t clip_stride, uint32_t n_frames,
@@ -810,9 +813,20 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     v4i bias_v;
 #pragma unroll
     for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
-    for (uint32_t i = tid; i < (uint32_t)T.n_kt * 128u; i += 256u) {
+    // horizontal table -> LDS: all K tiles, or (BAND, wide frames) only the tiles each output's taps reach, output-major
+    const uint32_t tab_vecs = BAND ? (uint32_t)T.band_stride : (uint32_t)T.n_kt * 128u;  // 16 outputs x stride / 16 bytes
+    for (uint32_t i = tid; i < tab_vecs; i += 256u) {
         const v4i v = T.bh[i];
         s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    }
+    int32_t band_lo = 0;
+    uint32_t band_nt = 0, band_base = 0;
+    const uint32_t band_zero = 16u * tab_vecs;  // 128 zero bytes behind the band table
+    if constexpr (BAND) {
+        if (tid < 8) s_tab[tab_vecs + tid] = uint4{0, 0, 0, 0};
+        band_lo = T.band_meta[r16];
+        band_nt = (uint32_t)T.band_meta[16 + r16];
+        band_base = r16 * (uint32_t)T.band_stride + 16u * g;
     }
     const v4i zero4 = {0, 0, 0, 0};
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
@@ -874,13 +888,22 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + (16u * wave + r16) * Wp + 16u * g;
             auto tile = [&](int kt) __attribute__((always_inline)) {
                 const v4i a = lds_pixels16<kPad ? 16 : ALIGN>(base + 64 * kt) ^ x80;
-                const uint4 th = s_tab[(kt * 2 + 0) * 64 + lane], tl = s_tab[(kt * 2 + 1) * 64 + lane];
+                uint4 th, tl;
+                if constexpr (BAND) {  // no branch: lanes outside their output's band read the zero slot behind the table
+                    const uint32_t j = (uint32_t)(kt - band_lo);
+                    const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
+                    th = *reinterpret_cast<const uint4 *>(q);
+                    tl = *reinterpret_cast<const uint4 *>(q + 64);
+                } else {
+                    th = s_tab[(kt * 2 + 0) * 64 + lane];
+                    tl = s_tab[(kt * 2 + 1) * 64 + lane];
+                }
                 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
                 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
             };
             int kt = 0;
-            for (; kt + 1 < T.n_kt; kt += 2) { tile(kt); tile(kt + 1); }  // two tiles' LDS reads in flight per wait
-            if (kt < T.n_kt) tile(kt);
+            for (; kt + 3 < T.n_kt; kt += 4) { tile(kt); tile(kt + 1); tile(kt + 2); tile(kt + 3); }  // four tiles' LDS reads per wait
+            for (; kt < T.n_kt; kt++) tile(kt);
             const int val = (int)finalize4(ah, al, T.prec_h);
             const uint32_t mb = (c * nb + wave) & 3u;  // block of the 64-row group: bytes 4 mb .. 4 mb + 3 of the operand
             v4i b;
@@ -919,11 +942,12 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     write_pending();
 }
 
-// LDS budget of the three instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide), M and L = one
-// workgroup per CU with the table of frames up to 1024 / 1536 wide and the rest of the 160 KB in the two chunk buffers
+// LDS budget of the instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide); M = one workgroup
+// per CU, 32 KB of table and two 62 KB chunk buffers: frames up to 1024 wide keep the whole table there, wider ones
+// (up to 1984: two 16-row blocks per chunk) the band form (16 outputs x at most 15 tiles x 128 B + padding)
 constexpr int kStreamBufS = 30 * 1024 + 64, kStreamTabS = 8;
 constexpr int kStreamBufM = 62 * 1024 + 64, kStreamTabM = 16;
-constexpr int kStreamBufL = 52 * 1024 + 64, kStreamTabL = 24;
+static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
 
 static uint32_t stream_blocks_per_chunk(uint32_t w, int buf_bytes)
 {
@@ -932,20 +956,27 @@ static uint32_t stream_blocks_per_chunk(uint32_t w, int buf_bytes)
     return 0;
 }
 
-// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = L; *nb = 16-row blocks per chunk
+// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
 static int stream_class(uint32_t w, uint32_t *nb)
 {
     const int n_kt = (int)((w + 63) / 64);
     w = (w + 15u) & ~15u;  // the LDS row pitch at most (widths that are a multiple of 4 but not of 8 are re-pitched to this)
     if (n_kt <= kStreamTabS && stream_blocks_per_chunk(w, kStreamBufS) == 4) { *nb = 4; return 1; }
-    if (n_kt <= kStreamTabM) { *nb = stream_blocks_per_chunk(w, kStreamBufM); return 2; }
-    *nb = stream_blocks_per_chunk(w, kStreamBufL);
-    return (n_kt <= kStreamTabL && *nb >= 2) ? 3 : 0;
+    *nb = stream_blocks_per_chunk(w, kStreamBufM);
+    if (n_kt <= kStreamTabM) return 2;
+    return *nb >= 2 ? 3 : 0;
+}
+
+bool resize_stream_wants_band(uint32_t w)
+{
+    uint32_t nb = 0;
+    return stream_class(w, &nb) == 3;
 }
 
 // Tightly packed frames, every frame starting on a 16-byte boundary (the DMA moves 16 bytes per lane).  Widths that are a
-// multiple of the 128-byte line gain only while a chunk holds a whole 64-row group (measured: 640 and 768 wide +12 %,
-// 1024 and 1280 wide level with the whole-line kernel); aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
+// multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
+// kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1024 and 1536 wide - 2 % with 48 KB chunks);
+// aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too)
 {
@@ -954,10 +985,10 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
     if (cls == 0) return false;
-    return w % 128 != 0 || nb == 4 || aligned_too;
+    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || aligned_too;
 }
 
-template <int BUF, int TAB>
+template <int BUF, int TAB, bool BAND>
 static void launch_stream_aligned(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
                                   size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
                                   uint32_t nb, uint8_t *small)
@@ -967,16 +998,16 @@ static void launch_stream_aligned(uint32_t grid, hipStream_t stream, const uint8
     // (500 wide: 5.4 against 4.8 with ds_read2_b32 x 2); anything else keeps its pitch and reads unaligned ds_read_b128
     // (854 wide: 4.4-5.0; 426: 5.5) because LDS-DMA drops the low two address bits of a global address.
     if (w % 16 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 16>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 16, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, small);
     else if (w % 8 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 8>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 8, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, small);
     else if (w % 4 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, small);
     else
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, small);
 }
 
@@ -992,15 +1023,16 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
+    if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
     if (cls == 1)
-        launch_stream_aligned<kStreamBufS, kStreamTabS>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
-                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_aligned<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w,
+                                                               h, frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     else if (cls == 2)
-        launch_stream_aligned<kStreamBufM, kStreamTabM>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_aligned<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                               frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     else
-        launch_stream_aligned<kStreamBufL, kStreamTabL>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                        frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_aligned<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                              frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     return hipGetLastError();
 }
 
@@ -1049,6 +1081,8 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
     T.prec_v = tv.precision;
     T.n_kt = th.n_tiles;
     T.n_rg = tv.n_tiles;
+    T.band_meta = nullptr;
+    T.band_stride = 0;
     v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
     const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
     // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very
@@ -1106,6 +1140,8 @@ static MfmaResizeTables make_tables(const MfmaResizeArgs &a)
     T.prec_v = a.prec_v;
     T.n_kt = a.n_kt;
     T.n_rg = a.n_rg;
+    T.band_meta = a.band_meta;
+    T.band_stride = a.band_stride;
     return T;
 }
 

@@ -5,6 +5,7 @@
 // ResizeAlg::Convolution(FilterType::Lanczos3) on PixelType::U8 with the whole image as crop box.
 // The crate's published algorithm: per output pixel a window of f64 weights normalised to 1,
 // quantised to i16 with the largest precision p such that round(max_w * 2^(p+1)) < 2^15.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -103,6 +104,34 @@ bool build_mfma_axis_table(uint32_t in_size, int layout, MfmaAxisTable &t)
         int64_t sum = 0;
         for (int32_t x = 0; x < n_tiles * 64; x++) sum += full[(size_t)o * n_tiles * 64 + x];
         t.bias[o] = (int32_t)((1 << (precision - 1)) + 128 * sum);
+    }
+    if (layout == kMfmaLayoutHorizontalBand) {
+        t.band_meta.assign(32, 0);
+        int32_t max_nt = 1;
+        for (uint32_t o = 0; o < D; o++) {
+            int32_t lo = n_tiles, hi = -1;
+            for (int32_t x = 0; x < n_tiles * 64; x++)
+                if (full[(size_t)o * n_tiles * 64 + x] != 0) { lo = std::min(lo, x / 64); hi = std::max(hi, x / 64); }
+            if (hi < lo) { lo = 0; hi = 0; }
+            t.band_meta[o] = lo;
+            t.band_meta[16 + o] = hi - lo + 1;
+            max_nt = std::max(max_nt, hi - lo + 1);
+        }
+        if (max_nt > kMfmaBandMaxTiles) t.ok = false;
+        t.band_stride = max_nt * 128 + 32;  // + 32: consecutive outputs start 8 banks apart
+        t.operand.assign((size_t)D * t.band_stride, 0);
+        for (uint32_t o = 0; o < D; o++)
+            for (int32_t j = 0; j < t.band_meta[16 + o]; j++)
+                for (int g = 0; g < 4; g++)
+                    for (int b = 0; b < 16; b++) {
+                        const int32_t c = full[(size_t)o * n_tiles * 64 + 64 * (t.band_meta[o] + j) + 16 * g + b];
+                        const int32_t lo = ((c + 128) & 255) - 128, hi = (c - lo) / 256;
+                        if (hi < -128 || hi > 127) t.ok = false;
+                        int8_t *q = t.operand.data() + (size_t)o * t.band_stride + (size_t)j * 128 + g * 16 + b;
+                        q[0] = (int8_t)hi;
+                        q[64] = (int8_t)lo;
+                    }
+        return true;
     }
     for (int32_t tile = 0; tile < n_tiles; tile++)
         for (int l = 0; l < 64; l++)

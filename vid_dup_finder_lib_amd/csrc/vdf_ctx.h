@@ -64,7 +64,7 @@ struct DeviceAxisTable {
 };
 
 struct DeviceMfmaTable {
-    DevBuf operand, bias;
+    DevBuf operand, bias, meta;  // meta: the band form's kt_lo[16], nt[16]
     vdf::MfmaAxisTable host;
 };
 

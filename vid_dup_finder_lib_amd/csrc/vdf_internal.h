@@ -94,6 +94,8 @@ struct MfmaResizeArgs {  // device pointers to the MFMA-layout tables (resize_ta
     const void *bh, *av;
     const int32_t *bias_h, *bias_v;
     int32_t prec_h, prec_v, n_kt, n_rg;
+    const int32_t *band_meta = nullptr;  // bh in band form (resize_tables.h): kt_lo[16], nt[16] on the device
+    int32_t band_stride = 0;
     int32_t no_persistent = 0;         // debugging: force the one-clip-per-workgroup fused kernel
     int32_t persistent_wgs_per_cu = 3; // resident workgroups per CU for the persistent kernel
 };
@@ -108,6 +110,7 @@ hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint
 // (a.av in kMfmaLayoutVertical order); resize_stream_eligible says whether a call qualifies
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too);
+bool resize_stream_wants_band(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
                                             uint8_t *small, hipStream_t stream);
