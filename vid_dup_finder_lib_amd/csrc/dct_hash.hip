@@ -756,43 +756,33 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wide_kernel(const uint8
 
 static MfmaResizeTables make_tables(const MfmaResizeArgs &a);
 
-// 16 operand bytes of one lane from LDS at an address that is only ALIGN-aligned (row * W + x with W % 16 != 0): the
-// compiler picks ds_read_b128, ds_read2_b64, or one unaligned ds_read_b128
-typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-template <int ALIGN>
-__device__ __forceinline__ v4i lds_pixels16(const uint8_t *p)
-{
-    if constexpr (ALIGN == 16) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p);
-        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-    } else if constexpr (ALIGN == 8) {
-        const u32x4_a8 v = *reinterpret_cast<const u32x4_a8 *>(p);
-        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-    } else {
-        const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(p);
-        return (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-    }
-}
-
-
-// ---- large frames whose pitch is not a multiple of the 128-byte line ------------------------------------------
-// With W % 128 != 0 every row-shaped wave load above (16 x 64 B or 8 x 128 B) straddles lines: 480 x 270 read at 4.5 TB/s
-// while the same bytes read linearly stream at 6.2 (tools/ubench_rowload.hip).  Here the global side IS linear: a
-// persistent workgroup copies its frames chunk by chunk (16 nb rows = 16 nb W contiguous bytes) into LDS with LDS-DMA,
-// 1 KB per wave instruction, and the MFMA operands are read back from LDS at (row, x), where the pitch costs nothing.
-// Chunks are double buffered: the DMA of chunk s + 1 is in flight while the waves run the products of chunk s, wave m
-// taking 16-row block m of the chunk (the vertical partial sums of the waves are added through LDS at the end of a
-// frame, as in the kernels above).  Nothing inside the loop waits on a global load: the horizontal table lives in LDS,
-// the two vertical fragments of the NEXT chunk are requested before its DMA, and the frame's result is written after
-// the next barrier - so the only vmcnt wait is the one in front of the barrier that hands a chunk over.
+// ---- large frames, linear-stream form ------------------------------------------------------------------------
+// With W % 128 != 0 every row-shaped wave load above (16 x 64 B or 8 x 128 B) straddles lines: 480 x 270 read at 4.6 TB/s
+// while the same bytes read linearly stream at 6.2 (tools/ubench_rowload.hip), and even line-aligned rows cap at 5.7.
+// Here the global side IS linear: a persistent workgroup copies its frames chunk by chunk (16 nb rows = 16 nb W contiguous
+// bytes) into LDS with LDS-DMA, 1 KB per wave instruction, and the MFMA operands are read back from LDS at (row, x), where
+// the pitch costs nothing.  Chunks are double buffered: the DMA of chunk s + 1 is in flight while the waves run the
+// products of chunk s, wave m taking 16-row block m of the chunk (the vertical partial sums of the waves are added through
+// LDS at the end of a frame, as in the kernels above).  Nothing inside the loop waits on a global load: the horizontal
+// table lives in LDS, the two vertical fragments of the NEXT chunk are requested before its DMA, and the frame's result
+// is written after the next barrier - so the only vmcnt wait is the one in front of the barrier that hands a chunk over.
 // The buffer resource is sized to the frame, so the last DMA of a frame cannot read past it (no CAREFUL variant).
 // The two pixel buffers and the table are separate arrays so the compiler knows a DMA into one does not alias reads of
 // the others.  Bit-identical to the other kernels (same products, same order of the exact integer sums).
-template <int BUF_BYTES, int TAB_TILES, int ALIGN, bool BAND>
+//
+// MODE 0 (W % 16 == 0): LDS holds the chunk as it is in memory, pitch W; one DMA instruction = 1 KB of the frame.
+// MODE 1, 2 (any other width): rows are RE-PITCHED on the way in.  LDS holds them at a pitch Wp that is an odd multiple of
+// 16 bytes - every operand read is an aligned ds_read_b128 and the 16 rows of a block fall into 16 different bank groups
+// (at the frame's own pitch 854 wide put six rows on the same banks and the LDS pipe became the limit: 4.5 TB/s) - and
+// each DMA lane fetches the 16 global bytes that belong at its LDS position: position row * Wp + x  <-  frame byte
+// row * W + x.  The global side is still a linear sweep (a row's tail lanes run into the next row).  LDS-DMA ignores the
+// low two bits of a global address, so MODE 2 (W % 4 != 0) starts each row at the dword below it and the operand read
+// takes one more dword and shifts by the row's 0..3 bytes (v_alignbyte, a per-lane constant).
+template <int BUF_BYTES, int TAB_TILES, int MODE, bool BAND>
 __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                        uint32_t H, size_t frame_stride,
                                                                        size_t clip_stride, uint32_t n_frames,
-                                                                       MfmaResizeTables T, uint32_t nb,
+                                                                       MfmaResizeTables T, uint32_t nb, uint32_t Wp,
                                                                        uint8_t *__restrict__ small)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_TILES * 2 * 64];
@@ -802,13 +792,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
-    // ALIGN == 0: rows are re-pitched on the way in.  LDS holds them at a pitch of Wp = W rounded up to 16 bytes (every operand
-    // read is an aligned ds_read_b128 again) and each DMA lane fetches the 16 global bytes that belong at its LDS position:
-    // position P = row * Wp + x  <-  frame byte row * W + x.  The global side stays a linear sweep (a row's tail lanes
-    // run into the next row), only byte-misaligned, which the texture path handles.
-    constexpr bool kPad = ALIGN == 0;
-    const uint32_t Wp = kPad ? (W + 15u) & ~15u : W;
-    const uint32_t magic = kPad ? (uint32_t)((0x100000000ull + Wp - 1) / Wp) : 0u;  // row = P / Wp for P < 2^16
+    const uint32_t magic = MODE ? (uint32_t)((0x100000000ull + Wp - 1) / Wp) : 0u;  // row = P / Wp for P < 2^16
     const int32_t bias_h = T.bias_h[r16];
     v4i bias_v;
 #pragma unroll
@@ -837,11 +821,12 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
-            if constexpr (kPad) {
-                const uint32_t P = off + 16u * lane, row = __umulhi(P, magic);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + P - row * (Wp - W)), 0, 0, 0);
-            } else {
+            if constexpr (MODE == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(16u * lane), (int)(start + off), 0, 0);
+            } else {
+                const uint32_t P = off + 16u * lane, row = __umulhi(P, magic), x = P - row * Wp;
+                const uint32_t row_start = MODE == 2 ? (row * W) & ~3u : row * W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + row_start + x), 0, 0, 0);
             }
         }
     };
@@ -885,9 +870,20 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         const uint32_t rows = min(rpc, H - c * rpc);
         if (16u * wave < rows) {
             v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
-            const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + (16u * wave + r16) * Wp + 16u * g;
+            const uint32_t row = 16u * wave + r16;  // in the chunk; chunks start on multiples of 16 rows, so (row * W) & 3 is the frame row's
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + row * Wp + 16u * g;
+            const uint32_t shift = MODE == 2 ? (row * W) & 3u : 0u;
             auto tile = [&](int kt) __attribute__((always_inline)) {
-                const v4i a = lds_pixels16<kPad ? 16 : ALIGN>(base + 64 * kt) ^ x80;
+                const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
+                v4i a = {(int)p.x, (int)p.y, (int)p.z, (int)p.w};
+                if constexpr (MODE == 2) {
+                    const uint32_t nx = *reinterpret_cast<const uint32_t *>(base + 64 * kt + 16);
+                    a[0] = (int)__builtin_amdgcn_alignbyte(p.y, p.x, shift);
+                    a[1] = (int)__builtin_amdgcn_alignbyte(p.z, p.y, shift);
+                    a[2] = (int)__builtin_amdgcn_alignbyte(p.w, p.z, shift);
+                    a[3] = (int)__builtin_amdgcn_alignbyte(nx, p.w, shift);
+                }
+                a = a ^ x80;
                 uint4 th, tl;
                 if constexpr (BAND) {  // no branch: lanes outside their output's band read the zero slot behind the table
                     const uint32_t j = (uint32_t)(kt - band_lo);
@@ -945,14 +941,24 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 // LDS budget of the instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide); M = one workgroup
 // per CU, 32 KB of table and two 62 KB chunk buffers: frames up to 1024 wide keep the whole table there, wider ones
 // (up to 1984: two 16-row blocks per chunk) the band form (16 outputs x at most 15 tiles x 128 B + padding)
-constexpr int kStreamBufS = 30 * 1024 + 64, kStreamTabS = 8;
-constexpr int kStreamBufM = 62 * 1024 + 64, kStreamTabM = 16;
+constexpr int kStreamBufS = 30 * 1024 + 128, kStreamTabS = 8;
+constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
 static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
 
-static uint32_t stream_blocks_per_chunk(uint32_t w, int buf_bytes)
+// LDS row pitch: the frame's own for multiples of 16; otherwise the next odd multiple of 16 that holds the row and the
+// up to 3 bytes a dword-aligned row start puts in front of it
+static uint32_t stream_pitch(uint32_t w)
+{
+    if (w % 16 == 0) return w;
+    uint32_t wp = (w + (w % 4 ? 3u : 0u) + 15u) & ~15u;
+    if ((wp / 16) % 2 == 0) wp += 16;
+    return wp;
+}
+
+static uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes)
 {
     for (uint32_t nb = 4; nb >= 1; nb--)
-        if ((size_t)((16u * nb * w + 1023u) & ~1023u) + 64u <= (size_t)buf_bytes) return nb;
+        if ((size_t)((16u * nb * wp + 1023u) & ~1023u) + 128u <= (size_t)buf_bytes) return nb;  // + the operand reads' overrun
     return 0;
 }
 
@@ -960,10 +966,10 @@ static uint32_t stream_blocks_per_chunk(uint32_t w, int buf_bytes)
 static int stream_class(uint32_t w, uint32_t *nb)
 {
     const int n_kt = (int)((w + 63) / 64);
-    w = (w + 15u) & ~15u;  // the LDS row pitch at most (widths that are a multiple of 4 but not of 8 are re-pitched to this)
-    if (n_kt <= kStreamTabS && stream_blocks_per_chunk(w, kStreamBufS) == 4) { *nb = 4; return 1; }
-    *nb = stream_blocks_per_chunk(w, kStreamBufM);
-    if (n_kt <= kStreamTabM) return 2;
+    const uint32_t wp = stream_pitch(w);
+    if (n_kt <= kStreamTabS && stream_blocks_per_chunk(wp, kStreamBufS) == 4) { *nb = 4; return 1; }
+    *nb = stream_blocks_per_chunk(wp, kStreamBufM);
+    if (n_kt <= kStreamTabM) return *nb >= 2 ? 2 : 0;
     return *nb >= 2 ? 3 : 0;
 }
 
@@ -989,26 +995,20 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
 }
 
 template <int BUF, int TAB, bool BAND>
-static void launch_stream_aligned(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
-                                  size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
-                                  uint32_t nb, uint8_t *small)
+static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
+                               size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
+                               uint32_t nb, uint8_t *small)
 {
-    // Widths that are not a multiple of 16 (measured, GB/s of frame bytes): a multiple of 8 reads its operands with
-    // ds_read2_b64 at the frame's own pitch (600 wide: 5.7 TB/s; re-pitched 5.4); a multiple of 4 is re-pitched by the DMA
-    // (500 wide: 5.4 against 4.8 with ds_read2_b32 x 2); anything else keeps its pitch and reads unaligned ds_read_b128
-    // (854 wide: 4.4-5.0; 426: 5.5) because LDS-DMA drops the low two address bits of a global address.
+    const uint32_t wp = stream_pitch(w);
     if (w % 16 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 16, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, small);
-    else if (w % 8 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 8, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, small);
-    else if (w % 4 == 0)
         hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, small);
-    else
+                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
+    else if (w % 4 == 0)
         hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, small);
+                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
+    else
+        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 2, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
 }
 
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
@@ -1025,14 +1025,14 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
     if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
     if (cls == 1)
-        launch_stream_aligned<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w,
-                                                               h, frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_mode<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
+                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     else if (cls == 2)
-        launch_stream_aligned<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                               frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     else
-        launch_stream_aligned<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                              frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+        launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
+                                                           frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
     return hipGetLastError();
 }
 
