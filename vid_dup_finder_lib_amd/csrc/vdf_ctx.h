@@ -92,6 +92,7 @@ struct vdf_ctx {
     // hash scratch
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables;
     PinBuf pin[2], pin_out[2];
+    PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
