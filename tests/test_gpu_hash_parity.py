@@ -131,7 +131,8 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     whole chunks, operands read back from LDS) when the width is not a multiple of the 128-byte line, or is one and still
     fits 64-row chunks: 480 / 272 / 320 / 352 / 464 wide = two workgroups per CU with 64-row chunks; 496 / 720 / 960 = the
     large-LDS form with 64-row chunks, 1360 / 1440 / 1520 with 32-row chunks (two of the four waves multiply); 600 / 500 /
-    854 / 426 / 333 / 1366 wide = LDS operand reads that are only 8 / 4 / 2 / 1-byte aligned; 640 / 768 = line-aligned
+    854 / 426 / 333 / 1366 wide = rows re-pitched by the DMA to an odd multiple of 16 bytes, the last four with the 0..3-byte
+    operand shift (row starts that are not dword-aligned); 640 / 768 = line-aligned
     widths the kernel also takes; wider than 1024 = the horizontal table in band form (only the K tiles an output's taps
     reach), 32- or 48-row chunks; 2000 wide = too wide, falls back to the whole-line kernel; 45 and 40 clips = more frames than resident workgroups,
     so the persistent loop crosses frame boundaries; 270 / 129 / 333 / 191 rows = partial last chunks and partial blocks."""

@@ -822,7 +822,8 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
             if constexpr (MODE == 0) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(16u * lane), (int)(start + off), 0, 0);
+                // the whole byte offset goes into the VGPR offset: that is the field the frame-sized range check surely covers
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, 0);
             } else {
                 const uint32_t P = off + 16u * lane, row = __umulhi(P, magic), x = P - row * Wp;
                 const uint32_t row_start = MODE == 2 ? (row * W) & ~3u : row * W;
