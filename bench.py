@@ -114,6 +114,12 @@ def read_traffic(name):
         return None
 
 
+def scaled_traffic(name, clips, profiled_clips):
+    """Committed PMC bytes of a hash kernel, measured at profiled_clips clips per launch, for a launch of `clips` clips."""
+    t = read_traffic(name)
+    return None if t is None else t * clips / profiled_clips
+
+
 def search_roofline(backend, kernel_ms):
     """roofline (+ companions) of the dominant search kernel from the library's per-step statistics:
     kernel_ms = [(kernel_ms, n_launches, pairs, pairs_computed, n_hits, pairs_early_exit, early_exit_bits)] per step,
@@ -596,7 +602,8 @@ def main():
                                       "frames_per_s_per_gpu": nh * 16 / (ms_hd * 1e-3),
                                       "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
                                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+                                                   "frac": gbs / HBM_PEAK_GBS,
+                                                   "traffic": scaled_traffic("resize_mfma_frame_stream_kernel@1920x1080", nh, 1000)}}
             del hd, out_h
             # a pitch that is not a multiple of the 128-byte line: the linear-stream kernel (LDS-DMA of whole chunks)
             nq = 4000
@@ -615,7 +622,8 @@ def main():
                                             "frames_per_s_per_gpu": nq * 16 / (ms_sd * 1e-3),
                                             "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
                                                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                         "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+                                                         "frac": gbs / HBM_PEAK_GBS,
+                                                         "traffic": scaled_traffic("resize_mfma_frame_stream_kernel@480x270", nq, 4000)}}
             del sd, out_h
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
