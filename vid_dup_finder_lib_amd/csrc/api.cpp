@@ -526,6 +526,66 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         int rc0 = ensure_cos_table(ctx, stream);
         if (rc0) return rc0;
     }
+    // Linear-stream form (frames of 256..1984 columns on dword-aligned bases): the crop box goes through LDS like a whole frame.
+    // Default for pitches that are not a multiple of the 128-byte line (measured, detect + crop + hash of letterboxed clips,
+    // whole-line kernel -> this: 854x480 1.68 -> 1.24 ms per 1000 clips, 720x576 1.42 -> 1.14, 426x240 x4000 1.85 -> 1.33,
+    // 960x540 1.63 -> 1.51, 1366x768 x500 2.19 -> 1.95); line-aligned pitches stay on the whole-line kernel (1920x1080
+    // 5.44 against 5.84 ms, 1280x720 2.54 against 2.74); VDF_RESIZE_MODE=5 takes them too.
+    int stream_cls = 0;
+    if (((ctx->resize_mode == 0 && w % 128 != 0) || ctx->resize_mode == 5) && (h + 63) / 64 > 2 &&
+        (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 && (uint64_t)w * h < (1ull << 31) &&
+        vdf::resize_cropped_stream_class(w, &stream_cls)) {
+        std::vector<vdf::CropStreamClip> sc(n_clips);
+        std::vector<vdf::CropStreamTable> st;
+        std::map<uint64_t, uint32_t> sindex;  // (size * 2 + vertical) -> entry
+        bool ok = true, need_shift = (w & 3u) != 0;
+        auto stream_entry = [&](uint32_t size, bool vertical, int *rc) -> uint32_t {
+            const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
+            auto it = sindex.find(key);
+            if (it != sindex.end()) return it->second;
+            DeviceMfmaTable *t = mfma_table(ctx, size, vertical ? vdf::kMfmaLayoutVertical : vdf::kMfmaLayoutHorizontalBand, stream, rc);
+            if (*rc) return 0;
+            if (!t->host.ok) { ok = false; return 0; }
+            vdf::CropStreamTable e{t->operand.p, t->bias.as<int32_t>(), vertical ? nullptr : t->meta.as<int32_t>(), t->host.n_tiles,
+                                   t->host.precision, t->host.band_stride, 0};
+            st.push_back(e);
+            sindex[key] = (uint32_t)st.size() - 1;
+            return (uint32_t)st.size() - 1;
+        };
+        for (size_t c = 0; c < n_clips && ok; c++) {
+            const uint32_t l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
+            if ((uint64_t)l + r >= w || (uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
+            vdf::CropStreamClip &q = sc[c];
+            q = vdf::CropStreamClip{};
+            q.x0 = l; q.y0 = t; q.w = w - l - r; q.h = h - t - b;
+            q.nb = vdf::resize_cropped_stream_blocks(q.w, q.x0, w, stream_cls, &q.wp);
+            need_shift = need_shift || (q.x0 & 3u) != 0;
+            if (q.nb < 2 && q.h > 16) { ok = false; break; }  // one block per chunk would leave three of the four waves idle
+            if (q.nb == 0) { ok = false; break; }
+            q.step_rows = 4096u / q.wp;
+            q.step_x = 4096u - q.step_rows * q.wp;
+            q.n_chunks = (q.h + 16 * q.nb - 1) / (16 * q.nb);
+            int rc = VDF_OK;
+            q.h_table = stream_entry(q.w, false, &rc);
+            if (rc) return rc;
+            if (ok) q.v_table = stream_entry(q.h, true, &rc);
+            if (rc) return rc;
+        }
+        if (ok) {
+            int rc = upload(ctx, ctx->crop_desc, sc.data(), sc.size() * sizeof(vdf::CropStreamClip), stream);
+            if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
+            if (rc) return rc;
+            VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
+            VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+            VDF_HIP(ctx, vdf::launch_resize_mfma_cropped_stream(d_frames, n_clips, w, h, frame_stride, clip_stride,
+                                                                ctx->crop_desc.as<vdf::CropStreamClip>(),
+                                                                ctx->crop_tables.as<vdf::CropStreamTable>(), stream_cls,
+                                                                need_shift, ctx->small.as<uint8_t>(), stream));
+            VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out,
+                                              d_dc, stream));
+            return VDF_OK;
+        }
+    }
     std::vector<vdf::CropClipDesc> desc(n_clips);
     std::vector<vdf::CropTableEntry> entries;
     const bool wide = w >= 192;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)

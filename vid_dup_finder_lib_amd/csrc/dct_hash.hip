@@ -792,7 +792,16 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
-    const uint32_t magic = MODE ? (uint32_t)((0x100000000ull + Wp - 1) / Wp) : 0u;  // row = P / Wp for P < 2^16
+    // MODE 1, 2: where this lane's first DMA instruction of a chunk lands (LDS position P0 = 1024 wave + 16 lane = row * Wp + x) and
+    // how far an instruction (4096 bytes of LDS further) moves it; the loop below only adds and compares - with a multiply
+    // high / two multiplies per instruction (16 cycles each) the ISSUE of a chunk's DMA cost 0.4 us of a 2.5 us step
+    uint32_t lane_x0 = 0, lane_ro0 = 0;
+    const uint32_t step_rows = MODE ? 4096u / Wp : 0u, step_x = MODE ? 4096u - step_rows * Wp : 0u;
+    if constexpr (MODE != 0) {
+        const uint32_t P0 = 1024u * wave + 16u * lane, row0 = P0 / Wp;
+        lane_x0 = P0 - row0 * Wp;
+        lane_ro0 = row0 * W;
+    }
     const int32_t bias_h = T.bias_h[r16];
     v4i bias_v;
 #pragma unroll
@@ -819,15 +828,17 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
         const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
+        uint32_t x = lane_x0, ro = lane_ro0;  // MODE 1, 2: this lane's position in the chunk: column, row * W
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
             if constexpr (MODE == 0) {
                 // the whole byte offset goes into the VGPR offset: that is the field the frame-sized range check surely covers
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, 0);
             } else {
-                const uint32_t P = off + 16u * lane, row = __umulhi(P, magic), x = P - row * Wp;
-                const uint32_t row_start = MODE == 2 ? (row * W) & ~3u : row * W;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + row_start + x), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, 0);
+                x += step_x;
+                ro += step_rows * W;
+                if (x >= Wp) { x -= Wp; ro += W; }
             }
         }
     };
@@ -861,13 +872,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     };
     auto step = [&](const uint4 *cur, uint4 *nxt, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
         __syncthreads();  // chunk (F, c) has landed in `cur` (vmcnt) and every wave is done with `nxt`
-        write_pending();
         uint32_t Fn = F, cn = c + 1;
         if (cn == n_chunks) { cn = 0; Fn = F + gridDim.x; }
-        if (Fn < n_frames) {
-            load_av(cn, avh_n, avl_n);
-            issue_dma(Fn, cn, nxt);
-        }
+        if (Fn < n_frames) issue_dma(Fn, cn, nxt);  // first: with one chunk in flight per workgroup its issue time is on the critical path
+        write_pending();
+        if (Fn < n_frames) load_av(cn, avh_n, avl_n);  // consumed in the next step, behind the barrier's vmcnt wait
         const uint32_t rows = min(rpc, H - c * rpc);
         if (16u * wave < rows) {
             v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
@@ -1034,6 +1043,285 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    return hipGetLastError();
+}
+
+// ---- cropped clips, linear-stream form ------------------------------------------------------------------------
+// The letterbox crop box is read in place, as in resize_mfma_cropped_kernel, but through the stream kernel's machinery:
+// rows x0 .. x0 + w of frame rows y0 .. y0 + h go to LDS by gather DMA at the clip's own conflict-free pitch (always the
+// re-pitch + byte-shift form: a crop's row starts have any alignment), the horizontal table is the band form of the
+// crop's width, and every per-frame quantity (box, pitch, chunk geometry, tables, precisions) comes from the clip's
+// descriptor by scalar loads.  A workgroup reloads its LDS table only when the next frame's clip uses another one
+// (clips of one source share their box); the biases and the vertical fragments are requested before the DMA of the
+// chunk that needs them, like the vertical fragments above.
+typedef const __attribute__((address_space(4))) CropStreamClip *const_clip_ptr;
+typedef const __attribute__((address_space(4))) CropStreamTable *const_table_ptr;
+
+template <int BUF_BYTES, int TAB_TILES, bool SHIFT>
+__global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
+                                                                         uint32_t frame_bytes, size_t frame_stride,
+                                                                         size_t clip_stride, uint32_t n_frames,
+                                                                         const CropStreamClip *__restrict__ clips_g,
+                                                                         const CropStreamTable *__restrict__ tables_g,
+                                                                         uint8_t *__restrict__ small)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_TILES * 2 * 64];
+    __shared__ __attribute__((aligned(16))) uint4 s_px0[BUF_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) uint4 s_px1[BUF_BYTES / 16];
+    __shared__ int32_t s_part[3][64][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
+    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+
+    // what the per-chunk code needs of a frame, in SGPRs (scalar loads, fetched a frame ahead of its first DMA); the rest
+    // (table and bias pointers) is read from the table entries where it is used, once per frame, off the critical path.
+    // Kept small on purpose: with the pointers in here the two copies spilled and the scalar loads turned into VMEM loads.
+    struct Geo {
+        uint32_t x0, y0, h, wp, step_rows, step_x, nb, n_chunks, h_table, v_table;  // step_*: 4096 = step_rows * wp + step_x
+        const __attribute__((address_space(1))) v4i *av;
+        int32_t n_kt, n_rg, prec_h, prec_v;
+    };
+    // Every value below is workgroup-uniform; the readfirstlane pins it to an SGPR.  Without that the compiler treated one of
+    // the descriptor loads as a vector load, and from there the chunk counter, the table index and the branches on them all
+    // became per-lane values (v_cmp + exec masks, table entries fetched through VGPR addresses, waits on the DMA).
+    auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    // (the result is cast back to the GLOBAL address space: as a generic pointer the loads through it became flat loads, and the
+    // compiler puts a vmcnt(0) in front of a flat load while an LDS-DMA is in flight - flat may read LDS)
+    auto sgpr_ptr = [&](const void *p) __attribute__((always_inline)) {
+        const uint64_t a = (uint64_t)(uintptr_t)p;
+        return (const __attribute__((address_space(1))) void *)(uintptr_t)(((uint64_t)sgpr((uint32_t)(a >> 32)) << 32) | sgpr((uint32_t)a));
+    };
+    typedef const __attribute__((address_space(1))) v4i *global_v4i;
+    typedef const __attribute__((address_space(1))) int32_t *global_i32;
+    auto geo_of = [&](uint32_t F) __attribute__((always_inline)) {
+        const uint32_t clip = sgpr(F >> 4);
+        Geo q;
+        q.x0 = sgpr(clips[clip].x0); q.y0 = sgpr(clips[clip].y0); q.h = sgpr(clips[clip].h);
+        q.wp = sgpr(clips[clip].wp); q.nb = sgpr(clips[clip].nb);
+        q.step_rows = sgpr(clips[clip].step_rows); q.step_x = sgpr(clips[clip].step_x);
+        q.n_chunks = sgpr(clips[clip].n_chunks);
+        q.h_table = sgpr(clips[clip].h_table);
+        q.v_table = sgpr(clips[clip].v_table);
+        q.n_kt = (int32_t)sgpr((uint32_t)tables[q.h_table].n_tiles);
+        q.prec_h = (int32_t)sgpr((uint32_t)tables[q.h_table].precision);
+        q.av = (global_v4i)sgpr_ptr(tables[q.v_table].operand);
+        q.n_rg = (int32_t)sgpr((uint32_t)tables[q.v_table].n_tiles);
+        q.prec_v = (int32_t)sgpr((uint32_t)tables[q.v_table].precision);
+        return q;
+    };
+    // lx0, lro0: this lane's column and row * pitch at its first DMA instruction of a chunk (LDS position 1024 wave + 16 lane)
+    auto issue_dma = [&](uint32_t F, const Geo &q, uint32_t lx0, uint32_t lro0, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
+        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
+        const uint32_t rpc = 16u * q.nb, rows = min(rpc, q.h - c * rpc), bytes = rows * q.wp;
+        const uint32_t first = (q.y0 + c * rpc) * pitch + q.x0;  // frame byte of the chunk's first pixel
+        // this lane's position in the chunk (column, row * pitch), advanced by adds and one compare per instruction: a multiply
+        // high and two multiplies per instruction made the ISSUE of a chunk's DMA cost 0.4 us of a 2.5 us step
+        uint32_t x = lx0, ro = first + lro0;
+        for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
+            auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)((SHIFT ? ro & ~3u : ro) + x), 0, 0, 0);
+            x += q.step_x;
+            ro += q.step_rows * pitch;
+            if (x >= q.wp) { x -= q.wp; ro += pitch; }
+        }
+    };
+    auto load_av = [&](const Geo &q, uint32_t c, v4i &h, v4i &l) __attribute__((always_inline)) {
+        uint32_t rg = (c * q.nb + wave) >> 2;
+        rg = rg < (uint32_t)q.n_rg ? rg : (uint32_t)q.n_rg - 1u;
+        h = q.av[(rg * 2 + 0) * 64 + lane];
+        l = q.av[(rg * 2 + 1) * 64 + lane];
+    };
+    // biases of the NEXT frame of this workgroup: requested a step ahead (any global load consumed in the step that issues a
+    // DMA would have to wait for that DMA - VMEM returns in order - so nothing is consumed in the step that requests it)
+    int32_t next_bias_h = 0;
+    v4i next_bias_v = {0, 0, 0, 0};
+    auto load_biases = [&](const Geo &q) __attribute__((always_inline)) {
+        const global_i32 bh_bias = (global_i32)sgpr_ptr(tables[q.h_table].bias), bv_bias = (global_i32)sgpr_ptr(tables[q.v_table].bias);
+        next_bias_h = bh_bias[r16];
+#pragma unroll
+        for (int r = 0; r < 4; r++) next_bias_v[r] = bv_bias[4 * g + r];
+    };
+
+    uint32_t cur_x0 = 0, cur_ro0 = 0, nf_x0 = 0, nf_ro0 = 0;
+    auto lane_start = [&](const Geo &q, uint32_t &lx0, uint32_t &lro0) __attribute__((always_inline)) {
+        const uint32_t P0 = 1024u * wave + 16u * lane, row0 = P0 / q.wp;  // one division per frame, not per chunk
+        lx0 = P0 - row0 * q.wp;
+        lro0 = row0 * pitch;
+    };
+    uint32_t F = blockIdx.x, c = 0;
+    Geo cur = {}, nf = {};  // the frame whose chunks are being multiplied; this workgroup's next frame
+    if (F < n_frames) { cur = geo_of(F); load_biases(cur); lane_start(cur, cur_x0, cur_ro0); }
+    uint32_t loaded_table = 0xFFFFFFFFu;
+    int32_t bias_h = 0, band_lo = 0, pend_prec_v = 0;
+    uint32_t band_nt = 0, band_base = 0, band_zero = 0;
+    v4i bias_v = zero4, pend_bias_v = zero4;
+    v4i acc_vh = zero4, acc_vl = zero4, pend_vh = zero4, pend_vl = zero4;
+    bool out_pending = false;
+    uint32_t out_F = 0;
+    auto write_pending = [&]() __attribute__((always_inline)) {
+        if (out_pending && wave == 0) {
+            v4i vh = pend_vh, vl = pend_vl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                vl[r] += pend_bias_v[r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) vl[r] += s_part[w][lane][r];
+            }
+            const uint32_t px = finalize4(vh, vl, pend_prec_v) ^ 0x80808080u;
+            uint8_t *dst = small + (size_t)out_F * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        }
+        out_pending = false;
+    };
+    auto step = [&](const uint4 *cur_px, uint4 *nxt_px, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        __syncthreads();  // chunk (F, c) has landed and every wave is done with the other buffer (and, at c == 0, with the old table)
+        uint32_t Fn = F, cn = c + 1;
+        const bool wraps = cn == cur.n_chunks;
+        if (wraps) { cn = 0; Fn = F + gridDim.x; }
+        // the next chunk's DMA first: with one chunk in flight per workgroup its issue time is on the critical path
+        if (Fn < n_frames) {
+            if (wraps && c == 0) { nf = geo_of(Fn); lane_start(nf, nf_x0, nf_ro0); }  // one-chunk frames: could not be fetched a step ahead
+            if (wraps) issue_dma(Fn, nf, nf_x0, nf_ro0, 0, nxt_px);
+            else issue_dma(Fn, cur, cur_x0, cur_ro0, cn, nxt_px);
+        }
+        write_pending();
+        if (c == 0) {  // first chunk of a frame: its biases (requested a frame ago), its table if it differs, the next frame's geometry
+            bias_h = next_bias_h;
+            bias_v = next_bias_v;
+            if (cur.h_table != loaded_table) {  // workgroup-uniform; rare (clips of one source share their box)
+                const uint32_t stride = sgpr((uint32_t)tables[cur.h_table].band_stride);
+                const global_v4i bh = (global_v4i)sgpr_ptr(tables[cur.h_table].operand);
+                const global_i32 meta = (global_i32)sgpr_ptr(tables[cur.h_table].meta);
+                for (uint32_t i = tid; i < stride; i += 256u) {
+                    const v4i v = bh[i];
+                    s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+                }
+                if (tid < 8) s_tab[stride + tid] = uint4{0, 0, 0, 0};
+                band_lo = meta[r16];
+                band_nt = (uint32_t)meta[16 + r16];
+                band_base = r16 * stride + 16u * g;
+                band_zero = 16u * stride;
+                loaded_table = cur.h_table;
+                // retire the two loads HERE: a barrier does not wait for loads, and a wait at their first use - inside the K
+                // loop, behind this step's DMA - would be a wait for that DMA in every step (seen in the ISA)
+                asm volatile("" ::"v"(band_lo), "v"(band_nt));
+                __syncthreads();
+            }
+            if (F + gridDim.x < n_frames) { nf = geo_of(F + gridDim.x); lane_start(nf, nf_x0, nf_ro0); }
+        }
+        if (Fn < n_frames) {
+            if (wraps) load_av(nf, 0, avh_n, avl_n);
+            else load_av(cur, cn, avh_n, avl_n);
+        }
+        const uint32_t rpc = 16u * cur.nb, rows = min(rpc, cur.h - c * rpc);
+        if (16u * wave < rows) {
+            v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
+            const uint32_t row = 16u * wave + r16;
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(cur_px) + row * cur.wp + 16u * g;
+            const uint32_t shift = ((cur.y0 + c * rpc + row) * pitch + cur.x0) & 3u;
+            auto tile = [&](int kt) __attribute__((always_inline)) {
+                const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
+                v4i a = {(int)p.x, (int)p.y, (int)p.z, (int)p.w};
+                if constexpr (SHIFT) {  // some row of some box starts off a dword boundary
+                    const uint32_t nx = *reinterpret_cast<const uint32_t *>(base + 64 * kt + 16);
+                    a[0] = (int)__builtin_amdgcn_alignbyte(p.y, p.x, shift);
+                    a[1] = (int)__builtin_amdgcn_alignbyte(p.z, p.y, shift);
+                    a[2] = (int)__builtin_amdgcn_alignbyte(p.w, p.z, shift);
+                    a[3] = (int)__builtin_amdgcn_alignbyte(nx, p.w, shift);
+                }
+                a = a ^ x80;
+                const uint32_t j = (uint32_t)(kt - band_lo);
+                const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
+                const uint4 th = *reinterpret_cast<const uint4 *>(q), tl = *reinterpret_cast<const uint4 *>(q + 64);
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
+            };
+            int kt = 0;
+            for (; kt + 3 < cur.n_kt; kt += 4) { tile(kt); tile(kt + 1); tile(kt + 2); tile(kt + 3); }
+            for (; kt < cur.n_kt; kt++) tile(kt);
+            const int val = (int)finalize4(ah, al, cur.prec_h);
+            const uint32_t mb = (c * cur.nb + wave) & 3u;
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) b[m] = mb == (uint32_t)m ? val : 0;
+            acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, acc_vh, 0, 0, 0);
+            acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
+        }
+        if (wraps) {  // frame complete
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // see resize_mfma_frame_stream_kernel
+            }
+            pend_vh = acc_vh; pend_vl = acc_vl; pend_bias_v = bias_v; pend_prec_v = cur.prec_v;
+            acc_vh = zero4; acc_vl = zero4;
+            out_pending = true;
+            out_F = F;
+            // the next frame's biases, consumed at its first chunk = the next step, behind the barrier (requested here and not in
+            // the c == 0 block above, where the same registers are read: the compiler then loaded into temporaries and waited)
+            if (Fn < n_frames) load_biases(nf);
+            cur = nf; cur_x0 = nf_x0; cur_ro0 = nf_ro0;
+        }
+        F = sgpr(Fn); c = sgpr(cn);
+    };
+    v4i av0h = zero4, av0l = zero4, av1h = zero4, av1l = zero4;
+    if (F < n_frames) {
+        load_av(cur, 0, av0h, av0l);
+        issue_dma(F, cur, cur_x0, cur_ro0, 0, s_px0);
+    }
+    while (F < n_frames) {
+        step(s_px0, s_px1, av0h, av0l, av1h, av1l);
+        if (!(F < n_frames)) break;
+        step(s_px1, s_px0, av1h, av1l, av0h, av0l);
+    }
+    __syncthreads();
+    write_pending();
+}
+
+bool resize_cropped_stream_class(uint32_t pitch, int *cls)
+{
+    if (pitch < 256 || pitch > 1984) return false;
+    uint32_t nb = 0;
+    const int c = stream_class(pitch | 1u, &nb);  // | 1: size the buffers for the re-pitched form of a full-width box
+    if (c == 0) return false;
+    *cls = c == 1 ? 1 : 2;
+    return true;
+}
+
+uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp)
+{
+    uint32_t p = (crop_w + 3u + 15u) & ~15u;
+    if ((p / 16) % 2 == 0) p += 16;
+    if (x0 == 0 && crop_w == pitch && pitch % 16 == 0) p = pitch;  // full-width box (top / bottom bars): the DMA is a linear copy
+    *wp = p;
+    return stream_blocks_per_chunk(p, cls == 1 ? kStreamBufS : kStreamBufM);
+}
+
+hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,
+                                             size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
+                                             const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
+                                             hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)pitch * frame_rows >= (1ull << 31)) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16), frame_bytes = pitch * frame_rows;
+    const dim3 grid_s(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u)), grid_m(std::min<uint32_t>(n_frames, (uint32_t)cus));
+#define VDF_LAUNCH_CROPPED(BUF, TAB, SH, GRID)                                                                              \
+    hipLaunchKernelGGL((resize_mfma_cropped_stream_kernel<BUF, TAB, SH>), GRID, dim3(256), 0, stream, frames, pitch,        \
+                       frame_bytes, frame_stride, clip_stride, n_frames, clips, tables, small)
+    if (cls == 1 && shift) VDF_LAUNCH_CROPPED(kStreamBufS, kStreamTabS, true, grid_s);
+    else if (cls == 1) VDF_LAUNCH_CROPPED(kStreamBufS, kStreamTabS, false, grid_s);
+    else if (shift) VDF_LAUNCH_CROPPED(kStreamBufM, kStreamTabM, true, grid_m);
+    else VDF_LAUNCH_CROPPED(kStreamBufM, kStreamTabM, false, grid_m);
+#undef VDF_LAUNCH_CROPPED
     return hipGetLastError();
 }
 

@@ -124,6 +124,25 @@ struct CropTableEntry {  // one MFMA-layout axis table (device pointers)
     const int32_t *bias;
     int32_t n_tiles, precision;
 };
+// The same for the linear-stream form (resize_mfma_cropped_stream_kernel): LDS row pitch, the chunk geometry and the
+// reciprocal the DMA lanes divide by are fixed per clip on the host; the horizontal table is in band form
+struct CropStreamClip {
+    uint32_t x0, y0, w, h;
+    uint32_t wp, nb, n_chunks, pad0;   // LDS pitch (odd multiple of 16 >= w + 3, or the frame pitch for a full-width box), 16-row blocks per chunk, chunks per frame
+    uint32_t h_table, v_table, step_rows, step_x;  // 4096 = step_rows * wp + step_x: what one DMA instruction advances a lane by
+};
+struct CropStreamTable {
+    const void *operand;
+    const int32_t *bias;
+    const int32_t *meta;  // band form: kt_lo[16], nt[16] (horizontal tables only)
+    int32_t n_tiles, precision, band_stride, pad;
+};
+bool resize_cropped_stream_class(uint32_t pitch, int *cls);                  // can frames of this pitch take the stream form, and which
+uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp);  // 16-row blocks per chunk (0: does not fit) and the LDS pitch
+hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,
+                                             size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
+                                             const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
+                                             hipStream_t stream);  // shift: some row of some box starts off a dword boundary
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
                             size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
