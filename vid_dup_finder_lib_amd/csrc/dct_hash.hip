@@ -11,6 +11,7 @@
 // dct_hash (one workgroup per clip: f64 DCT-II along x, y, t through LDS, pruned to the 10 outputs
 // per axis that are consumed, sign test, __ballot pack: ballot of wave-word w IS hash word w).
 #include <algorithm>
+#include <cstdlib>
 
 #include "resize_tables.h"
 #include "vdf_internal.h"
@@ -1340,7 +1341,14 @@ hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    hipLaunchKernelGGL(dct_hash_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, small, small_clip_stride,
+    size_t pad = 0;
+#ifdef VDF_BENCH_ABLATE  // occupancy experiment: unused dynamic LDS limits the workgroups per CU (VDF_DCT_LDS_PAD bytes)
+    if (const char *e = std::getenv("VDF_DCT_LDS_PAD")) {
+        pad = (size_t)std::atol(e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dct_hash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    }
+#endif
+    hipLaunchKernelGGL(dct_hash_kernel, dim3((uint32_t)n_clips), dim3(256), pad, stream, small, small_clip_stride,
                        small_frame_stride, cos_table, out_hashes, out_dontcare);
     return hipGetLastError();
 }
