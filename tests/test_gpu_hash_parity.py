@@ -148,6 +148,27 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("h,w,n", [(576, 1024, 2), (864, 1536, 1), (1152, 2048, 1), (1440, 2560, 1), (2160, 3840, 1), (300, 4096, 1),
+                                   (333, 3008, 1), (130, 1040, 40), (720, 1280, 1), (1080, 1920, 1)])
+def test_ksplit_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
+    """Wide frames (1024..4096 columns, multiples of 16) that the stream kernel leaves out take its K-split form: the
+    horizontal table in registers, the four waves of a workgroup sharing each 16-row block, partial sums through LDS behind
+    an LDS-only barrier.  1024 / 1536 / 2048 wide = 64 / 48 / 32-row chunks, 2560..4096 = 16-row chunks (4 / 8 / 16 K
+    tiles per wave), 3008 = a K-tile count that is not a multiple of 4, 40 clips of 130 rows = frame boundaries in the
+    persistent loop and a 2-row last block; 1280 / 1920 run it only when forced (mode 6)."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(6000 + h * 7 + w)
+        frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+        _check(eng, frames)
+    finally:
+        eng.close()
+
+
 def test_linear_stream_kernel_publishes_its_partial_sums():
     """Regression: the per-frame partial sums of waves 1..3 cross a barrier that sits on the persistent loop's back edge, and
     the compiler emitted that barrier without the LDS wait; wave 0 then read stale sums in about one launch in ten when two

@@ -436,7 +436,13 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             if (rc) return rc;
             if (!mh->host.ok) { streamed = false; mh = nullptr; }
         }
-        const bool wide = !fused && !streamed && ctx->resize_mode != 2;
+        // wide frames the stream kernel leaves out (1024 / 1536 wide, wider than 1984): its K-split form, table in registers
+        // (measured against the whole-line kernel: 3840 wide 5.4 -> 6.3 TB/s, 2560 5.3 -> 5.8, 2048 5.9 -> 6.1; 1024 and 1536
+        // wide lose - four or three blocks per chunk, each with its own reduction barrier - and stay where they are)
+        const bool ksplit = !fused && ((ctx->resize_mode == 0 && !streamed && w >= 2048) || ctx->resize_mode == 6) &&
+                            vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
+        if (ksplit) { streamed = false; mh = nullptr; }
+        const bool wide = !fused && !streamed && !ksplit && ctx->resize_mode != 2;
         if (!mh) mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
         DeviceMfmaTable *mv = mfma_table(ctx, h, wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, &rc);
@@ -463,7 +469,10 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
                 return VDF_OK;
             }
             VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-            if (streamed) {
+            if (ksplit) {
+                VDF_HIP(ctx, vdf::launch_resize_mfma_frames_ksplit(d_frames, n_clips, w, h, frame_stride, clip_stride, a,
+                                                                   ctx->small.as<uint8_t>(), stream));
+            } else if (streamed) {
                 VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_clips, w, h, frame_stride, clip_stride, a,
                                                                    ctx->small.as<uint8_t>(), stream));
             } else {
@@ -752,7 +761,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     }
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
-        if (m >= 0 && m <= 5) ctx->resize_mode = m;
+        if (m >= 0 && m <= 6) ctx->resize_mode = m;
     }
     if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
         if (!std::strcmp(s, "valu")) ctx->search_backend = 0;

@@ -960,7 +960,10 @@ static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "
 // up to 3 bytes a dword-aligned row start puts in front of it
 static uint32_t stream_pitch(uint32_t w)
 {
-    if (w % 16 == 0) return w;
+    // multiples of 256: at the frame's own pitch the 16 rows of a block would share one bank group (16-way conflict on
+    // every operand read); re-pitched, 768 / 1024 / 1280 wide gain 12 / 10 / 6 %.  Pitches with 8-way conflicts or fewer
+    // (1920, 640, 480 ...) are faster left alone: the linear DMA is worth more than the conflicts cost.
+    if (w % 16 == 0) return (w % 256 == 0 && w >= 768) ? w + 16 : w;
     uint32_t wp = (w + (w % 4 ? 3u : 0u) + 15u) & ~15u;
     if ((wp / 16) % 2 == 0) wp += 16;
     return wp;
@@ -1002,7 +1005,8 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
     if (cls == 0) return false;
-    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || aligned_too;
+    const bool repitched_whole_table = stream_pitch(w) != w && cls == 2;  // 1024 wide: 48-row chunks of 50 KB, 5.8 against 5.4 TB/s
+    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) || aligned_too;
 }
 
 template <int BUF, int TAB, bool BAND>
@@ -1011,7 +1015,7 @@ static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t 
                                uint32_t nb, uint8_t *small)
 {
     const uint32_t wp = stream_pitch(w);
-    if (w % 16 == 0)
+    if (wp == w)
         hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, wp, small);
     else if (w % 4 == 0)
@@ -1044,6 +1048,212 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    return hipGetLastError();
+}
+
+// ---- wide frames, linear-stream form with the K tiles split over the waves -----------------------------------
+// The stream kernel above keeps the horizontal table in LDS (2 KB per K tile, or its band form) and gives each wave its own
+// 16-row block.  For wide frames that leaves too little LDS for the chunks in flight (1024 / 1536 wide: 48 KB chunks) or does
+// not fit at all (wider than 1984).  Here the table lives in REGISTERS: all four waves work on the same 16-row block, wave w
+// taking K tiles w, w + 4, ... - always the same tiles, so its B fragments (2 x 4 VGPRs per tile, at most 16 tiles = 128
+// VGPRs for 4096 columns) are loaded once per launch - and the four partial sums of a block meet in LDS (exact integers,
+// hi and lo folded into one i32 as in finalize4) behind an LDS-only barrier that does not wait for the DMA in flight.
+// The wave that sums a block (block index & 3) also owns its byte column of the vertical operand and does the vertical
+// product, so the vertical partial sums are spread over the waves as before.  LDS holds nothing but the two chunk
+// buffers (75 KB each: 16 rows of 4096 columns, 32 of 2048, 48 of 1536, 64 of 1024), rows re-pitched to an odd multiple of
+// 16 bytes by the DMA (at the frame's own pitch the 16 rows of a block would share one bank group: 3840 = 240 x 16).
+template <int MAXT>
+__global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+                                                                       uint32_t H, size_t frame_stride,
+                                                                       size_t clip_stride, uint32_t n_frames,
+                                                                       MfmaResizeTables T, uint32_t nb, uint32_t Wp,
+                                                                       uint8_t *__restrict__ small)
+{
+    constexpr int kBuf = 75 * 1024 + 128;
+    __shared__ __attribute__((aligned(16))) uint4 s_px0[kBuf / 16];
+    __shared__ __attribute__((aligned(16))) uint4 s_px1[kBuf / 16];
+    __shared__ __attribute__((aligned(16))) v4i s_red[2][3][64];  // partial sums of the three waves that do not own the block, by block parity
+    __shared__ int32_t s_part[3][64][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    // this wave's K tiles, for the whole launch
+    v4i bt[MAXT][2];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        const int kt = (int)wave + 4 * i;
+        bt[i][0] = zero4; bt[i][1] = zero4;
+        if (kt < T.n_kt) { bt[i][0] = T.bh[(kt * 2 + 0) * 64 + lane]; bt[i][1] = T.bh[(kt * 2 + 1) * 64 + lane]; }
+    }
+    const int32_t bias_h = T.bias_h[r16];
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    // gather DMA: where this lane's first instruction of a chunk lands (LDS position 1024 wave + 16 lane = row * Wp + x)
+    const uint32_t step_rows = 4096u / Wp, step_x = 4096u - step_rows * Wp;
+    uint32_t lane_x0, lane_ro0;
+    {
+        const uint32_t P0 = 1024u * wave + 16u * lane, row0 = P0 / Wp;
+        lane_x0 = P0 - row0 * Wp;
+        lane_ro0 = row0 * W;
+    }
+    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
+        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
+        const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
+        uint32_t x = lane_x0, ro = lane_ro0;
+        for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
+            auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + ro + x), 0, 0, 0);
+            x += step_x;
+            ro += step_rows * W;
+            if (x >= Wp) { x -= Wp; ro += W; }
+        }
+    };
+    // the block of chunk c this wave owns (block index & 3 == wave), if the chunk has one: its vertical fragments
+    auto load_av = [&](uint32_t c, v4i &h, v4i &l) __attribute__((always_inline)) {
+        const uint32_t j = (wave - c * nb) & 3u;  // block j of the chunk has index c * nb + j
+        uint32_t rg = (c * nb + j) >> 2;
+        rg = rg < (uint32_t)T.n_rg ? rg : (uint32_t)T.n_rg - 1u;
+        h = T.av[(rg * 2 + 0) * 64 + lane];
+        l = T.av[(rg * 2 + 1) * 64 + lane];
+    };
+
+    uint32_t F = blockIdx.x, c = 0;
+    v4i acc_vh = zero4, acc_vl = zero4, pend_vh = zero4, pend_vl = zero4;
+    bool out_pending = false;
+    uint32_t out_F = 0;
+    auto write_pending = [&]() __attribute__((always_inline)) {
+        if (out_pending && wave == 0) {
+            v4i vh = pend_vh, vl = pend_vl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                vl[r] += bias_v[r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) vl[r] += s_part[w][lane][r];
+            }
+            const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+            uint8_t *dst = small + (size_t)out_F * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        }
+        out_pending = false;
+    };
+    auto step = [&](const uint4 *cur, uint4 *nxt, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        __syncthreads();  // chunk (F, c) has landed in `cur` (vmcnt) and every wave is done with `nxt`
+        uint32_t Fn = F, cn = c + 1;
+        if (cn == n_chunks) { cn = 0; Fn = F + gridDim.x; }
+        if (Fn < n_frames) issue_dma(Fn, cn, nxt);
+        write_pending();
+        if (Fn < n_frames) load_av(cn, avh_n, avl_n);
+        const uint32_t rows = min(rpc, H - c * rpc), n_blocks = (rows + 15u) >> 4;
+        for (uint32_t j = 0; j < n_blocks; j++) {
+            const uint32_t owner = (c * nb + j) & 3u;
+            v4i ah = zero4, al = zero4;
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + (16u * j + r16) * Wp + 64u * wave + 16u * g;
+#pragma unroll
+            for (int i = 0; i < MAXT; i++) {
+                if ((int)wave + 4 * i < T.n_kt) {  // wave-uniform
+                    const uint4 p = *reinterpret_cast<const uint4 *>(base + 256 * i);
+                    const v4i a = (v4i){(int)p.x, (int)p.y, (int)p.z, (int)p.w} ^ x80;
+                    ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[i][0], ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bt[i][1], al, 0, 0, 0);
+                }
+            }
+            v4i part;
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[r] = (ah[r] << 8) + al[r];
+            if (wave != owner) s_red[j & 1][(wave - owner - 1u) & 3u][lane] = part;
+            // LDS-only barrier: the partial sums are LDS writes; a __syncthreads() here would also wait for the DMA in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (wave == owner) {
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    const v4i o = s_red[j & 1][w][lane];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) part[r] += o[r];
+                }
+                const v4i hi0 = zero4;
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[r] += bias_h;
+                const int val = (int)finalize4(hi0, part, T.prec_h);
+                v4i b;
+#pragma unroll
+                for (int m = 0; m < 4; m++) b[m] = owner == (uint32_t)m ? val : 0;
+                acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, acc_vh, 0, 0, 0);
+                acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
+            }
+        }
+        if (c + 1 == n_chunks) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // see resize_mfma_frame_stream_kernel
+            }
+            pend_vh = acc_vh; pend_vl = acc_vl;
+            acc_vh = zero4; acc_vl = zero4;
+            out_pending = true;
+            out_F = F;
+        }
+        F = Fn; c = cn;
+    };
+    v4i av0h = zero4, av0l = zero4, av1h = zero4, av1l = zero4;
+    if (F < n_frames) {
+        load_av(0, av0h, av0l);
+        issue_dma(F, 0, s_px0);
+    }
+    while (F < n_frames) {
+        step(s_px0, s_px1, av0h, av0l, av1h, av1l);
+        if (!(F < n_frames)) break;
+        step(s_px1, s_px0, av1h, av1l, av0h, av0l);
+    }
+    __syncthreads();
+    write_pending();
+}
+
+constexpr int kKsplitBuf = 75 * 1024 + 128;
+
+// LDS pitch and 16-row blocks per chunk of the K-split form (0 blocks: the width does not fit)
+static uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
+{
+    uint32_t p = w;  // w % 16 == 0
+    if ((p / 16) % 2 == 0) p += 16;
+    *wp = p;
+    return stream_blocks_per_chunk(p, kKsplitBuf);
+}
+
+bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
+{
+    if (w % 16 != 0 || w < 1024 || w > 4096 || (uint64_t)w * h >= (1ull << 31) || frame_stride != (size_t)w * h) return false;
+    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
+    uint32_t wp = 0;
+    return ksplit_geometry(w, &wp) >= 1;
+}
+
+hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
+                                            size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
+                                            uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    uint32_t wp = 0;
+    const uint32_t nb = ksplit_geometry(w, &wp);
+    if (n_clips * 16 > 0xFFFFFFFFull || nb == 0 || a.n_kt > 64 || a.band_meta) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16);
+    const dim3 grid(std::min<uint32_t>(n_frames, (uint32_t)cus));
+    if (a.n_kt <= 16)
+        hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<4>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                           n_frames, make_tables(a), nb, wp, small);
+    else if (a.n_kt <= 32)
+        hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<8>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                           n_frames, make_tables(a), nb, wp, small);
+    else
+        hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<16>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                           n_frames, make_tables(a), nb, wp, small);
     return hipGetLastError();
 }
 

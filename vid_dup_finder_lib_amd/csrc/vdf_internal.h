@@ -114,6 +114,12 @@ bool resize_stream_wants_band(uint32_t w);  // the kernel then takes a.bh in kMf
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
                                             uint8_t *small, hipStream_t stream);
+// K-split form for wide frames (1024..4096 columns, a multiple of 16): horizontal table in registers, a.bh in plain
+// kMfmaLayoutHorizontal form, a.av in kMfmaLayoutVertical order
+bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride);
+hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
+                                            size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
+                                            uint8_t *small, hipStream_t stream);
 // ---- letterbox crop detection + cropped resize -------------------------------------------
 struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
     uint32_t x0, y0, w, h;
