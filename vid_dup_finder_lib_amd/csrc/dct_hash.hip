@@ -1508,7 +1508,8 @@ uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pit
 {
     uint32_t p = (crop_w + 3u + 15u) & ~15u;
     if ((p / 16) % 2 == 0) p += 16;
-    if (x0 == 0 && crop_w == pitch && pitch % 16 == 0) p = pitch;  // full-width box (top / bottom bars): the DMA is a linear copy
+    // full-width box (top / bottom bars): the DMA is a linear copy - unless that pitch puts a block's 16 rows on one bank group
+    if (x0 == 0 && crop_w == pitch && pitch % 16 == 0 && pitch % 256 != 0) p = pitch;
     *wp = p;
     return stream_blocks_per_chunk(p, cls == 1 ? kStreamBufS : kStreamBufM);
 }
