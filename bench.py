@@ -625,6 +625,28 @@ def main():
                                                          "frac": gbs / HBM_PEAK_GBS,
                                                          "traffic": scaled_traffic("resize_mfma_frame_stream_kernel@480x270", nq, 4000)}}
             del sd, out_h
+            # 4K: the K-split form of the stream kernel (horizontal table in registers)
+            nu = 250
+            uhd = torch.empty((nu, 16, 2160, 3840), dtype=torch.uint8, device=dev)
+            for c0 in range(0, nu, 25):
+                uhd[c0:c0 + 25] = torch.randint(0, 256, (min(25, nu - c0), 16, 2160, 3840), dtype=torch.uint8, device=dev, generator=g)
+            out_h = torch.zeros((nu, 16), dtype=torch.int64, device=dev)
+            eng.hash_frames_device(uhd.data_ptr(), nu, 16, 3840, 2160, out_h.data_ptr(), stream=stream)
+            barrier()
+            ev0.record()
+            for _ in range(args.steps):
+                eng.hash_frames_device(uhd.data_ptr(), nu, 16, 3840, 2160, out_h.data_ptr(), stream=stream)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms_u = ev0.elapsed_time(ev1) / args.steps
+            gbs = nu * 16 * (3840 * 2160 + 8) / (ms_u * 1e-3) / 1e9
+            out["hash"]["uhd_3840x2160"] = {"workload": f"{nu} clips of 16 x 2160 x 3840 u8 per GPU", "ms_per_step": ms_u,
+                                            "frames_per_s_per_gpu": nu * 16 / (ms_u * 1e-3),
+                                            "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_ksplit_kernel",
+                                                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                         "frac": gbs / HBM_PEAK_GBS,
+                                                         "traffic": scaled_traffic("resize_mfma_frame_ksplit_kernel@3840x2160", nu, 250)}}
+            del uhd, out_h
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)

@@ -13,6 +13,7 @@ B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --
 H1="python3 $R/tools/bench_hash.py --steps 1"
 H2="python3 $R/tools/bench_hash.py --steps 1 --clips 1000 --w 1920 --h 1080"   # the bench's full_hd leg (linear-stream kernel)
 H3="python3 $R/tools/bench_hash.py --steps 1 --clips 4000 --w 480 --h 270"     # the bench's pitch_480x270 leg
+H4="python3 $R/tools/bench_hash.py --steps 1 --clips 250 --w 3840 --h 2160"    # the bench's uhd_3840x2160 leg (K-split kernel)
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hash -- $H1 > /dev/null 2>&1
@@ -21,6 +22,9 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hd -- $H2
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_hd -- $H2 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_sd -- $H3 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_sd -- $H3 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_uhd -- $H4 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_uhd -- $H4 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq_uhd -- $H4 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/sq_hd -- $H2 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/sq_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq_search2 -- $B1 > /dev/null 2>&1

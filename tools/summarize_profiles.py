@@ -72,9 +72,10 @@ for k in summary.get("fetch_hash", {}):
         t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
                                                     "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
 for tag_, fd, wd in (("resize_mfma_frame_stream_kernel@1920x1080", "fetch_hd", "write_hd"),
-                     ("resize_mfma_frame_stream_kernel@480x270", "fetch_sd", "write_sd")):
+                     ("resize_mfma_frame_stream_kernel@480x270", "fetch_sd", "write_sd"),
+                     ("resize_mfma_frame_ksplit_kernel@3840x2160", "fetch_uhd", "write_uhd")):
     for k in summary.get(fd, {}):
-        if k.startswith("resize_mfma_frame_stream_kernel"):
+        if k.startswith(tag_.split("@")[0]):
             t[tag_] = traffic(fd, wd, k, 2, "frames stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction; "
                                             "launch = tools/bench_hash.py at the bench leg's shape")
 old = {}
