@@ -205,18 +205,22 @@ def test_full_hd_clip_matches_oracle(engine):
     _check(engine, frames)
 
 
-@pytest.mark.parametrize("h,w", [(64, 64), (48, 80), (120, 136), (270, 480), (301, 203)])
-def test_strided_and_misaligned_device_buffers(engine, h, w):
+@pytest.mark.parametrize("h,w", [(64, 64), (48, 80), (120, 136), (270, 480), (301, 203), (300, 854), (200, 2048)])
+@pytest.mark.parametrize("base,pad_f,pad_c", [(3, 37, 101), (16, 48, 112)])
+def test_strided_and_misaligned_device_buffers(engine, h, w, base, pad_f, pad_c):
     """vdf_hash_frames_u8_device takes any frame_stride >= W*H, any clip_stride, any base alignment and ignores frames
     beyond the 16th (video_hash.rs:53): padded strides, 18 frames per clip and a base pointer 3 bytes off 16-byte alignment
-    must hash exactly like the packed copy (covers every resize kernel's addressing and its end-of-buffer guard)."""
+    must hash exactly like the packed copy (covers every resize kernel's addressing and its end-of-buffer guard); with
+    16-byte-aligned padding the linear-stream kernels still apply (frames start on 16-byte boundaries, rows are packed)."""
     import torch
 
     rng = np.random.default_rng(h * 1000 + w)
     n, nf = 5, 18
     frames = rng.integers(0, 256, size=(n, nf, h, w), dtype=np.uint8)
-    fs, base = w * h + 37, 3
-    cs = nf * fs + 101
+    if (w * h) % 16:  # keep every frame start 16-byte aligned in the aligned variant
+        pad_f += 16 - (w * h + pad_f) % 16 if base == 16 else 0
+    fs = w * h + pad_f
+    cs = nf * fs + pad_c
     buf = np.full(base + (n - 1) * cs + (nf - 1) * fs + w * h, 0xAB, np.uint8)  # ends exactly at the last byte of the last frame
     for c in range(n):
         for f in range(nf):

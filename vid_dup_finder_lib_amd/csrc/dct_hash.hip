@@ -1020,7 +1020,7 @@ bool resize_stream_wants_band(uint32_t w)
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too)
 {
-    if (w < 256 || (uint64_t)w * h >= (1ull << 31) || frame_stride != (size_t)w * h) return false;
+    if (w < 256 || (uint64_t)w * h >= (1ull << 31)) return false;  // (rows are packed inside a frame; frames and clips may be padded)
     if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
@@ -1246,7 +1246,7 @@ static uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
 
 bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
 {
-    if (w % 16 != 0 || w < 1024 || w > 4096 || (uint64_t)w * h >= (1ull << 31) || frame_stride != (size_t)w * h) return false;
+    if (w % 16 != 0 || w < 1024 || w > 4096 || (uint64_t)w * h >= (1ull << 31)) return false;
     if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
     uint32_t wp = 0;
     return ksplit_geometry(w, &wp) >= 1;
