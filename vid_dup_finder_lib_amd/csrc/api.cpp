@@ -9,6 +9,7 @@
 #include <cstring>
 #include <numeric>
 
+#include "host_sort.h"
 #include "vdf_ctx.h"
 
 namespace {
@@ -69,27 +70,6 @@ bool is_sorted_u32(const uint32_t *d, size_t n)
 
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
 constexpr size_t kPinSmallBytes = 4u << 20;
-
-// Hits into (row, col) order.  LSD radix sort over the 64-bit key row << 32 | col, 11-bit digits, digits that every key shares
-// skipped (row < 2^17 and col < 2^20 leave four passes): 50 k hits 0.3 ms, where std::sort through hit_less took 2-3 ms.
-static void sort_hits(vdf_hit *hits, size_t n)
-{
-    if (n < 4096) { std::sort(hits, hits + n, [](const vdf_hit &a, const vdf_hit &b) { return hit_less(a, b); }); return; }
-    auto key = [](const vdf_hit &h) { return ((uint64_t)h.row << 32) | h.col; };
-    uint64_t all_or = 0, all_and = ~0ull;
-    for (size_t i = 0; i < n; i++) { const uint64_t k = key(hits[i]); all_or |= k; all_and &= k; }
-    std::vector<vdf_hit> tmp(n);
-    vdf_hit *src = hits, *dst = tmp.data();
-    for (int shift = 0; shift < 64; shift += 11) {
-        if ((((all_or ^ all_and) >> shift) & 0x7FFull) == 0) continue;
-        size_t count[2049] = {0};
-        for (size_t i = 0; i < n; i++) count[((key(src[i]) >> shift) & 0x7FFull) + 1]++;
-        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
-        for (size_t i = 0; i < n; i++) dst[count[(key(src[i]) >> shift) & 0x7FFull]++] = src[i];
-        std::swap(src, dst);
-    }
-    if (src != hits) std::memcpy(hits, src, n * sizeof(vdf_hit));
-}
 
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
@@ -668,28 +648,6 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
                                d_out, d_dc, stream);
 }
 
-
-// perm = the stable ascending order of keys (LSD radix sort, 11-bit digits; a digit every key shares is skipped - durations
-// rarely need the third).  std::stable_sort through an index comparator took 8 ms for 100 k references, ten times the
-// search kernel; this takes ~0.4 ms.
-static void stable_argsort_u32(const uint32_t *keys, size_t n, uint32_t *perm)
-{
-    std::iota(perm, perm + n, 0u);
-    std::vector<uint32_t> tmp_v(n);
-    uint32_t *src = perm, *dst = tmp_v.data();
-    uint32_t all_or = 0, all_and = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; i++) { all_or |= keys[i]; all_and &= keys[i]; }
-    for (int shift = 0; shift < 32; shift += 11) {
-        const uint32_t mask = 0x7FFu;
-        if ((((all_or ^ all_and) >> shift) & mask) == 0) continue;  // every key has the same digit here
-        size_t count[2049] = {0};
-        for (size_t i = 0; i < n; i++) count[((keys[src[i]] >> shift) & mask) + 1]++;
-        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
-        for (size_t i = 0; i < n; i++) dst[count[(keys[src[i]] >> shift) & mask]++] = src[i];
-        std::swap(src, dst);
-    }
-    if (src != perm) std::memcpy(perm, src, n * 4);
-}
 
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                                      size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
