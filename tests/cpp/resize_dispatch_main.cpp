@@ -1,0 +1,92 @@
+// Host-only check of csrc/resize_dispatch.cpp: for every width the geometry the launchers will use must fit the kernels'
+// LDS buffers, keep the operand reads aligned and conflict-free where the rules say so, and the documented sizes must land
+// on the documented kernels.  Built with g++ (no HIP).
+#include <cstdio>
+#include <cstdint>
+
+#include "../../vid_dup_finder_lib_amd/csrc/resize_dispatch.h"
+
+using namespace vdf;
+
+static int fails = 0;
+#define CHECK(c, ...) do { if (!(c)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); fails++; } } while (0)
+
+int main()
+{
+    const uint8_t *aligned = reinterpret_cast<const uint8_t *>(uintptr_t(0x10000));
+    for (uint32_t w = 1; w <= 4200; w++) {
+        // ---- stream kernel
+        const uint32_t wp = stream_pitch(w);
+        CHECK(wp % 16 == 0 && wp >= w, "pitch %u -> %u", w, wp);
+        if (w % 16 != 0) {
+            CHECK((wp / 16) % 2 == 1, "re-pitched rows must fall in 16 different bank groups: %u -> %u", w, wp);
+            CHECK(wp >= w + (w % 4 ? 3u : 0u) && wp < w + 48, "pitch holds the row and the dword-alignment slack: %u -> %u", w, wp);
+        } else if (w % 256 == 0 && w >= 768) {
+            CHECK(wp == w + 16, "multiples of 256 are re-pitched: %u -> %u", w, wp);
+        } else {
+            CHECK(wp == w, "other multiples of 16 keep their pitch: %u -> %u", w, wp);
+        }
+        uint32_t nb = 0;
+        const int cls = stream_class(w, &nb);
+        const int n_kt = (int)((w + 63) / 64);
+        if (cls) {
+            const int buf = cls == 1 ? kStreamBufS : kStreamBufM;
+            CHECK(nb >= (cls == 1 ? 4u : 2u) && nb <= 4, "blocks per chunk w=%u cls=%d nb=%u", w, cls, nb);
+            // every DMA instruction fills a whole KB of LDS, and the last operand read may run 64 + 16 + 3 bytes past the chunk
+            CHECK(((16 * nb * wp + 1023) & ~1023u) + 128 <= (uint32_t)buf, "chunk fits its buffer w=%u cls=%d nb=%u wp=%u", w, cls, nb, wp);
+            CHECK(cls == 3 ? n_kt > kStreamTabM : n_kt <= (cls == 1 ? kStreamTabS : kStreamTabM), "table class w=%u cls=%d n_kt=%d", w, cls, n_kt);
+            CHECK(resize_stream_wants_band(w) == (cls == 3), "band flag w=%u", w);
+        }
+        for (uint32_t h : {129u, 270u, 1080u}) {
+            const size_t fs = (size_t)w * h;
+            const bool e = resize_stream_eligible(aligned, w, h, (fs + 15) & ~size_t(15), 16 * ((fs + 15) & ~size_t(15)), false);
+            if (e) CHECK(cls != 0 && w >= 256, "eligible implies a class w=%u", w);
+            if (cls != 0 && w >= 256 && w % 128 != 0) CHECK(e, "every unaligned width with a class streams w=%u", w);
+            CHECK(!resize_stream_eligible(aligned + 4, w, h, fs, 16 * fs, true), "misaligned base must not stream w=%u", w);
+        }
+        // ---- K-split kernel
+        if (w % 16 == 0 && w >= 1024 && w <= 4096) {
+            uint32_t kp = 0;
+            const uint32_t knb = ksplit_geometry(w, &kp);
+            CHECK(kp % 16 == 0 && (kp / 16) % 2 == 1 && kp >= w && kp <= w + 16, "k-split pitch %u -> %u", w, kp);
+            CHECK(knb >= 1 && knb <= 4 && ((16 * knb * kp + 1023) & ~1023u) + 128 <= (uint32_t)kKsplitBuf, "k-split chunk w=%u nb=%u", w, knb);
+            CHECK(n_kt <= 64, "k-split tiles per wave w=%u", w);
+            CHECK(resize_ksplit_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "k-split eligible w=%u", w);
+        } else {
+            CHECK(!resize_ksplit_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "k-split must refuse w=%u", w);
+        }
+        // ---- cropped stream kernel: every crop box of an eligible pitch must fit with at least one block
+        int ccls = 0;
+        if (resize_cropped_stream_class(w, &ccls)) {
+            CHECK(ccls == 1 || ccls == 2, "cropped class pitch=%u", w);
+            for (uint32_t cw : {1u, 17u, w / 3 + 1, w - 1, w}) {
+                for (uint32_t x0 : {0u, 1u, 5u}) {
+                    if (cw == 0 || x0 + cw > w) continue;
+                    uint32_t cp = 0;
+                    const uint32_t cnb = resize_cropped_stream_blocks(cw, x0, w, ccls, &cp);
+                    const bool linear = x0 == 0 && cw == w && w % 16 == 0 && w % 256 != 0;
+                    CHECK(cp % 16 == 0 && (linear ? cp == w : (cp >= cw + 3 && (cp / 16) % 2 == 1)), "crop pitch pitch=%u cw=%u x0=%u -> %u", w, cw, x0, cp);
+                    CHECK(cnb >= 1 && ((16 * cnb * cp + 1023) & ~1023u) + 128 <= (uint32_t)(ccls == 1 ? kStreamBufS : kStreamBufM),
+                          "crop chunk pitch=%u cw=%u nb=%u cp=%u", w, cw, cnb, cp);
+                }
+            }
+        }
+    }
+    // the sizes DESIGN.md names
+    struct { uint32_t w; int cls; uint32_t nb; } want[] = {{480, 1, 4}, {426, 1, 4}, {854, 2, 4}, {960, 2, 4}, {640, 2, 4}, {768, 2, 4}, {1024, 2, 3},
+                                                            {1280, 3, 3}, {1440, 3, 2}, {1920, 3, 2}, {1366, 3, 2}};
+    for (auto &q : want) {
+        uint32_t nb = 0;
+        const int cls = stream_class(q.w, &nb);
+        CHECK(cls == q.cls && nb == q.nb, "w=%u: class %d nb %u, expected %d %u", q.w, cls, nb, q.cls, q.nb);
+    }
+    for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u})
+        CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should stream by default", w);
+    for (uint32_t w : {1536u, 2048u, 3840u, 128u, 200u})
+        CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should not stream by default", w);
+    uint32_t kp = 0;
+    CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");
+    CHECK(ksplit_geometry(2048, &kp) == 2 && kp == 2064, "2048 wide: two blocks per chunk");
+    if (fails == 0) std::printf("resize dispatch ok\n");
+    return fails ? 1 : 0;
+}

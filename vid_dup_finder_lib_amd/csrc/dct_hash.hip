@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "resize_dispatch.h"
 #include "resize_tables.h"
 #include "vdf_internal.h"
 
@@ -969,66 +970,6 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     write_pending();
 }
 
-// LDS budget of the instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide); M = one workgroup
-// per CU, 32 KB of table and two 62 KB chunk buffers: frames up to 1024 wide keep the whole table there, wider ones
-// (up to 1984: two 16-row blocks per chunk) the band form (16 outputs x at most 15 tiles x 128 B + padding)
-constexpr int kStreamBufS = 30 * 1024 + 128, kStreamTabS = 8;
-constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
-static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
-
-// LDS row pitch: the frame's own for multiples of 16; otherwise the next odd multiple of 16 that holds the row and the
-// up to 3 bytes a dword-aligned row start puts in front of it
-static uint32_t stream_pitch(uint32_t w)
-{
-    // multiples of 256: at the frame's own pitch the 16 rows of a block would share one bank group (16-way conflict on
-    // every operand read); re-pitched, 768 / 1024 / 1280 wide gain 12 / 10 / 6 %.  Pitches with 8-way conflicts or fewer
-    // (1920, 640, 480 ...) are faster left alone: the linear DMA is worth more than the conflicts cost.
-    if (w % 16 == 0) return (w % 256 == 0 && w >= 768) ? w + 16 : w;
-    uint32_t wp = (w + (w % 4 ? 3u : 0u) + 15u) & ~15u;
-    if ((wp / 16) % 2 == 0) wp += 16;
-    return wp;
-}
-
-static uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes)
-{
-    for (uint32_t nb = 4; nb >= 1; nb--)
-        if ((size_t)((16u * nb * wp + 1023u) & ~1023u) + 128u <= (size_t)buf_bytes) return nb;  // + the operand reads' overrun
-    return 0;
-}
-
-// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
-static int stream_class(uint32_t w, uint32_t *nb)
-{
-    const int n_kt = (int)((w + 63) / 64);
-    const uint32_t wp = stream_pitch(w);
-    if (n_kt <= kStreamTabS && stream_blocks_per_chunk(wp, kStreamBufS) == 4) { *nb = 4; return 1; }
-    *nb = stream_blocks_per_chunk(wp, kStreamBufM);
-    if (n_kt <= kStreamTabM) return *nb >= 2 ? 2 : 0;
-    return *nb >= 2 ? 3 : 0;
-}
-
-bool resize_stream_wants_band(uint32_t w)
-{
-    uint32_t nb = 0;
-    return stream_class(w, &nb) == 3;
-}
-
-// Tightly packed frames, every frame starting on a 16-byte boundary (the DMA moves 16 bytes per lane).  Widths that are a
-// multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
-// kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1024 and 1536 wide - 2 % with 48 KB chunks);
-// aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
-                            bool aligned_too)
-{
-    if (w < 256 || (uint64_t)w * h >= (1ull << 31)) return false;  // (rows are packed inside a frame; frames and clips may be padded)
-    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
-    uint32_t nb = 0;
-    const int cls = stream_class(w, &nb);
-    if (cls == 0) return false;
-    const bool repitched_whole_table = stream_pitch(w) != w && cls == 2;  // 1024 wide: 48-row chunks of 50 KB, 5.8 against 5.4 TB/s
-    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) || aligned_too;
-}
-
 template <int BUF, int TAB, bool BAND>
 static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
                                size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
@@ -1089,7 +1030,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
                                                                        MfmaResizeTables T, uint32_t nb, uint32_t Wp,
                                                                        uint8_t *__restrict__ small)
 {
-    constexpr int kBuf = 75 * 1024 + 128;
+    constexpr int kBuf = kKsplitBuf;
     __shared__ __attribute__((aligned(16))) uint4 s_px0[kBuf / 16];
     __shared__ __attribute__((aligned(16))) uint4 s_px1[kBuf / 16];
     __shared__ __attribute__((aligned(16))) v4i s_red[2][3][64];  // partial sums of the three waves that do not own the block, by block parity
@@ -1231,25 +1172,6 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
     }
     __syncthreads();
     write_pending();
-}
-
-constexpr int kKsplitBuf = 75 * 1024 + 128;
-
-// LDS pitch and 16-row blocks per chunk of the K-split form (0 blocks: the width does not fit)
-static uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
-{
-    uint32_t p = w;  // w % 16 == 0
-    if ((p / 16) % 2 == 0) p += 16;
-    *wp = p;
-    return stream_blocks_per_chunk(p, kKsplitBuf);
-}
-
-bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
-{
-    if (w % 16 != 0 || w < 1024 || w > 4096 || (uint64_t)w * h >= (1ull << 31)) return false;
-    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
-    uint32_t wp = 0;
-    return ksplit_geometry(w, &wp) >= 1;
 }
 
 hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
@@ -1519,26 +1441,6 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     }
     __syncthreads();
     write_pending();
-}
-
-bool resize_cropped_stream_class(uint32_t pitch, int *cls)
-{
-    if (pitch < 256 || pitch > 1984) return false;
-    uint32_t nb = 0;
-    const int c = stream_class(pitch | 1u, &nb);  // | 1: size the buffers for the re-pitched form of a full-width box
-    if (c == 0) return false;
-    *cls = c == 1 ? 1 : 2;
-    return true;
-}
-
-uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp)
-{
-    uint32_t p = (crop_w + 3u + 15u) & ~15u;
-    if ((p / 16) % 2 == 0) p += 16;
-    // full-width box (top / bottom bars): the DMA is a linear copy - unless that pitch puts a block's 16 rows on one bank group
-    if (x0 == 0 && crop_w == pitch && pitch % 16 == 0 && pitch % 256 != 0) p = pitch;
-    *wp = p;
-    return stream_blocks_per_chunk(p, cls == 1 ? kStreamBufS : kStreamBufM);
 }
 
 hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,

@@ -1,0 +1,84 @@
+#include "resize_dispatch.h"
+
+namespace vdf {
+
+uint32_t stream_pitch(uint32_t w)
+{
+    if (w % 16 == 0) return (w % 256 == 0 && w >= 768) ? w + 16 : w;
+    uint32_t wp = (w + (w % 4 ? 3u : 0u) + 15u) & ~15u;
+    if ((wp / 16) % 2 == 0) wp += 16;
+    return wp;
+}
+
+uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes)
+{
+    for (uint32_t nb = 4; nb >= 1; nb--)
+        if ((size_t)((16u * nb * wp + 1023u) & ~1023u) + 128u <= (size_t)buf_bytes) return nb;  // a DMA instruction fills whole KBs
+    return 0;
+}
+
+int stream_class(uint32_t w, uint32_t *nb)
+{
+    const int n_kt = (int)((w + 63) / 64);
+    const uint32_t wp = stream_pitch(w);
+    if (n_kt <= kStreamTabS && stream_blocks_per_chunk(wp, kStreamBufS) == 4) { *nb = 4; return 1; }
+    *nb = stream_blocks_per_chunk(wp, kStreamBufM);
+    if (n_kt <= kStreamTabM) return *nb >= 2 ? 2 : 0;
+    return *nb >= 2 ? 3 : 0;
+}
+
+bool resize_stream_wants_band(uint32_t w)
+{
+    uint32_t nb = 0;
+    return stream_class(w, &nb) == 3;
+}
+
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                            bool aligned_too)
+{
+    if (w < 256 || (uint64_t)w * h >= (1ull << 31)) return false;
+    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
+    uint32_t nb = 0;
+    const int cls = stream_class(w, &nb);
+    if (cls == 0) return false;
+    const bool repitched_whole_table = stream_pitch(w) != w && cls == 2;  // 1024 wide: 48-row chunks of 50 KB, 5.8 against 5.4 TB/s
+    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) || aligned_too;
+}
+
+uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
+{
+    uint32_t p = w;  // w % 16 == 0
+    if ((p / 16) % 2 == 0) p += 16;
+    *wp = p;
+    return stream_blocks_per_chunk(p, kKsplitBuf);
+}
+
+bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
+{
+    if (w % 16 != 0 || w < 1024 || w > 4096 || (uint64_t)w * h >= (1ull << 31)) return false;
+    if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
+    uint32_t wp = 0;
+    return ksplit_geometry(w, &wp) >= 1;
+}
+
+bool resize_cropped_stream_class(uint32_t pitch, int *cls)
+{
+    if (pitch < 256 || pitch > 1984) return false;
+    uint32_t nb = 0;
+    const int c = stream_class(pitch | 1u, &nb);  // | 1: size the buffers for the re-pitched form of a full-width box
+    if (c == 0) return false;
+    *cls = c == 1 ? 1 : 2;
+    return true;
+}
+
+uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp)
+{
+    uint32_t p = (crop_w + 3u + 15u) & ~15u;
+    if ((p / 16) % 2 == 0) p += 16;
+    // full-width box (top / bottom bars): the DMA is a linear copy - unless that pitch puts a block's 16 rows on one bank group
+    if (x0 == 0 && crop_w == pitch && pitch % 16 == 0 && pitch % 256 != 0) p = pitch;
+    *wp = p;
+    return stream_blocks_per_chunk(p, cls == 1 ? kStreamBufS : kStreamBufM);
+}
+
+}  // namespace vdf

@@ -1,0 +1,53 @@
+// Which linear-stream resize kernel a frame size gets and with what geometry (LDS row pitch, 16-row blocks per chunk).
+// Host-only arithmetic (no HIP), shared by the launchers in dct_hash.hip and by api.cpp; tests/cpp/resize_dispatch_main.cpp
+// checks the LDS budgets and the pitch rules for every width on the CPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "resize_tables.h"
+
+namespace vdf {
+
+// LDS budget of the stream kernel's instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide);
+// M = one workgroup per CU, 32 KB of table and two 62 KB chunk buffers: frames up to 1024 wide keep the whole table there,
+// wider ones (up to 1984: two 16-row blocks per chunk) its band form (16 outputs x at most 15 tiles x 128 B + padding).
+// The K-split kernel keeps its table in registers: two 75 KB buffers.  + 128: the operand reads' overrun past the last row.
+constexpr int kStreamBufS = 30 * 1024 + 128, kStreamTabS = 8;
+constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
+constexpr int kKsplitBuf = 75 * 1024 + 128;
+constexpr int kStreamPartBytes = 3 * 64 * 4 * 4;  // s_part: the vertical partial sums of waves 1..3
+constexpr int kLdsPerCu = 160 * 1024;
+static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
+static_assert(2 * (2 * kStreamBufS + kStreamTabS * 2048 + kStreamPartBytes) <= kLdsPerCu, "two S workgroups per CU");
+static_assert(2 * kStreamBufM + kStreamTabM * 2048 + kStreamPartBytes <= kLdsPerCu, "one M workgroup per CU");
+static_assert(2 * kKsplitBuf + 2 * 3 * 64 * 16 + kStreamPartBytes <= kLdsPerCu, "one K-split workgroup per CU");
+
+// LDS row pitch of the stream kernel: the frame's own for multiples of 16 - unless it is a multiple of 256, where the 16
+// rows of a block would share one bank group (16-way conflict on every operand read: re-pitched, 768 / 1024 / 1280 wide
+// gain 12 / 10 / 6 %; pitches with 8-way conflicts or fewer - 1920, 640, 480 - are faster left alone: the linear DMA is
+// worth more than the conflicts cost); otherwise the next odd multiple of 16 that holds the row and the up to 3 bytes a
+// dword-aligned row start puts in front of it.
+uint32_t stream_pitch(uint32_t w);
+// 16-row blocks per chunk (at most 4) that fit a buffer at that pitch; 0 = not even one
+uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes);
+// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
+int stream_class(uint32_t w, uint32_t *nb);
+bool resize_stream_wants_band(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
+// Frames starting on 16-byte boundaries, rows packed inside a frame (frames and clips may be padded).  Widths that are a
+// multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
+// kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1536 wide - 2 % with 48 KB chunks);
+// aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                            bool aligned_too);
+
+// K-split form (1024..4096 columns, a multiple of 16): LDS pitch (an odd multiple of 16) and blocks per chunk (0: does not fit)
+uint32_t ksplit_geometry(uint32_t w, uint32_t *wp);
+bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride);
+
+// cropped clips: can frames of this pitch take the stream form and with which buffers (1 = S, 2 = M); per crop box the LDS
+// pitch and the blocks per chunk (a full-width box at a pitch without 16-way conflicts keeps the frame's pitch: linear DMA)
+bool resize_cropped_stream_class(uint32_t pitch, int *cls);
+uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp);
+
+}  // namespace vdf

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/vdf.h"
+#include "resize_dispatch.h"
 
 namespace vdf {
 
@@ -108,15 +109,11 @@ hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint
                                      const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream);
 // linear-stream form for tightly packed frames whose width is a multiple of 16 but not of the 128-byte line
 // (a.av in kMfmaLayoutVertical order); resize_stream_eligible says whether a call qualifies
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
-                            bool aligned_too);
-bool resize_stream_wants_band(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
                                             uint8_t *small, hipStream_t stream);
 // K-split form for wide frames (1024..4096 columns, a multiple of 16): horizontal table in registers, a.bh in plain
 // kMfmaLayoutHorizontal form, a.av in kMfmaLayoutVertical order
-bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride);
 hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
                                             uint8_t *small, hipStream_t stream);
@@ -143,8 +140,6 @@ struct CropStreamTable {
     const int32_t *meta;  // band form: kt_lo[16], nt[16] (horizontal tables only)
     int32_t n_tiles, precision, band_stride, pad;
 };
-bool resize_cropped_stream_class(uint32_t pitch, int *cls);                  // can frames of this pitch take the stream form, and which
-uint32_t resize_cropped_stream_blocks(uint32_t crop_w, uint32_t x0, uint32_t pitch, int cls, uint32_t *wp);  // 16-row blocks per chunk (0: does not fit) and the LDS pitch
 hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,
                                              size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
                                              const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
