@@ -37,11 +37,12 @@ int main()
             CHECK(cls == 3 ? n_kt > kStreamTabM : n_kt <= (cls == 1 ? kStreamTabS : kStreamTabM), "table class w=%u cls=%d n_kt=%d", w, cls, n_kt);
             CHECK(resize_stream_wants_band(w) == (cls == 3), "band flag w=%u", w);
         }
-        for (uint32_t h : {129u, 270u, 1080u}) {
+        for (uint32_t h : {129u, 270u, 1080u, 1088u}) {
             const size_t fs = (size_t)w * h;
             const bool e = resize_stream_eligible(aligned, w, h, (fs + 15) & ~size_t(15), 16 * ((fs + 15) & ~size_t(15)), false);
-            if (e) CHECK(cls != 0 && w >= 256, "eligible implies a class w=%u", w);
-            if (cls != 0 && w >= 256 && w % 128 != 0) CHECK(e, "every unaligned width with a class streams w=%u", w);
+            if (e) CHECK(cls != 0 && w >= 64, "eligible implies a class w=%u", w);
+            if (cls != 0 && w >= 64 && w % 128 != 0 && ((uint64_t)w * h) % 16 == 0) CHECK(e, "every unaligned width with a class streams w=%u", w);
+            if (((uint64_t)w * h) % 16 != 0) CHECK(!e, "frames that do not end on a 16-byte boundary must not stream w=%u h=%u", w, h);
             CHECK(!resize_stream_eligible(aligned + 4, w, h, fs, 16 * fs, true), "misaligned base must not stream w=%u", w);
         }
         // ---- K-split kernel
@@ -80,9 +81,9 @@ int main()
         const int cls = stream_class(q.w, &nb);
         CHECK(cls == q.cls && nb == q.nb, "w=%u: class %d nb %u, expected %d %u", q.w, cls, nb, q.cls, q.nb);
     }
-    for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u})
+    for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u, 240u, 160u, 128u})
         CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should stream by default", w);
-    for (uint32_t w : {1536u, 2048u, 3840u, 128u, 200u})
+    for (uint32_t w : {1536u, 2048u, 3840u, 48u, 63u})
         CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should not stream by default", w);
     uint32_t kp = 0;
     CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");

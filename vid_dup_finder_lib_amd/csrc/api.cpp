@@ -522,7 +522,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     // 5.44 against 5.84 ms, 1280x720 2.54 against 2.74); VDF_RESIZE_MODE=5 takes them too.
     int stream_cls = 0;
     if (((ctx->resize_mode == 0 && w % 128 != 0) || ctx->resize_mode == 5) && (h + 63) / 64 > 2 &&
-        (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 && (uint64_t)w * h < (1ull << 31) &&
+        (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 && (uint64_t)w * h < (1ull << 31) && ((uint64_t)w * h) % 16 == 0 &&
         vdf::resize_cropped_stream_class(w, &stream_cls)) {
         std::vector<vdf::CropStreamClip> sc(n_clips);
         std::vector<vdf::CropStreamTable> st;

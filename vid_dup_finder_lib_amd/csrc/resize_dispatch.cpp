@@ -36,7 +36,11 @@ bool resize_stream_wants_band(uint32_t w)
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too)
 {
-    if (w < 256 || (uint64_t)w * h >= (1ull << 31)) return false;
+    // narrow tall frames (portrait video) gain the most: 240 x 426 4.6 -> 6.1 TB/s, 160 x 200 3.5 -> 4.2 against the whole-line kernels
+    if (w < 64 || (uint64_t)w * h >= (1ull << 31)) return false;
+    // frames must also END on a 16-byte boundary: the buffer resource is sized to the frame and the range check drops a dword that
+    // straddles its end (203 x 301 frames lost their last pixels: found by the strided-buffer test)
+    if (((uint64_t)w * h) % 16 != 0) return false;
     if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
