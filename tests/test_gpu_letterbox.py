@@ -67,7 +67,8 @@ def stream_mode(request, monkeypatch):
 
 
 @pytest.mark.parametrize("h,w", [(40, 56), (64, 64), (90, 160), (217, 131), (120, 256), (270, 480), (300, 200), (136, 333),
-                                 (360, 640), (480, 854), (576, 720), (300, 500), (1080, 1920), (333, 1366), (240, 426)])
+                                 (360, 640), (480, 854), (576, 720), (300, 500), (1080, 1920), (333, 1366), (240, 426),
+                                 (426, 240), (320, 176), (200, 96)])
 def test_letterbox_hash_matches_oracle(h, w, stream_mode):
     """crop_video_frames(Letterbox) + from_frames: same crop, same hash bits (don't-care rule) as hashing the cropped
     copies on the CPU; the device reads the crop box in place.  Frames of 256..1984 columns and more than 128 rows go
@@ -125,6 +126,29 @@ def test_cropped_device_entry_point_and_errors(engine):
     with pytest.raises(vdf.VdfError) as ei:
         engine.hash_frames_letterbox(frames[:, :9])
     assert ei.value.code == -1  # NotEnoughFrames
+
+
+@pytest.mark.parametrize("h,w,crop", [(300, 720, (5, 3, 10, 7)), (426, 240, (5, 3, 60, 29)), (320, 176, (2, 13, 71, 13)),
+                                      (300, 720, (6, 2, 0, 0)), (300, 720, (0, 0, 31, 17))])
+def test_cropped_box_whose_padded_width_equals_the_pitch(engine, h, w, crop):
+    """A crop box narrower than the frame whose LDS pitch (width + 3, rounded up to an odd multiple of 16) comes out equal to
+    the frame's pitch takes the linear DMA loop of the cropped stream kernel although it does not start on a dword: the
+    copy must start at the dword below the first pixel (LDS-DMA does not simply ignore the low address bits; found at
+    240 and 176 wide, could have hit 720 wide)."""
+    rng = np.random.default_rng(h + w)
+    frames = rng.integers(0, 256, size=(24, 16, h, w), dtype=np.uint8)
+    crops = np.tile(np.array(crop, np.uint32), (24, 1))
+    crops[::3] = 0  # a third of the clips uncropped: mixed boxes in one launch
+    d = torch.from_numpy(frames).cuda()
+    out = torch.zeros((24, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.hash_frames_cropped_device(d.data_ptr(), 24, 16, w, h, crops, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for c in range(24):
+        l, r, t, b = (int(x) for x in crops[c])
+        rc, want, coefs = orc.hash_clip(np.ascontiguousarray(frames[c][:, t:h - b, l:w - r]), want_coefs=True)
+        assert rc == 0 and np.array_equal(got[c], want), c
 
 
 def test_gen_hashes_mirrors_the_builder_default(engine):

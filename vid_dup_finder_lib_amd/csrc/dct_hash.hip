@@ -1273,10 +1273,12 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
         const uint32_t first = (q.y0 + c * rpc) * pitch + q.x0;  // frame byte of the chunk's first pixel
         // this lane's position in the chunk (column, row * pitch), advanced by adds and one compare per instruction: a multiply
         // high and two multiplies per instruction made the ISSUE of a chunk's DMA cost 0.4 us of a 2.5 us step
-        if (q.wp == pitch) {  // full-width box at the frame's own pitch: LDS position P <- frame byte first + P, a linear copy
+        if (q.wp == pitch) {  // LDS pitch == frame pitch (a full-width box, or a narrower one whose padded width happens to be the
+            // pitch): LDS position P <- frame byte first + P, a linear copy from the dword at or below the box's first pixel
+            const uint32_t first_al = SHIFT ? first & ~3u : first;
             for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
                 auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(first + off + 16u * lane), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(first_al + off + 16u * lane), 0, 0, 0);
             }
             return;
         }

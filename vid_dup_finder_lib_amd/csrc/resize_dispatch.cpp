@@ -67,7 +67,7 @@ bool resize_ksplit_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
 
 bool resize_cropped_stream_class(uint32_t pitch, int *cls)
 {
-    if (pitch < 256 || pitch > 1984) return false;
+    if (pitch < 64 || pitch > 1984) return false;
     uint32_t nb = 0;
     const int c = stream_class(pitch | 1u, &nb);  // | 1: size the buffers for the re-pitched form of a full-width box
     if (c == 0) return false;
