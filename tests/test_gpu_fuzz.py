@@ -144,3 +144,51 @@ def test_hash_fuzz_large_frames(seed):
             eng.close()
         gb = np.unpackbits(got.view(np.uint8), bitorder="little").reshape(2, 1024)[:, :1000]
         assert not (gb != wb).any(), (mode, h, w)
+
+
+@pytest.mark.parametrize("seed", range(max(30, _SOAK // 4)))
+def test_cropped_hash_fuzz(seed):
+    """vdf_hash_frames_u8_cropped_device with random frame sizes (pitches of every alignment class, 64..1100 columns, 129..420
+    rows) and random per-clip crop boxes (some clips uncropped, some full-width, some starting off a dword) through the
+    default kernels and the forced cropped-stream / whole-line ones: hashes equal to the oracle's on the cropped copies."""
+    import os
+
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(90_000 + seed)
+    w = int(rng.choice([64, 96, 176, 200, 240, 272, 320, 426, 480, 500, 600, 640, 720, 854, 960, 1024, 1100]))
+    if seed % 5 == 0:
+        w = int(rng.integers(64, 1100))
+    h = int(rng.integers(129, 420))
+    if (w * h) % 16 and seed % 2:
+        h += (16 - h % 16) % 16  # most sizes whose frames end on 16-byte boundaries (the stream kernels' condition), some that do not
+    n = 10
+    frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+    crops = np.zeros((n, 4), np.uint32)
+    for c in range(n):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            continue
+        t, b = int(rng.integers(0, h // 4)), int(rng.integers(0, h // 4))
+        l, r = (0, 0) if kind == 1 else (int(rng.integers(0, w // 5)), int(rng.integers(0, w // 5)))
+        crops[c] = (l, r, t, b)
+    want = np.stack([orc.hash_clip(np.ascontiguousarray(frames[c][:, crops[c][2]:h - crops[c][3], crops[c][0]:w - crops[c][1]]))[1]
+                     for c in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    for mode in (0, 5, 4):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+        try:
+            out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out.data_ptr())
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+        finally:
+            eng.close()
+        assert np.array_equal(got, want), (mode, h, w, np.nonzero((got != want).any(axis=1))[0].tolist(), crops.tolist())
