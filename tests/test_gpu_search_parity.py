@@ -285,3 +285,31 @@ def test_suspect_queue_overflow_goes_through_the_overflow_protocol(cand_capacity
         assert eng.search_refs_sorted(w, d, w[pick], d[pick], 300) == orc.search_refs_sorted(w, d, w[pick], d[pick], 300)
     finally:
         eng.close()
+
+
+def test_suspect_queue_slots_beyond_a_smaller_launch_are_not_read_stale(monkeypatch):
+    """One context, three searches: dense near-duplicates (the suspect queue overflows and is re-run x4 larger until it
+    fits), then a tiny search (small queue again), then the dense one once more.  The slots the first search dirtied beyond
+    the second search's capacity must be empty again before the third reads them: a stale suspect that is a true hit would
+    be emitted twice, and search_with_references outputs every hit (duplicate group members, inflated n_hits)."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_CAND_CAPACITY", "64")
+    monkeypatch.setenv("VDF_SEARCH_BACKEND", "mfma")
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(77)
+        words, dur = hg.planted_set(rng, 3000, n_clusters=20, max_copies=60, max_flips=100, durations="zero")
+        w, d, _ = hg.sort_by_duration(words, dur)
+        pick = rng.choice(len(d), size=256, replace=False)
+        want_refs = orc.search_refs_sorted(w, d, w[pick], d[pick], 350)
+        want_self = orc.search_self_sorted(w, d, 350)
+        tiny_w, tiny_d = w[:40].copy(), d[:40].copy()
+        want_tiny = orc.search_refs_sorted(tiny_w, tiny_d, tiny_w[:4], tiny_d[:4], 350)
+        for _ in range(3):
+            assert eng.search_refs_sorted(w, d, w[pick], d[pick], 350) == want_refs
+            assert eng.search_refs_sorted(tiny_w, tiny_d, tiny_w[:4], tiny_d[:4], 350) == want_tiny
+            assert eng.search_self_sorted(w, d, 350) == want_self
+            assert eng.search_self_sorted(tiny_w, tiny_d, 350) == orc.search_self_sorted(tiny_w, tiny_d, 350)
+    finally:
+        eng.close()

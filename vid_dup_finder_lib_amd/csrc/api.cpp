@@ -221,10 +221,13 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         const void *before = ctx->cand.p;
         VDF_HIP(ctx, ctx->cand.reserve((size_t)L.cand_capacity * 16));
         if (ctx->cand.p != before) ctx->cand_dirty = SIZE_MAX;  // fresh allocation: fill all of it
-        // only the slots the previous launch may have touched need the empty pattern (0xFF) again
-        const size_t fill = ctx->cand_dirty == SIZE_MAX ? ctx->cand.cap / 16 * 16 : std::min<size_t>((size_t)L.cand_capacity, ctx->cand_dirty) * 16;
+        // Only the slots earlier launches may have touched need the empty pattern (0xFF) again - ALL of them, whatever this
+        // launch's capacity is: a launch with a smaller queue (after an overflow retry's x4, or a smaller search) must not
+        // leave the slots beyond its own capacity stale for a later, larger launch to read as suspects.
+        const size_t slots = ctx->cand.cap / 16;
+        const size_t fill = (ctx->cand_dirty == SIZE_MAX ? slots : std::min<size_t>(slots, ctx->cand_dirty)) * 16;
         if (fill) VDF_HIP(ctx, hipMemsetAsync(ctx->cand.p, 0xFF, fill, stream));
-        ctx->cand_dirty = 0;
+        ctx->cand_dirty = L.cand_capacity;  // until the launch reports how far it got (an error return below keeps this bound)
         L.cand = ctx->cand.p;
         L.cand_head = ctx->counters.as<unsigned long long>() + 6;
     }
@@ -1011,6 +1014,7 @@ int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_
 {
     if (!ctx) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     if (frames_per_clip == 0) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "no frames to detect a crop on");
     if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
     if (n_clips == 0) return VDF_OK;
@@ -1030,6 +1034,7 @@ int vdf_hash_frames_u8_cropped_device(vdf_ctx *ctx, const uint8_t *d_frames, siz
 {
     if (!ctx) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops,
                                d_out_hashes, d_out_dontcare, stream ? (hipStream_t)stream : ctx->stream);
 }
@@ -1041,6 +1046,7 @@ int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, s
 {
     if (!ctx) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
     return letterbox_hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
                                         d_out_hashes, d_out_dontcare, out_crops,
                                         stream ? (hipStream_t)stream : ctx->stream);
@@ -1062,24 +1068,27 @@ int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, cons
     if (refs)
         for (uint64_t g = 0; g < ng; g++)
             if (groups->ref_index[g] >= (int64_t)n_ref) return fail(ctx, VDF_E_INVAL, "reference index out of range");
-    VDF_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    // a multi-GPU context runs this small job on its first device (the parent itself owns no stream or scratch)
+    vdf_ctx *d = device_ctx(ctx, 0);
+    DeviceGuard restore_device;
+    VDF_HIP(ctx, hipSetDevice(d->device));
+    hipStream_t s = d->stream;
     DevBuf d_off, d_mem, d_ref, d_out;
-    int rc = upload(ctx, ctx->up_hashes, hashes, n * VDF_HASH_WORDS * 8, s);
-    if (rc == VDF_OK && refs) rc = upload(ctx, ctx->up_ref_hashes, ref_hashes, n_ref * VDF_HASH_WORDS * 8, s);
-    if (rc == VDF_OK) rc = upload(ctx, d_off, groups->offsets, (ng + 1) * 8, s);
-    if (rc == VDF_OK) rc = upload(ctx, d_mem, groups->members, std::max<uint64_t>(nm, 1) * 8, s);
-    if (rc == VDF_OK && refs) rc = upload(ctx, d_ref, groups->ref_index, ng * 8, s);
+    int rc = upload(d, d->up_hashes, hashes, n * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK && refs) rc = upload(d, d->up_ref_hashes, ref_hashes, n_ref * VDF_HASH_WORDS * 8, s);
+    if (rc == VDF_OK) rc = upload(d, d_off, groups->offsets, (ng + 1) * 8, s);
+    if (rc == VDF_OK) rc = upload(d, d_mem, groups->members, std::max<uint64_t>(nm, 1) * 8, s);
+    if (rc == VDF_OK && refs) rc = upload(d, d_ref, groups->ref_index, ng * 8, s);
     hipError_t e = rc == VDF_OK ? d_out.reserve(ng * 4) : hipSuccess;
     if (rc == VDF_OK && e == hipSuccess)
-        e = vdf::launch_group_max_distance(ctx->up_hashes.as<uint32_t>(), d_off.as<unsigned long long>(),
+        e = vdf::launch_group_max_distance(d->up_hashes.as<uint32_t>(), d_off.as<unsigned long long>(),
                                            d_mem.as<unsigned long long>(),
-                                           refs ? ctx->up_ref_hashes.as<uint32_t>() : nullptr,
+                                           refs ? d->up_ref_hashes.as<uint32_t>() : nullptr,
                                            refs ? d_ref.as<long long>() : nullptr, (uint32_t)ng, d_out.as<uint32_t>(), s);
     if (rc == VDF_OK && e == hipSuccess) e = hipMemcpyAsync(out_max, d_out.p, ng * 4, hipMemcpyDeviceToHost, s);
     if (rc == VDF_OK && e == hipSuccess) e = hipStreamSynchronize(s);
     d_off.release(); d_mem.release(); d_ref.release(); d_out.release();
-    if (rc) return rc;
+    if (rc) { if (d != ctx) ctx->err = d->err; return rc; }
     if (e != hipSuccess) return fail_hip(ctx, e, "vdf_groups_max_distance");
     return VDF_OK;
 }

@@ -20,7 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/vdf.h"
+#include "vdf_ctx.h"
 
 namespace {
 
@@ -73,6 +73,7 @@ int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_bat
     q->clip_bytes = (size_t)w * h * VDF_DCT_SIZE;
     const int n_dev = vdf_ctx_device_count(ctx);
     q->slots.resize((size_t)(2 * n_dev));
+    vdf_impl::DeviceGuard restore_device;  // the loop below visits every device of the context on the caller's thread
     for (size_t k = 0; k < q->slots.size(); k++) {
         Slot &s = q->slots[k];
         const int dev = vdf_ctx_device_at(ctx, (int)(k % (size_t)n_dev));

@@ -160,6 +160,7 @@ static void worker_main(vdf_ctx *parent, int k)
 
 void destroy_multi(vdf_ctx *ctx)
 {
+    DeviceGuard restore_device;
     for (Worker *w : ctx->workers) {
         {
             std::lock_guard<std::mutex> lk(w->m);
@@ -204,19 +205,34 @@ static int replicate(vdf_ctx *ctx, const void *const *shards, const size_t *shar
         bool equal = true;
         for (size_t k = 1; k < G; k++) equal = equal && shard_n[k] == shard_n[0];
         VDF_NCCL(ctx, st, st->api.GroupStart());
-        for (size_t k = 0; k < G; k++) {
+        // A failing call must not leave the group open on this thread (some ranks queued, others not): remember the
+        // first failure, stop queueing, ALWAYS close the group, then report.
+        ncclResult_t first = ncclSuccess;
+        const char *what = "";
+        for (size_t k = 0; k < G && first == ncclSuccess; k++) {
             vdf_ctx *d = ctx->subs[k];
             char *dst = static_cast<char *>(full(d));
             if (equal) {  // X1 / X2 of SURVEY.md 2b: sendcount = (n / G) * 16 x u64, resp. n / G x u32, as 32-bit words
-                VDF_NCCL(ctx, st, st->api.AllGather(shards[k], dst, shard_n[k] * elem_bytes / 4, ncclUint32, st->comms[k], d->stream));
+                first = st->api.AllGather(shards[k], dst, shard_n[k] * elem_bytes / 4, ncclUint32, st->comms[k], d->stream);
+                what = "ncclAllGather";
             } else {
-                for (size_t r = 0; r < G; r++)
-                    if (shard_n[r])
-                        VDF_NCCL(ctx, st, st->api.Broadcast(shards[r], dst + off[r] * elem_bytes, shard_n[r] * elem_bytes / 4,
-                                                            ncclUint32, (int)r, st->comms[k], d->stream));
+                for (size_t r = 0; r < G && first == ncclSuccess; r++)
+                    if (shard_n[r]) {
+                        first = st->api.Broadcast(shards[r], dst + off[r] * elem_bytes, shard_n[r] * elem_bytes / 4, ncclUint32,
+                                                  (int)r, st->comms[k], d->stream);
+                        what = "ncclBroadcast";
+                    }
             }
         }
-        VDF_NCCL(ctx, st, st->api.GroupEnd());
+        const ncclResult_t ended = st->api.GroupEnd();
+        if (first == ncclSuccess && ended != ncclSuccess) { first = ended; what = "ncclGroupEnd"; }
+        if (first != ncclSuccess) {
+            const std::string msg = std::string(what) + ": " + st->api.GetErrorString(first);
+            for (ncclComm_t c : st->comms)  // the communicators' state is unknown now: the next call builds new ones
+                if (c) (void)st->api.CommDestroy(c);
+            st->comms.clear();
+            return fail(ctx, VDF_E_RCCL, msg);
+        }
         return VDF_OK;
     }
     for (size_t k = 0; k < G; k++) {
@@ -243,6 +259,7 @@ int vdf_ctx_create_multi(const int *device_ids, int n_devices, vdf_ctx **out)
     if (!device_ids || n_devices < 1 || n_devices > 64) return VDF_E_INVAL;
     vdf_ctx *parent = new (std::nothrow) vdf_ctx();
     if (!parent) return VDF_E_OOM;
+    DeviceGuard restore_device;  // create_single binds the calling thread to each listed device in turn
     parent->device = device_ids[0];
     std::string err;
     for (int k = 0; k < n_devices; k++) {
@@ -296,6 +313,7 @@ int vdf_search_self_shards(vdf_ctx *ctx, const uint64_t *const *d_hash_shards, c
     }
     if (n == 0) return vdf_groups_finish_self(out);
     if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    DeviceGuard restore_device;
     for (vdf_ctx *d : ctx->subs) {
         VDF_HIP(ctx, hipSetDevice(d->device));
         VDF_HIP(ctx, d->up_hashes.reserve(n * VDF_HASH_WORDS * 8));
@@ -334,6 +352,7 @@ int vdf_search_refs_shards(vdf_ctx *ctx, const uint64_t *const *d_cand_hash_shar
     }
     if (n_cand == 0 || n_ref == 0) return vdf_groups_from_ref_hits(nullptr, 0, out);
     if (n_cand >= 0xFFFFFFFFull || n_ref >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    DeviceGuard restore_device;
     for (size_t k = 0; k < G; k++) {
         vdf_ctx *d = ctx->subs[k];
         VDF_HIP(ctx, hipSetDevice(d->device));

@@ -138,6 +138,16 @@ int fail_hip(vdf_ctx *ctx, hipError_t e, const char *what);
         if (e__ != hipSuccess) return vdf_impl::fail_hip((ctx), e__, #call);    \
     } while (0)
 
+// Entry points that walk over several devices on the CALLER's thread put its current HIP device back on every exit path
+// (a torch caller would otherwise silently continue on the last listed GPU).
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) { saved = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 inline bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; }
 
 // ---- single-device building blocks (api.cpp); the caller holds the lock of the context it passes -----------------
