@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: all-pairs Hamming search() over random VideoHashes (BASELINE.json configs[1]:
 1 M hashes, default tolerance 0.35 -> 350, one MI355X), plus the DCT-hash throughput on 64x64 frame stacks
-(configs[2]) reported in the same JSON line under "hash".
+(configs[2]) reported in the same JSON line under "hash", and the named legs below.
 
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 runs one rank per GPU over RCCL.  Launched by torch.distributed.run (RANK in the environment) this process IS a
 rank; launched plainly it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process
-BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's status.  --single-process uses
-the C ABI's multi-GPU context instead (vdf_ctx_create_multi: one host thread per device inside the library, no torch
-collectives): the form a Rust caller of search() gets.
+BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's status.  Either way, once the ranks
+have torn their process group down, rank 0 also runs the SAME workload through the C ABI's multi-GPU context in a fresh
+child process (`--single-process`: vdf_ctx_create_multi, one host thread per device inside the library, the library's own
+RCCL all-gather - the form a Rust caller of search() gets) and carries its result as "single_process" in the one line;
+a failing or hanging leg is reported there, the exit status stays the ranks'.
 
 A step = one full pass of the search hot path over the database resident in HBM: (N > 1: RCCL all-gather of the
-per-rank shards,) duration windows + tile list, the tiled XOR+popcount kernel, hit download, host replay of the
+per-rank shards,) duration windows + tile list, the distance kernel, hit download, host replay of the
 greedy grouping.  value = hash pairs admitted by the reference's duration windows / wall time, whole job.
-Scaling is weak: the database grows as sqrt(N) so the pairs PER GPU stay fixed (~5e11).
+Scaling of the headline is weak: the database grows as sqrt(N) so the pairs PER GPU stay fixed (~5e11).
+
+Named legs in the same line (sizes are flags, so tests run them small):
+  c4_10m_sharded   BASELINE configs[3]: all-pairs search() over 10 M hashes, database sharded over the N ranks, one
+                   all-gather, row tiles round-robin (strong scaling; at N = 1 also reported as "ten_million")
+  c5_end_to_end    BASELINE configs[4]: 1 M candidate + 100 k reference clips of 16 x 64 x 64 hashed per rank, hashes
+                   all-gathered, Search::sort on the device, search_with_references, groups - with a phase breakdown
+  dup_heavy        a duplicate-DENSE database (10 % of 1 M hashes in clusters of 2-200): what hits, suspect queue,
+                   download and replay cost when the finder finds a lot (N = 1)
+  windowed, valu_backend, refs_c5_shape, hash.* (N = 1), cpu_baseline (the oracle on host cores; N = 1)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -39,6 +51,7 @@ BYTES_PER_FRAME = 4104  # 4096 B read + 8 B written per 64x64 frame
 FLOP_PER_PAIR = 2048
 MFMA_FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: ~10 PF dense FP4/FP6 (spec).  tools/ubench_mfma.hip sustains
 #                                  4.4e12 pairs/s = 9.0 PFLOP/s with operands held in registers.
+LEG_STEPS_MAX = 3  # the side legs repeat at most this often, whatever --steps the driver picks for the headline
 
 
 def make_hashes(n, seed, planted_every=1000):
@@ -58,9 +71,47 @@ def make_hashes(n, seed, planted_every=1000):
     return words
 
 
+def make_dup_heavy(n, seed=20250619, frac=0.10, max_cluster=200):
+    """A duplicate-dense database in Search::sort order: `frac` of the n hashes sit in clusters of 2..max_cluster
+    near-copies of a centre (every bit flipped with a per-member probability <= 0.15, so all members of a cluster are
+    within tolerance 350 of each other) that share the centre's duration; durations log-uniform 5 s .. 2 h.
+    Returns (words [n, 16] u64, durations [n] u32, n_clusters, pairs_in_clusters)."""
+    rng = np.random.default_rng(seed)
+    words = rng.integers(0, 2**64, size=(n, 16), dtype=np.uint64)
+    words[:, 15] &= np.uint64((1 << 40) - 1)
+    dur = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n))).astype(np.uint32)
+    n_dup = int(n * frac)
+    sizes = []
+    left = n_dup
+    while left >= 2:
+        s = int(min(rng.integers(2, max_cluster + 1), left))
+        if left - s == 1:
+            s += 1
+        sizes.append(s)
+        left -= s
+    idx = rng.permutation(n)[: sum(sizes)]
+    pos = 0
+    pairs = 0
+    for s in sizes:
+        mem = idx[pos:pos + s]
+        pos += s
+        pairs += s * (s - 1) // 2
+        centre = np.unpackbits(words[mem[0]].view(np.uint8), bitorder="little")
+        flips = rng.random((s - 1, 1024), dtype=np.float32) < rng.uniform(0.0, 0.15, size=(s - 1, 1)).astype(np.float32)
+        bits = centre[None, :] ^ flips.astype(np.uint8)
+        words[mem[1:]] = np.packbits(bits, axis=1, bitorder="little").view(np.uint64)
+        dur[mem[1:]] = dur[mem[0]]
+    order = np.argsort(dur, kind="stable")
+    return np.ascontiguousarray(words[order]), np.ascontiguousarray(dur[order]), len(sizes), pairs
+
+
 def cpu_baseline(words, tol_int, target_seconds=12.0):
     """The oracle (C port of Search::search_self, single thread like the reference) on a prefix of the same
-    database.  Sized to ~10-20 s from a short calibration run."""
+    database.  Sized to ~10-20 s from a short calibration run.  all_cores: the search_one loop
+    (search_algorithm.rs:67-74) row-parallel over every host thread - NOT in the reference (its search is single-threaded),
+    stated so that the box's core count sits next to the 1-thread figure (optional row)."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import vdf_oracle as orc
 
     cal = 6000
@@ -75,8 +126,22 @@ def cpu_baseline(words, tol_int, target_seconds=12.0):
     orc.search_self_sorted(words[:n], d, tol_int)
     dt = time.perf_counter() - t0
     pairs = n * (n - 1) / 2
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rows_per = 256
+    n_cols = int(min(len(words), 200_000))
+    n_rows = int(min(n_cols, max(cores * rows_per, rate * 4.0 * cores / n_cols // rows_per * rows_per)))  # ~4 s
+    cw, cd = words[:n_cols], np.zeros(n_cols, np.uint32)
+    chunks = [(a, min(a + rows_per, n_rows)) for a in range(0, n_rows, rows_per)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL
+        list(ex.map(lambda ab: orc.search_refs_sorted(cw, cd, cw[ab[0]:ab[1]], cd[ab[0]:ab[1]], tol_int), chunks))
+    dta = time.perf_counter() - t0
+    out["all_cores"] = {"value": n_rows * n_cols / dta, "unit": "pairs/s", "cores": cores, "in_reference": False,
+                        "sample": f"oracle search_one loop, {n_rows} target rows x {n_cols} candidates over a {cores}-thread pool "
+                                  f"({dta:.1f} s); the reference's search is single-threaded"}
+    return out
 
 
 def cpu_baseline_hash(clips_per_thread=96):
@@ -120,6 +185,13 @@ def scaled_traffic(name, clips, profiled_clips):
     return None if t is None else t * clips / profiled_clips
 
 
+def executed_pairs(st):
+    """Pair comparisons' worth of arithmetic a launch executed: blocks that take the exact early exit stop after
+    early_exit_bits of the 1024 bit positions."""
+    ee = st["early_exit_bits"]
+    return st["pairs_computed"] - st["pairs_early_exit"] * ((1.0 - ee / 1024.0) if ee else 0.0)
+
+
 def search_roofline(backend, kernel_ms):
     """roofline (+ companions) of the dominant search kernel from the library's per-step statistics:
     kernel_ms = [(kernel_ms, n_launches, pairs, pairs_computed, n_hits, pairs_early_exit, early_exit_bits)] per step,
@@ -129,16 +201,22 @@ def search_roofline(backend, kernel_ms):
     k_comp = float(np.mean([k[3] for k in kernel_ms]))   # pairs the tiles evaluated (>= admitted)
     stream_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
     hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": stream_gbs / HBM_PEAK_GBS,
-                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream model of the reference loop: 128 B per pair "
-                         "against 8 TB/s (north_star target frac >= 0.5).  Tiles keep targets in registers and share "
-                         "candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per pair (see traffic)"}
+                 "x_of_hbm_model": stream_gbs / HBM_PEAK_GBS,
+                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream MODEL of the reference loop: 128 B per pair "
+                         "against 8 TB/s (north_star target x >= 0.5).  Not a physical bandwidth: tiles keep targets in "
+                         "registers and share candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per "
+                         "pair (see roofline.traffic); x_of_hbm_model is how many times the model's roofline the kernel runs at"}
     if backend == "valu":
         kname = "hamming_tile_kernel"
-        roofline = dict(hbm_model, kernel=kname, traffic=read_traffic(kname),
-                        traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
-                        kernel_ms=k_ms, pairs_per_launch=k_pairs)
-        valu = {"achieved": k_comp * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
+        roofline = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": stream_gbs / HBM_PEAK_GBS, "note": hbm_model["note"], "kernel": kname,
+                    "traffic": read_traffic(kname),
+                    "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
+                    "kernel_ms": k_ms, "pairs_per_launch": k_pairs}
+        k_early = float(np.mean([k[5] for k in kernel_ms]))
+        ee_bits = int(kernel_ms[-1][6])
+        lane_ops = (k_comp - k_early * ((1.0 - ee_bits / 1024.0) if ee_bits else 0.0)) * LANEOPS_PER_PAIR
+        valu = {"achieved": lane_ops / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
         valu["frac"] = valu["achieved"] / valu["peak"]
         extra = {"valu": valu}
         dtype = "u32 (xor + popcount over 32 dwords per hash)"
@@ -180,11 +258,21 @@ def free_port():
         return so.getsockname()[1]
 
 
+def clean_child_env():
+    """Environment for a child process that must not inherit this process's rank identity."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+              "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+              "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+              "TORCHELASTIC_ERROR_FILE", "VDF_DIST_BACKEND"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks as a CHILD process tree (never exec: this may run under a
     profiler that has already initialised the GPU) and relay rank 0's line.  Nothing here imports torch."""
-    import subprocess
-
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -195,6 +283,63 @@ def self_launch(args):
         if line.startswith("{"):
             print(line, flush=True)
     raise SystemExit(proc.returncode)
+
+
+def single_process_leg(args, timeout_s=600):
+    """The C ABI's own multi-GPU form in a fresh CHILD process (never exec), after the ranks released the GPUs.
+    Returns the dict carried as "single_process"; failures are reported, never raised."""
+    import signal
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--n-hashes", str(args.n_hashes), "--tolerance", str(args.tolerance),
+           "--hash-clips", "0", "--c4-hashes", str(args.c4_hashes)]
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=clean_child_env(),
+                                start_new_session=True)
+        try:
+            so, se = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)  # exactly the process group started above
+            proc.communicate()
+            return {"rccl": f"error: no result within {timeout_s} s (killed)", "wall_s": time.perf_counter() - t0}
+    except Exception as e:  # noqa: BLE001
+        return {"rccl": f"error: could not start the leg: {e}"}
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        tail = (se or so or "").strip().splitlines()[-3:]
+        return {"rccl": "error: rc %d: %s" % (proc.returncode, " | ".join(tail)[-600:]), "wall_s": time.perf_counter() - t0}
+    d = json.loads(lines[-1])
+    out = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "per_device_kernel_ms", "per_device_pairs", "match_groups",
+                                 "devices", "replication")}
+    out["rccl"] = "ok"
+    out["roofline_frac"] = d.get("roofline", {}).get("frac")
+    out["c4_10m_sharded"] = d.get("c4_10m_sharded")
+    out["form"] = d["config"]["parallelism"]
+    out["wall_s"] = time.perf_counter() - t0
+    return out
+
+
+def gen_device_hashes(torch, dev, n, seed, plant_every=100_000, plant_flips=341):
+    """n random VideoHashes generated ON the device (bits 1000..1023 zero); every plant_every-th gets a copy with 0..340
+    flipped bits right behind it.  Returns (int64 tensor [n, 16], number of planted pairs)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lo32 = torch.randint(0, 2**32, (n, 16), dtype=torch.int64, device=dev, generator=g)
+    hi32 = torch.randint(0, 2**32, (n, 16), dtype=torch.int64, device=dev, generator=g)
+    w = lo32 | (hi32 << 32)
+    del lo32, hi32
+    w[:, 15] &= (1 << 40) - 1
+    src = torch.arange(0, n - 1, plant_every, device=dev)
+    if len(src):
+        rng = np.random.default_rng(seed)
+        rows = w[src].cpu().numpy().view(np.uint64)
+        for r in range(len(rows)):
+            bits = np.unpackbits(rows[r].view(np.uint8), bitorder="little")
+            bits[rng.choice(1024, size=int(rng.integers(0, plant_flips)), replace=False)] ^= 1
+            rows[r] = np.packbits(bits, bitorder="little").view(np.uint64)
+        w[src + 1] = torch.from_numpy(rows.view(np.int64)).to(dev)
+    return w, int(len(src))
 
 
 def run_single_process(args):
@@ -257,6 +402,7 @@ def run_single_process(args):
     kernel_ms = [(q["kernel_ms"], q["n_launches"], q["pairs"], q["pairs_computed"], q["n_hits"], q["pairs_early_exit"],
                   q["early_exit_bits"]) for q in slow]
     roofline, extra, dtype = search_roofline(backend, kernel_ms)
+    distinct = len(set(devices)) == len(devices)
     out = {
         "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
         "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": G, "steps": args.steps,
@@ -267,11 +413,42 @@ def run_single_process(args):
                    "n_hashes": n_total, "hashes_per_gpu_shard": sizes[0], "pairs": pairs, "tolerance_int": tol_int,
                    "parallelism": f"ONE process, vdf_ctx_create_multi over devices {devices}: shards resident per GPU, "
                                   "RCCL all-gather inside the library, row tiles round-robin, one host replay"},
-        "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
+        "roofline": roofline, "match_groups": n_groups, "search_backend": backend, "devices": devices,
+        "replication": ("ncclAllGather over xGMI (librccl loaded by the library)" if distinct and G > 1
+                        else "device-to-device copies (repeated or single device: RCCL takes one rank per device)"),
         "per_device_kernel_ms": [float(np.mean([st[k]["kernel_ms"] for st in per_dev])) for k in range(G)],
         "per_device_pairs": [int(per_dev[-1][k]["pairs"]) for k in range(G)],
     }
     out.update(extra)
+    del sw, sd
+    # ---- BASELINE configs[3] in this form: 10 M hashes, shard k generated on GPU k, one vdf_search_self_shards call
+    if args.c4_hashes > 0:
+        n10 = args.c4_hashes
+        sh, sdur, ssz, planted = [], [], [], 0
+        for k in range(G):
+            lo, hi = vd.split_range(n10, k, G)
+            dev = torch.device("cuda", devices[k])
+            w, npl = gen_device_hashes(torch, dev, hi - lo, 20250614 + k)
+            sh.append(w)
+            sdur.append(torch.zeros(hi - lo, dtype=torch.int32, device=dev))
+            ssz.append(hi - lo)
+            planted += npl
+        sync_all()
+        tenth = [max(s // 10, 1) for s in ssz]
+        eng.search_self_shards([t.data_ptr() for t in sh], [t.data_ptr() for t in sdur], tenth, tol_int)  # allocations
+        sync_all()
+        t1 = time.perf_counter()
+        g10 = eng.search_self_shards([t.data_ptr() for t in sh], [t.data_ptr() for t in sdur], ssz, tol_int)
+        sync_all()
+        dt10 = time.perf_counter() - t1
+        p10 = n10 * (n10 - 1) // 2
+        out["c4_10m_sharded"] = {"workload": f"BASELINE configs[3]: all-pairs search() over {n10} random VideoHashes sharded over "
+                                             f"{G} device(s), one call of vdf_search_self_shards", "n_hashes": n10, "pairs": p10,
+                                 "scaling": "strong", "steps": 1, "ms_per_step": dt10 * 1e3, "pairs_per_s": p10 / dt10,
+                                 "match_groups": len(g10), "planted_pairs": planted,
+                                 "per_device_kernel_ms": [eng.device_stats(k)["kernel_ms"] for k in range(G)],
+                                 "timing": eng.last_timing()}
+        del sh, sdur
     if args.hash_clips > 0:
         nc = args.hash_clips
         frames, outs = [], []
@@ -311,10 +488,16 @@ def main():
     ap.add_argument("--tolerance", type=float, default=0.35)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-windowed", dest="windowed", action="store_false", help="skip the windowed-durations leg")
-    ap.add_argument("--ten-million", type=int, default=10_000_000,
-                    help="size of the north_star target leg (all-pairs at one GPU; 0 = skip; only at --gpus 1)")
+    ap.add_argument("--c4-hashes", "--ten-million", dest="c4_hashes", type=int, default=10_000_000,
+                    help="BASELINE configs[3] leg: all-pairs over this many hashes sharded over the ranks (the north_star target "
+                         "at --gpus 1; 0 = skip)")
+    ap.add_argument("--c5-cands", type=int, default=1_000_000, help="BASELINE configs[4] leg: candidate clips, all ranks together (0 = skip)")
+    ap.add_argument("--c5-refs", type=int, default=100_000, help="BASELINE configs[4] leg: reference clips")
+    ap.add_argument("--dup-heavy", type=int, default=1_000_000, help="size of the duplicate-dense leg (0 = skip; --gpus 1 only)")
     ap.add_argument("--no-valu", dest="valu_leg", action="store_false", help="skip the XOR+popcount backend leg")
     ap.add_argument("--no-refs", dest="refs_leg", action="store_false", help="skip the search_with_references leg")
+    ap.add_argument("--no-single-process-leg", dest="sp_leg", action="store_false",
+                    help="N > 1: do not run the C ABI's single-process form after the ranks")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1 inside ONE process through vdf_ctx_create_multi (no torch.distributed)")
     args = ap.parse_args()
@@ -352,6 +535,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     eng = vdf.Engine(local_rank)
     tol_int = ve.tolerance_int(args.tolerance)
+    leg_steps = max(1, min(args.steps, LEG_STEPS_MAX))
+    cdev = dev if dist_backend == "nccl" else torch.device("cpu")
 
     # ---- database: n grows as sqrt(world) so that pairs per GPU stay fixed (weak scaling) ----------------
     n_total = int(round(args.n_hashes * world ** 0.5))
@@ -372,8 +557,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     kernel_ms = []
     n_groups = None
+    launches, suspects = [], []
 
     def step():
         nonlocal n_groups
@@ -382,6 +580,8 @@ def main():
         st = eng.last_stats()
         kernel_ms.append((st["kernel_ms"], st["n_launches"], st["pairs"], st["pairs_computed"], st["n_hits"],
                           st["pairs_early_exit"], st["early_exit_bits"]))
+        launches.append(st["n_launches"])
+        suspects.append(eng.last_timing()["suspects"])
         if rank == 0:
             n_groups = len(groups)
 
@@ -390,6 +590,8 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
+    launches.clear()
+    suspects.clear()
     gc.collect()
     gc.disable()  # a generation-2 collection (tens of ms after importing torch) must not land inside a 150 ms step
     barrier()
@@ -399,11 +601,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    cdev = dev if dist_backend == "nccl" else torch.device("cpu")
-    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = max_over_ranks(dt)
 
     backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
     roofline, extra, dtype = search_roofline(backend, kernel_ms)
@@ -418,6 +616,7 @@ def main():
                    "parallelism": f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1
                    else "single GPU"},
         "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
+        "n_launches": int(round(float(np.mean(launches)))), "suspects": int(round(float(np.mean(suspects)))),
     }
     out.update(extra)
 
@@ -429,18 +628,18 @@ def main():
         wd = torch.from_numpy(dur.view(np.int32)).to(dev)
         ww = torch.from_numpy(words[: args.n_hashes].view(np.int64)).to(dev)
         torch.cuda.synchronize()
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(max(min(args.warmup, 2), 1)):
             eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
         w_k = []
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(leg_steps):
             hits_w, _, _ = eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
             w_k.append(eng.last_stats()["kernel_ms"])
-        dtw = (time.perf_counter() - t1) / args.steps
+        dtw = (time.perf_counter() - t1) / leg_steps
         st = eng.last_stats()
         out["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"],
                            "waste_ratio": st["pairs_computed"] / max(st["pairs"], 1), "kernel_ms": float(np.mean(w_k)),
-                           "ms": dtw * 1e3, "steps": args.steps, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
+                           "ms": dtw * 1e3, "steps": leg_steps, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
                            "note": "log-uniform durations, one-sided x1.1 window (search_algorithm.rs:99); mean over steps"}
         del ww, wd
 
@@ -464,63 +663,66 @@ def main():
         torch.cuda.synchronize()
         dtv = time.perf_counter() - tv
         sv = eng_v.last_stats()
-        lane_ops = (sv["pairs_computed"] - sv["pairs_early_exit"] * (1.0 - sv["early_exit_bits"] / 1024.0
-                                                                      if sv["early_exit_bits"] else 0.0)) * LANEOPS_PER_PAIR
+        # lane-ops the kernel executed for rows < n_rows: the last row tile is padded to whole tiles (its lanes run, on
+        # zeros - not counted), waves that take the early exit stop after early_exit_bits
+        pad_rows = (-n_total) % 512
+        lane_ops = executed_pairs(sv) * (1.0 - pad_rows / (n_total + pad_rows)) * LANEOPS_PER_PAIR
         out["valu_backend"] = {"kernel": "hamming_tile_kernel", "pairs_per_s": pairs / dtv, "ms_per_step": dtv * 1e3,
                                "kernel_ms": sv["kernel_ms"], "match_groups": len(gv), "steps": 1,
                                "valu": {"achieved": lane_ops / (sv["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
-                                        "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS},
+                                        "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS,
+                                        "note": "xor + bcnt lane-ops of rows < n_rows only (64 per full pair, 52 for a wave that "
+                                                "leaves after 832 bits); peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"},
                                "note": "XOR + v_bcnt over 32 dwords per pair, candidates streamed through SGPRs; same exact "
                                        "early exit; identical MatchGroups"}
         assert len(gv) == n_groups, "VALU and MFMA backends disagree"
         eng_v.close()
+    del shard_w, shard_d
 
-    # ---- the north_star's own target size: all-pairs search() over 10 M VideoHashes on ONE GPU (BASELINE configs[3]'s
-    # database at 1 GPU).  One warm-up at a tenth of the size (allocations), one timed step.  Generated on the device.
-    if rank == 0 and world == 1 and args.ten_million > 0:
-        n10 = args.ten_million
-        g10 = torch.Generator(device=dev)
-        g10.manual_seed(20250614)
-        lo32 = torch.randint(0, 2**32, (n10, 16), dtype=torch.int64, device=dev, generator=g10)
-        hi32 = torch.randint(0, 2**32, (n10, 16), dtype=torch.int64, device=dev, generator=g10)
-        w10 = lo32 | (hi32 << 32)
-        del lo32, hi32
-        w10[:, 15] &= (1 << 40) - 1
-        # planted near-duplicates: every 100 000th hash gets a copy with 0..340 flipped bits right behind it
-        src10 = torch.arange(0, n10 - 1, 100_000, device=dev)
-        rng10 = np.random.default_rng(20250614)
-        rows = w10[src10].cpu().numpy().view(np.uint64)
-        for r in range(len(rows)):
-            bits = np.unpackbits(rows[r].view(np.uint8), bitorder="little")
-            bits[rng10.choice(1024, size=int(rng10.integers(0, 341)), replace=False)] ^= 1
-            rows[r] = np.packbits(bits, bitorder="little").view(np.uint64)
-        w10[src10 + 1] = torch.from_numpy(rows.view(np.int64)).to(dev)
-        d10 = torch.zeros(n10, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        vd.search_self_sharded(eng, w10[: n10 // 10], d10[: n10 // 10], tol_int, stream=stream)
-        torch.cuda.synchronize()
+    # ---- BASELINE configs[3]: all-pairs search() over 10 M VideoHashes, the database sharded over the ranks (shard r
+    # generated on GPU r), ONE all-gather, row tiles dealt round-robin, one replay on rank 0.  STRONG scaling: the work is
+    # fixed, expect ~10.7 s / N + the all-gather.  At one GPU this is the north_star's own target ("ten_million").
+    if args.c4_hashes > 0:
+        n10 = args.c4_hashes
+        lo10, hi10 = vd.split_range(n10, rank, world)
+        w10, planted = gen_device_hashes(torch, dev, hi10 - lo10, 20250614 + rank)
+        d10 = torch.zeros(hi10 - lo10, dtype=torch.int32, device=dev)
+        planted = int(round(sum_over_ranks(planted)))
+        tenth = max((hi10 - lo10) // 10, 1)
+        fw, fd = vd.all_gather_database(w10[:tenth].contiguous(), d10[:tenth].contiguous(), force=use_dist)
+        vd.search_self_sharded(eng, fw, fd, tol_int, stream=stream)  # allocations
+        del fw, fd
+        barrier()
         t10 = time.perf_counter()
-        g10r = vd.search_self_sharded(eng, w10, d10, tol_int, stream=stream)
+        fw, fd = vd.all_gather_database(w10, d10, force=use_dist)
         torch.cuda.synchronize()
-        dt10 = time.perf_counter() - t10
+        t_gather = time.perf_counter() - t10
+        g10r = vd.search_self_sharded(eng, fw, fd, tol_int, stream=stream)
+        barrier()
+        dt10 = max_over_ranks(time.perf_counter() - t10)
         s10 = eng.last_stats()
         p10 = n10 * (n10 - 1) // 2
-        ex10 = (s10["pairs_computed"] - s10["pairs_early_exit"] * (1.0 - s10["early_exit_bits"] / 1024.0
-                                                                   if s10["early_exit_bits"] else 0.0))
-        k10 = s10["kernel_ms"] * 1e-3
-        out["ten_million"] = {"workload": f"all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
-                                          f"{tol_int}, ONE GPU (north_star target; BASELINE configs[3] database)",
-                              "n_hashes": n10, "pairs": p10, "steps": 1, "ms_per_step": dt10 * 1e3,
-                              "pairs_per_s": p10 / dt10, "kernel_ms": s10["kernel_ms"], "n_launches": s10["n_launches"],
-                              "match_groups": len(g10r), "planted_pairs": int(len(src10)),
-                              "hbm_operand_stream_frac": p10 / dt10 * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
-        if backend != "valu":
-            out["ten_million"]["roofline"] = {"bound": "mfma", "kernel": roofline["kernel"],
-                                              "achieved": ex10 * FLOP_PER_PAIR / k10 / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
-                                              "unit": "TFLOP/s", "frac": ex10 * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
-                                              "algorithmic_frac": s10["pairs_computed"] * FLOP_PER_PAIR / k10 / 1e12 / MFMA_FP4_PEAK_TFLOPS,
-                                              "traffic": None}
-        del w10, d10
+        k10 = max_over_ranks(s10["kernel_ms"]) * 1e-3
+        ex_all = sum_over_ranks(executed_pairs(s10))
+        comp_all = sum_over_ranks(s10["pairs_computed"])
+        if rank == 0:
+            c4 = {"workload": f"BASELINE configs[3]: all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
+                              f"{tol_int}, database sharded over {world} GPU(s): one all-gather, row tiles round-robin, one replay",
+                  "n_hashes": n10, "pairs": p10, "scaling": "strong", "n_gpus": world, "steps": 1, "ms_per_step": dt10 * 1e3,
+                  "pairs_per_s": p10 / dt10, "all_gather_ms": t_gather * 1e3, "kernel_ms": k10 * 1e3,
+                  "n_launches": s10["n_launches"], "match_groups": len(g10r), "planted_pairs": planted,
+                  "hbm_operand_stream_x": p10 / dt10 * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
+            if backend != "valu":
+                c4["roofline"] = {"bound": "mfma", "kernel": roofline["kernel"], "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "achieved": ex_all * FLOP_PER_PAIR / k10 / 1e12 / world,
+                                  "frac": ex_all * FLOP_PER_PAIR / k10 / 1e12 / world / MFMA_FP4_PEAK_TFLOPS,
+                                  "algorithmic_frac": comp_all * FLOP_PER_PAIR / k10 / 1e12 / world / MFMA_FP4_PEAK_TFLOPS,
+                                  "traffic": None, "note": "per GPU: executed MFMA FLOP of all ranks / N / the slowest rank's kernel time"}
+            out["c4_10m_sharded"] = c4
+            if world == 1:
+                out["ten_million"] = dict(c4, workload=f"all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
+                                                       f"{tol_int}, ONE GPU (north_star target; BASELINE configs[3] database)")
+        del w10, d10, fw, fd
 
     # ---- search_with_references at the BASELINE configs[4] shape (hash-less half): 1 M candidates x 100 k references,
     # log-uniform durations, +-5 % windows; half of the references are near-copies of candidates.  1 GPU, rank 0.
@@ -536,21 +738,37 @@ def main():
         rw, rdur = rw[pr], rdur[pr]
         tt = [torch.from_numpy(a).to(dev) for a in (cw.view(np.int64), cdur.view(np.int32), rw.view(np.int64), rdur.view(np.int32))]
         torch.cuda.synchronize()
-        kms, wall = [], []
-        for i in range(args.steps + 1):
+        kms, wall, tms = [], [], []
+        for i in range(leg_steps + 2):
             t1 = time.perf_counter()
             hr, nh = eng.search_refs_device(tt[0].data_ptr(), tt[1].data_ptr(), n_c, tt[2].data_ptr(), tt[3].data_ptr(), n_r, tol_int,
                                             stream=stream)
-            if i:
+            if i >= 2:
                 wall.append(time.perf_counter() - t1)
                 kms.append(eng.last_stats()["kernel_ms"])
+                tms.append(eng.last_timing())
         sr = eng.last_stats()
         out["refs_c5_shape"] = {"workload": "search_with_references, 1 M candidates x 100 k references (BASELINE configs[4] without the "
                                             "hashing half), log-uniform durations, +-5 % windows, half of the references planted",
                                 "pairs": sr["pairs"], "pairs_computed": sr["pairs_computed"],
                                 "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "kernel_ms": float(np.mean(kms)),
-                                "ms": float(np.mean(wall)) * 1e3, "hits": int(nh), "pairs_per_s": sr["pairs"] / float(np.mean(wall))}
+                                "ms": float(np.mean(wall)) * 1e3, "hits": int(nh), "pairs_per_s": sr["pairs"] / float(np.mean(wall)),
+                                "timing": {k: float(np.mean([t[k] for t in tms])) for k in ("prep_ms", "stream_ms", "resolve_ms", "download_ms")}}
         del tt
+
+    # ---- BASELINE configs[4] END TO END: candidate and reference clips (16 x 64 x 64 u8) resident per rank -> hashes ->
+    # all-gather -> Search::sort on the device -> search_with_references -> groups.  Half of the references are copies of
+    # this rank's candidate clips (same frames, same duration): each must find exactly its source.
+    if args.c5_cands > 0 and args.c5_refs > 0:
+        out_c5 = leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stream, barrier, max_over_ranks,
+                        sum_over_ranks, leg_steps)
+        if rank == 0:
+            out["c5_end_to_end"] = out_c5
+
+    # ---- a duplicate-DENSE database: the product's own case.  Whole call through the C ABI on device-resident shards
+    # (vdf_search_self_shards on a one-device context: replication = one device copy), with the library's phase timing.
+    if rank == 0 and world == 1 and args.dup_heavy > 0:
+        out["dup_heavy"] = leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, words, leg_steps)
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM; clips are independent, so every rank hashes its
     # own args.hash_clips clips with no communication (weak scaling) and the job rate is the sum -----------------
@@ -569,10 +787,7 @@ def main():
             eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
         ev1.record()
         torch.cuda.synchronize()
-        ms_t = torch.tensor([ev0.elapsed_time(ev1) / args.steps], dtype=torch.float64, device=cdev)
-        if use_dist:
-            dist.all_reduce(ms_t, op=dist.ReduceOp.MAX)
-        ms = float(ms_t.item())
+        ms = max_over_ranks(ev0.elapsed_time(ev1) / args.steps)
         fps = world * nc * 16 / (ms * 1e-3)
         h_gbs = nc * 16 / (ms * 1e-3) * BYTES_PER_FRAME / 1e9  # per GPU: the kernel's own roofline
         out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": fps,
@@ -583,81 +798,158 @@ def main():
                                     "traffic": read_traffic("resize_dct_hash_fused_kernel")}}
         del frames, out_h
         # the same path at the size decoders really hand over (informational; the headline stays the 64 x 64 config)
-        if args.hash_hd_clips > 0:
-            nh = args.hash_hd_clips
-            hd = torch.empty((nh, 16, 1080, 1920), dtype=torch.uint8, device=dev)
-            for c0 in range(0, nh, 100):
-                hd[c0:c0 + 100] = torch.randint(0, 256, (min(100, nh - c0), 16, 1080, 1920), dtype=torch.uint8, device=dev, generator=g)
-            out_h = torch.zeros((nh, 16), dtype=torch.int64, device=dev)
-            eng.hash_frames_device(hd.data_ptr(), nh, 16, 1920, 1080, out_h.data_ptr(), stream=stream)
-            barrier()
-            ev0.record()
-            for _ in range(args.steps):
-                eng.hash_frames_device(hd.data_ptr(), nh, 16, 1920, 1080, out_h.data_ptr(), stream=stream)
-            ev1.record()
-            torch.cuda.synchronize()
-            ms_hd = ev0.elapsed_time(ev1) / args.steps
-            gbs = nh * 16 * (1920 * 1080 + 8) / (ms_hd * 1e-3) / 1e9
-            out["hash"]["full_hd"] = {"workload": f"{nh} clips of 16 x 1080 x 1920 u8 per GPU", "ms_per_step": ms_hd,
-                                      "frames_per_s_per_gpu": nh * 16 / (ms_hd * 1e-3),
-                                      "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
-                                                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                   "frac": gbs / HBM_PEAK_GBS,
-                                                   "traffic": scaled_traffic("resize_mfma_frame_stream_kernel@1920x1080", nh, 1000)}}
-            del hd, out_h
+        if args.hash_hd_clips > 0 and world == 1:
+            def big_leg(name, n, w, h, kernel, key, profiled):
+                buf = torch.empty((n, 16, h, w), dtype=torch.uint8, device=dev)
+                chunk = max(1, (1 << 31) // (16 * h * w))
+                for c0 in range(0, n, chunk):
+                    buf[c0:c0 + chunk] = torch.randint(0, 256, (min(chunk, n - c0), 16, h, w), dtype=torch.uint8, device=dev, generator=g)
+                oh = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+                eng.hash_frames_device(buf.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
+                barrier()
+                ev0.record()
+                for _ in range(leg_steps):
+                    eng.hash_frames_device(buf.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
+                ev1.record()
+                torch.cuda.synchronize()
+                ms_l = ev0.elapsed_time(ev1) / leg_steps
+                gbs = n * 16 * (w * h + 8) / (ms_l * 1e-3) / 1e9
+                out["hash"][name] = {"workload": f"{n} clips of 16 x {h} x {w} u8 per GPU", "ms_per_step": ms_l,
+                                     "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3),
+                                     "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                                  "traffic": scaled_traffic(key, n, profiled)}}
+                del buf, oh
+
+            big_leg("full_hd", args.hash_hd_clips, 1920, 1080, "resize_mfma_frame_stream_kernel",
+                    "resize_mfma_frame_stream_kernel@1920x1080", 1000)
             # a pitch that is not a multiple of the 128-byte line: the linear-stream kernel (LDS-DMA of whole chunks)
-            nq = 4000
-            sd = torch.randint(0, 256, (nq, 16, 270, 480), dtype=torch.uint8, device=dev, generator=g)
-            out_h = torch.zeros((nq, 16), dtype=torch.int64, device=dev)
-            eng.hash_frames_device(sd.data_ptr(), nq, 16, 480, 270, out_h.data_ptr(), stream=stream)
-            barrier()
-            ev0.record()
-            for _ in range(args.steps):
-                eng.hash_frames_device(sd.data_ptr(), nq, 16, 480, 270, out_h.data_ptr(), stream=stream)
-            ev1.record()
-            torch.cuda.synchronize()
-            ms_sd = ev0.elapsed_time(ev1) / args.steps
-            gbs = nq * 16 * (480 * 270 + 8) / (ms_sd * 1e-3) / 1e9
-            out["hash"]["pitch_480x270"] = {"workload": f"{nq} clips of 16 x 270 x 480 u8 per GPU", "ms_per_step": ms_sd,
-                                            "frames_per_s_per_gpu": nq * 16 / (ms_sd * 1e-3),
-                                            "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_stream_kernel",
-                                                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                         "frac": gbs / HBM_PEAK_GBS,
-                                                         "traffic": scaled_traffic("resize_mfma_frame_stream_kernel@480x270", nq, 4000)}}
-            del sd, out_h
+            big_leg("pitch_480x270", 4000, 480, 270, "resize_mfma_frame_stream_kernel", "resize_mfma_frame_stream_kernel@480x270", 4000)
             # 4K: the K-split form of the stream kernel (horizontal table in registers)
-            nu = 250
-            uhd = torch.empty((nu, 16, 2160, 3840), dtype=torch.uint8, device=dev)
-            for c0 in range(0, nu, 25):
-                uhd[c0:c0 + 25] = torch.randint(0, 256, (min(25, nu - c0), 16, 2160, 3840), dtype=torch.uint8, device=dev, generator=g)
-            out_h = torch.zeros((nu, 16), dtype=torch.int64, device=dev)
-            eng.hash_frames_device(uhd.data_ptr(), nu, 16, 3840, 2160, out_h.data_ptr(), stream=stream)
-            barrier()
-            ev0.record()
-            for _ in range(args.steps):
-                eng.hash_frames_device(uhd.data_ptr(), nu, 16, 3840, 2160, out_h.data_ptr(), stream=stream)
-            ev1.record()
-            torch.cuda.synchronize()
-            ms_u = ev0.elapsed_time(ev1) / args.steps
-            gbs = nu * 16 * (3840 * 2160 + 8) / (ms_u * 1e-3) / 1e9
-            out["hash"]["uhd_3840x2160"] = {"workload": f"{nu} clips of 16 x 2160 x 3840 u8 per GPU", "ms_per_step": ms_u,
-                                            "frames_per_s_per_gpu": nu * 16 / (ms_u * 1e-3),
-                                            "roofline": {"bound": "hbm", "kernel": "resize_mfma_frame_ksplit_kernel",
-                                                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                         "frac": gbs / HBM_PEAK_GBS,
-                                                         "traffic": scaled_traffic("resize_mfma_frame_ksplit_kernel@3840x2160", nu, 250)}}
-            del uhd, out_h
+            big_leg("uhd_3840x2160", 250, 3840, 2160, "resize_mfma_frame_ksplit_kernel", "resize_mfma_frame_ksplit_kernel@3840x2160", 250)
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)
         if args.hash_clips > 0:
             out["hash"]["cpu_baseline"] = cpu_baseline_hash()
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    if rank == 0:
+        if world > 1 and args.sp_leg:
+            # the ranks are gone (or going: their memory is not needed - 288 GB per GPU); this process never execs
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            out["single_process"] = single_process_leg(args)
+        print(json.dumps(out), flush=True)
+
+
+def leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stream, barrier, max_over_ranks, sum_over_ranks,
+           leg_steps):
+    n_c, n_r = args.c5_cands, args.c5_refs
+    clo, chi = vd.split_range(n_c, rank, world)
+    rlo, rhi = vd.split_range(n_r, rank, world)
+    nc_l, nr_l = chi - clo, rhi - rlo
+    need = (nc_l + nr_l) * 65536 + (n_c + n_r) * 700 + (4 << 30)
+    free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    short = sum_over_ranks(1.0 if free < need else 0.0)
+    if short:
+        return {"skipped": f"needs {need / 2**30:.0f} GiB of free HBM per GPU"}
+    torch.cuda.empty_cache()
+    g = torch.Generator(device=dev)
+    g.manual_seed(20250615 + rank)
+    cand = torch.empty((nc_l, 16, 64, 64), dtype=torch.uint8, device=dev)
+    for c0 in range(0, nc_l, 32768):  # bounded temporaries
+        cand[c0:c0 + 32768] = torch.randint(0, 256, (min(32768, nc_l - c0), 16, 64, 64), dtype=torch.uint8, device=dev, generator=g)
+    rng = np.random.default_rng(20250616 + rank)
+    cd = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=nc_l))).astype(np.int32)
+    n_pl = min(nr_l // 2, nc_l)
+    src = rng.choice(nc_l, size=n_pl, replace=False) if n_pl else np.zeros(0, np.int64)
+    origin = np.concatenate([src, np.full(nr_l - n_pl, -1)]).astype(np.int64)
+    origin = origin[rng.permutation(nr_l)]
+    ref = torch.randint(0, 256, (nr_l, 16, 64, 64), dtype=torch.uint8, device=dev, generator=g)
+    planted = np.nonzero(origin >= 0)[0]
+    if len(planted):
+        ref[torch.from_numpy(planted).to(dev)] = cand[torch.from_numpy(origin[planted]).to(dev)]
+    rd = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=nr_l))).astype(np.int32)
+    rd[planted] = cd[origin[planted]]
+    d_cd, d_rd = torch.from_numpy(cd).to(dev), torch.from_numpy(rd).to(dev)
+    n_planted = int(round(sum_over_ranks(len(planted))))
+    res = vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False)  # allocations, tables
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(leg_steps):
+        res = vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False)
+    barrier()
+    dt = max_over_ranks((time.perf_counter() - t0) / leg_steps)
+    tm = {}
+    vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False, timings=tm)  # phases, each behind a sync
+    sr = eng.last_stats()
+    stl = eng.last_timing()
+    tm = {k: max_over_ranks(v) for k, v in sorted(tm.items())} if use_dist else tm
+    pairs = sum_over_ranks(sr["pairs"])
+    del cand, ref
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    offsets, members, ref_index = res[0]
+    clips = n_c + n_r
+    # device work of a step: hashing at the hash kernel's rate + the search kernel: what the wall time is compared with
+    return {"workload": f"BASELINE configs[4] end to end: {n_c} candidate + {n_r} reference clips of 16 x 64 x 64 u8 resident in HBM "
+                        f"({clips * 65536 / 1e9:.1f} GB over {world} GPU(s)) -> VideoHash -> all-gather -> Search::sort (device) -> "
+                        "search_with_references (+-5 % windows) -> groups",
+            "n_candidates": n_c, "n_references": n_r, "n_gpus": world, "scaling": "strong", "steps": leg_steps,
+            "ms_per_step": dt * 1e3, "clips_per_s": clips / dt, "frames_per_s": clips * 16 / dt,
+            "phases_ms": tm, "phases_note": "one extra call with a device synchronisation after every phase (max over ranks); "
+                                            "group_ms = hit gather + CSR groups + order download on rank 0",
+            "search_pairs": pairs, "search_kernel_ms": sr["kernel_ms"], "search_call_timing": stl,
+            "groups": int(len(ref_index)), "members": int(len(members)), "planted_references": n_planted}
+
+
+def leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, sparse_words, leg_steps):
+    n = args.dup_heavy
+    t_gen = time.perf_counter()
+    words, dur, n_clusters, cluster_pairs = make_dup_heavy(n)
+    t_gen = time.perf_counter() - t_gen
+    eng1 = vdf.Engine(devices=[local_rank])
+    out = {}
+    try:
+        def run(w, d, reps):
+            tw = torch.from_numpy(w.view(np.int64)).to(dev)
+            td = torch.from_numpy(d.view(np.int32)).to(dev)
+            torch.cuda.synchronize()
+            eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int)  # allocations
+            wall, tms, sts, ng = [], [], [], 0
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                groups = eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int)
+                wall.append((time.perf_counter() - t0) * 1e3)
+                tms.append(eng1.last_timing())
+                sts.append(eng1.last_stats())
+                ng = len(groups)
+                members = sum(len(g) for g in groups)
+            tm = {k: float(np.mean([t[k] for t in tms])) for k in tms[0]}
+            return float(np.mean(wall)), tm, sts[-1], ng, members
+
+        ns = min(n, len(sparse_words))
+        sp_dur = np.ascontiguousarray(dur[np.linspace(0, n - 1, ns).astype(np.int64)])  # the same (sorted) duration profile
+        sp_ms, sp_tm, sp_st, sp_groups, _ = run(np.ascontiguousarray(sparse_words[:ns]), sp_dur, leg_steps)
+        dn_ms, dn_tm, dn_st, dn_groups, dn_members = run(words, dur, leg_steps)
+        out = {"workload": f"search() over {n} hashes, {n_clusters} clusters of 2..200 near-copies ({int(0.10 * n)} hashes) within "
+                           "tolerance 350 sharing their centre's duration, log-uniform durations (one-sided x1.1 windows); whole "
+                           "vdf_search_self_shards call on the device-resident database (one-device context)",
+               "n_hashes": n, "clusters": n_clusters, "pairs_inside_clusters": cluster_pairs, "steps": leg_steps,
+               "ms_per_call": dn_ms, "pairs": dn_st["pairs"], "pairs_per_s": dn_st["pairs"] / (dn_ms * 1e-3),
+               "n_hits": dn_st["n_hits"], "n_launches": dn_st["n_launches"], "kernel_ms": dn_st["kernel_ms"],
+               "timing": dn_tm, "suspect_queue_fill": dn_tm["suspects"] / max(dn_tm["suspect_capacity"], 1),
+               "match_groups": dn_groups, "grouped_hashes": dn_members,
+               "sparse_same_windows": {"ms_per_call": sp_ms, "n_hits": sp_st["n_hits"], "match_groups": sp_groups, "timing": sp_tm,
+                                       "note": "the headline's random hashes (planted every 1000th) under the same sorted durations"},
+               "dense_over_sparse": dn_ms / sp_ms, "generation_s": t_gen}
+    finally:
+        eng1.close()
+    return out
 
 
 if __name__ == "__main__":

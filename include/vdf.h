@@ -92,6 +92,19 @@ typedef struct vdf_search_stats {
     uint32_t reserved;
 } vdf_search_stats;
 
+/* Where the time of the last search call on a context went (benchmarks; accumulated over the launches of the call).
+ * Device figures are HIP-event times on the kernels' own stream, host figures wall time. */
+typedef struct vdf_search_timing {
+    float prep_ms;      /* host wall: operand expansion + window / tile kernels, up to the launch of the distance kernel */
+    float stream_ms;    /* device: the distance kernel proper */
+    float resolve_ms;   /* device: exact evaluation of the queued suspect pairs (matrix-core backend; else 0) */
+    float download_ms;  /* host wall: hit list into (row, col) order and into the caller's buffer */
+    float replay_ms;    /* host wall: greedy replay / group assembly (host-level calls only) */
+    float total_ms;     /* host wall of the whole call (host-level calls only) */
+    uint64_t suspects;          /* suspect-queue entries written (matrix-core backend) */
+    uint64_t suspect_capacity;  /* size of that queue in the last launch */
+} vdf_search_timing;
+
 /* ---- context ------------------------------------------------------------------------------ */
 int vdf_ctx_create(int device_id, vdf_ctx **out);
 /* One context over n_devices GPUs of this node: the single search() / search_with_references() call of the crate
@@ -114,6 +127,7 @@ int vdf_ctx_device(const vdf_ctx *ctx);
 /* Hit-buffer capacity (entries) used by the host-level search calls; default 1<<24. */
 int vdf_ctx_set_hit_capacity(vdf_ctx *ctx, uint64_t capacity);
 int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out);
+int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out); /* multi-GPU context: host figures + the slowest device's */
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------------ */
 /* VideoHash::hamming_distance, video_hash.rs:190-192,311-317: all 16 words, padding included. */
@@ -212,6 +226,17 @@ int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const ui
                            size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
                            uint64_t capacity, uint64_t *n_hits, void *stream);
 
+/* Search::sort on the device (search_algorithm.rs:55-61: stable sort_by_key on (duration, src_path)) for a database that is
+ * already resident in HBM - hashes just produced on the GPU need not visit the host between hashing and searching.
+ * d_perm_out[k] = input index of the entry at sorted position k.  Paths stay with the caller: d_path_rank (DEVICE, nullable)
+ * gives each entry the rank of its src_path among the caller's paths in PathBuf's (component-wise) order, equal paths sharing
+ * a rank; NULL = all paths equal.  Entries with equal (duration, rank) keep their input order, as the stable sort does. */
+int vdf_sort_order_device(vdf_ctx *ctx, const uint32_t *d_durations, const uint32_t *d_path_rank, size_t n,
+                          uint32_t *d_perm_out, void *stream);
+/* d_hashes_out[k] = d_hashes[d_perm[k]] (and the durations likewise; both duration pointers may be NULL).  Not in place. */
+int vdf_apply_order_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, const uint32_t *d_perm, size_t n,
+                           uint64_t *d_hashes_out, uint32_t *d_durations_out, void *stream);
+
 uint32_t vdf_row_tile_size(void); /* rows per tile of the default backend (informational: any shard_count works) */
 
 /* Host replay of search_self's consumption order (search_algorithm.rs:131-170) over hits sorted
@@ -222,6 +247,9 @@ uint32_t vdf_row_tile_size(void); /* rows per tile of the default backend (infor
 int vdf_replay_self(size_t n, const vdf_hit *hits, uint64_t n_hits, uint32_t row_begin, uint32_t row_end,
                     uint8_t *matched, vdf_groups *out);
 int vdf_groups_finish_self(vdf_groups *g);
+/* Hits into (row, col) order, in place (host; what the replay and the grouping expect: merging the lists of several
+ * processes, one GPU each, is concatenate + this). */
+int vdf_sort_hits(vdf_hit *hits, uint64_t n_hits);
 /* Groups for search_with_references from hits sorted by (row, col). */
 int vdf_groups_from_ref_hits(const vdf_hit *hits, uint64_t n_hits, vdf_groups *out);
 

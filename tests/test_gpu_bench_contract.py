@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_emits_the_contract_line(backend):
     env = dict(os.environ, VDF_SEARCH_BACKEND=backend)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20", "--ten-million", "200000"], capture_output=True, text=True, timeout=600, env=env)
+                          "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20", "--ten-million", "200000",
+                          "--c5-cands", "4000", "--c5-refs", "400", "--dup-heavy", "40000"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly ONE JSON line on stdout
@@ -39,10 +40,21 @@ def test_bench_emits_the_contract_line(backend):
     assert rf["hits"] == 50000 and 1.0 <= rf["waste_ratio"] < 1.5 and rf["kernel_ms"] > 0
     t = d["ten_million"]  # the north_star's target leg (here at a test size)
     assert t["n_hashes"] == 200000 and t["pairs"] == 200000 * 199999 // 2 and t["match_groups"] >= t["planted_pairs"] - 1
+    assert d["c4_10m_sharded"]["ms_per_step"] == t["ms_per_step"] and d["c4_10m_sharded"]["scaling"] == "strong"
+    c5 = d["c5_end_to_end"]  # BASELINE configs[4] end to end (here at a test size)
+    assert c5["groups"] == c5["planted_references"] == 200 and c5["members"] == 200 and c5["clips_per_s"] > 0
+    assert set(c5["phases_ms"]) == {"hash_ms", "all_gather_ms", "sort_ms", "search_ms", "group_ms"}
+    dh = d["dup_heavy"]  # the duplicate-dense leg
+    assert dh["n_hits"] >= dh["pairs_inside_clusters"] > 0 and dh["match_groups"] == dh["clusters"]
+    assert dh["grouped_hashes"] == 4000 and dh["n_launches"] >= 1 and dh["timing"]["total_ms"] > 0
+    assert dh["sparse_same_windows"]["n_hits"] < dh["n_hits"] and 0 <= dh["suspect_queue_fill"] <= 1.0
+    assert d["n_launches"] == 1 and d["suspects"] >= 0
+    assert d["cpu_baseline"]["all_cores"]["in_reference"] is False and d["cpu_baseline"]["all_cores"]["cores"] >= 1
     if backend == "mfma":
         # frac prices the MFMA work actually executed; the algorithmic figure is reported beside it and is never smaller
         assert r["algorithmic_frac"] >= r["frac"] and "traffic_source" in r
         v = d["valu_backend"]
         assert v["match_groups"] == d["match_groups"] and v["pairs_per_s"] > 0 and 0 < v["valu"]["frac"] < 1.2
+        assert "x_of_hbm_model" in d["hbm_operand_stream_model"] and "frac" not in d["hbm_operand_stream_model"]
     else:
         assert "valu_backend" not in d

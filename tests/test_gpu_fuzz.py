@@ -192,3 +192,122 @@ def test_cropped_hash_fuzz(seed):
         finally:
             eng.close()
         assert np.array_equal(got, want), (mode, h, w, np.nonzero((got != want).any(axis=1))[0].tolist(), crops.tolist())
+
+
+@pytest.mark.parametrize("seed", range(max(12, _SOAK // 10)))
+def test_hash_fuzz_wide_frames(seed):
+    """The wide kernels numerically fuzzed: 1500..4200 columns, 129..2200 rows, through the device entry point with random
+    base alignment and frame / clip strides (packed and aligned, 16-byte-aligned padding, odd padding off a 3..15-byte base):
+    auto dispatch, the whole-line kernel (4), the linear-stream kernel wherever it applies (5: up to 1984 columns) and its
+    K-split form wherever it applies (6: 2048..4096 columns, a multiple of 16) - whole hash words against the oracle."""
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(110_000 + seed)
+    if seed % 3 == 0:
+        w = int(rng.integers(94, 257)) * 16          # multiple of 16: 1504 .. 4096 (stream / K-split eligible)
+    elif seed % 3 == 1:
+        w = int(rng.integers(1500, 4201))            # anything, odd widths included (whole-line kernel; > 4096 too)
+    else:
+        w = int(rng.integers(12, 33)) * 128          # line-aligned pitches 1536 .. 4096
+    h = int(rng.integers(129, 2201)) if seed % 4 else int(rng.choice([1080, 1440, 2160, 1152, 1200]))
+    n, nf = 2, int(rng.choice([16, 17]))
+    frames = rng.integers(0, 256, size=(n, nf, h, w), dtype=np.uint8)
+    if seed % 5 == 0:
+        frames = (frames // 32 * 32 + rng.integers(0, 3, size=(n, nf, 1, 1))).astype(np.uint8)  # banded content
+    want = orc.hash_clips(np.ascontiguousarray(frames[:, :16]))
+    layout = (seed // 3) % 3 if seed < 9 else int(rng.integers(0, 3))  # seeds 0..8: every layout meets every width class
+    if layout == 0:
+        base, pad_f, pad_c = 0, 0, 0
+    elif layout == 1:
+        base, pad_f, pad_c = 16, 16 * int(rng.integers(0, 9)), 16 * int(rng.integers(0, 9))
+        pad_f += (16 - (w * h + pad_f) % 16) % 16  # every frame starts on a 16-byte boundary
+    else:
+        base, pad_f, pad_c = int(rng.integers(3, 16)), int(rng.integers(1, 200)), int(rng.integers(1, 200))
+    fs = w * h + pad_f
+    cs = nf * fs + pad_c
+    buf = np.full(base + (n - 1) * cs + (nf - 1) * fs + w * h, 0xAB, np.uint8)  # ends with the last byte of the last frame
+    for c in range(n):
+        for f in range(nf):
+            o = base + c * cs + f * fs
+            buf[o:o + w * h] = frames[c, f].reshape(-1)
+    d_buf = torch.from_numpy(buf).cuda()
+    for mode in (0, 4, 5, 6):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+        try:
+            d_out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.hash_frames_device(d_buf.data_ptr() + base, n, nf, w, h, d_out.data_ptr(), frame_stride=fs, clip_stride=cs)
+            torch.cuda.synchronize()
+            got = d_out.cpu().numpy().view(np.uint64)
+        except vdf.VdfError as e:
+            assert e.code == -2, (mode, h, w, str(e))  # a forced MFMA mode on tables that need the scalar fallback
+            continue
+        finally:
+            eng.close()
+        assert np.array_equal(got, want), (mode, h, w, layout, base, pad_f, pad_c)
+
+
+_SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
+    ("K-split 2048", 300, 2048, 24, False), ("K-split 3840", 200, 3840, 12, False), ("stream 1024 (re-pitched)", 300, 1024, 32, False),
+    ("stream 422 (shifted)", 240, 422, 40, False), ("stream band 1920", 300, 1920, 24, False), ("stream 480", 270, 480, 40, False),
+    ("whole-line 1536", 200, 1536, 24, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
+    ("cropped stream 854", 480, 854, 24, True), ("cropped stream 480", 270, 480, 40, True), ("cropped whole-line 1280", 360, 1280, 16, True),
+]
+
+
+@pytest.mark.parametrize("name,h,w,n,letterbox", _SOAK_FAMILIES, ids=[f[0] for f in _SOAK_FAMILIES])
+def test_stream_kernels_soak(name, h, w, n, letterbox):
+    """Race hunt, bounded: every kernel family of the hash path is launched >= 20 times on FRESH engines (fresh allocations,
+    cold tables and caches - the persistent kernels' barrier / LDS-DMA bugs of round 2 showed up in about one launch in ten)
+    and every launch must reproduce the oracle's hashes (and the scalar kernel's, VDF_RESIZE_MODE=1)."""
+    import vid_dup_finder_lib_amd as vdf
+
+    def fresh(mode):
+        os.environ["VDF_RESIZE_MODE"] = str(mode)
+        try:
+            return vdf.Engine(0)
+        finally:
+            os.environ.pop("VDF_RESIZE_MODE", None)
+
+    rng = np.random.default_rng(len(name) * 1000 + w)
+    frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
+    if letterbox:
+        for c in range(n):
+            t, b = int(rng.integers(0, h // 5)), int(rng.integers(0, h // 5))
+            l, r = (int(rng.integers(0, w // 6)), int(rng.integers(0, w // 6))) if c % 2 else (0, 0)
+            if t:
+                frames[c, :, :t] = 16
+            if b:
+                frames[c, :, h - b:] = 16
+            if l:
+                frames[c, :, :, :l] = 16
+            if r:
+                frames[c, :, :, w - r:] = 16
+        want = np.stack([orc.hash_clip_letterbox(frames[c])[1] for c in range(n)])
+        call = lambda e: e.hash_frames_letterbox(frames)[0]  # noqa: E731
+    else:
+        want = orc.hash_clips(frames)
+        call = lambda e: e.hash_frames(frames)  # noqa: E731
+    e = fresh(1)
+    try:
+        assert np.array_equal(call(e), want), "scalar kernel vs oracle"
+    finally:
+        e.close()
+    reps = max(10, _SOAK // 4)
+    bad = []
+    for rep in range(reps):
+        e = fresh(0)
+        try:
+            for k in range(2):
+                got = call(e)
+                if not np.array_equal(got, want):
+                    bad.append((rep, k, np.nonzero((got != want).any(axis=1))[0].tolist()))
+        finally:
+            e.close()
+    assert not bad, f"{name}: {len(bad)} bad launches of {2 * reps}: {bad[:5]}"

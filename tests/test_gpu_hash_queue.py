@@ -1,10 +1,25 @@
-"""concurrent per-clip submitters share batched launches and get exactly the batch API's hashes."""
+"""concurrent per-clip submitters share batched launches; every submitted clip's hash (and crop box) is
+compared with the CPU ORACLE's from_frames / Cropdetect::Letterbox + from_frames for that clip (and, as a second check, with
+the batch API of the same library)."""
 import threading
 
 import numpy as np
 import pytest
 
+from oracle import vdf_oracle as orc
+
 pytestmark = pytest.mark.gpu
+
+
+def _oracle_letterbox(frames):
+    """(hashes [n, 16], crops [n, 4]) of the oracle's crop_video_frames(Letterbox) + from_frames, clip by clip."""
+    hs, cs = [], []
+    for clip in frames:
+        rc, h, _, crop = orc.hash_clip_letterbox(clip)
+        assert rc == 0
+        hs.append(h)
+        cs.append(tuple(int(x) for x in crop))
+    return np.stack(hs), cs
 
 
 @pytest.mark.parametrize("letterbox", [False, True])
@@ -18,6 +33,11 @@ def test_many_threads_one_batch(engine, letterbox):
         frames[:, :, :5, :] = 16
         frames[::3, :, :, -7:] = 200
     want = engine.hash_frames_letterbox(frames) if letterbox else (engine.hash_frames(frames), np.zeros((n, 4), np.uint32))
+    if letterbox:
+        o_hash, o_crop = _oracle_letterbox(frames)
+        assert any(c != (0, 0, 0, 0) for c in o_crop)  # the bars are really detected
+    else:
+        o_hash, o_crop = orc.hash_clips(frames), [(0, 0, 0, 0)] * n
     q = HashQueue(engine, w, h, max_batch=32, max_wait_us=20000, letterbox=letterbox)
     got = [None] * n
     errs = []
@@ -36,7 +56,9 @@ def test_many_threads_one_batch(engine, letterbox):
         t.join(timeout=120)
     assert not errs and all(g is not None for g in got)
     for i in range(n):
-        assert np.array_equal(got[i][0], want[0][i])
+        assert np.array_equal(got[i][0], o_hash[i]), i        # the oracle, clip by clip
+        assert got[i][1] == o_crop[i], i
+        assert np.array_equal(got[i][0], want[0][i])          # and the batch API
         assert got[i][1] == tuple(int(x) for x in want[1][i])
     n_batches, n_clips = q.stats()
     assert n_clips == n and n_batches < n  # concurrent callers really were batched together
@@ -49,9 +71,11 @@ def test_single_caller_does_not_wait_for_a_full_batch(engine):
     rng = np.random.default_rng(2)
     frames = rng.integers(0, 256, size=(3, 16, 32, 32), dtype=np.uint8)
     q = HashQueue(engine, 32, 32, max_batch=1024, max_wait_us=1000)
+    o_hash = orc.hash_clips(frames)
     for i in range(3):
         hsh, crop = q.submit(frames[i])
-        assert np.array_equal(hsh, engine.hash_frames(frames[i:i + 1])[0]) and crop == (0, 0, 0, 0)
+        assert np.array_equal(hsh, o_hash[i]) and crop == (0, 0, 0, 0)
+        assert np.array_equal(hsh, engine.hash_frames(frames[i:i + 1])[0])
     assert q.stats() == (3, 3)
     with pytest.raises(ValueError):
         q.submit(frames[0][:, :16, :])
@@ -69,6 +93,7 @@ def test_full_hd_callers_overlap_batches(engine):
     base = rng.integers(0, 256, size=(4, 16, h, w), dtype=np.uint8)
     frames = [np.roll(base[i % 4], shift=i, axis=2) for i in range(n)]  # 64 distinct clips without 2 GB of RNG output
     want = np.concatenate([engine.hash_frames(np.stack(frames[i:i + 8])) for i in range(0, n, 8)])
+    o_hash = np.concatenate([orc.hash_clips(np.stack(frames[i:i + 8])) for i in range(0, n, 8)])  # ~4 s of host work
     q = HashQueue(engine, w, h, max_batch=16, max_wait_us=200000)
     got = [None] * n
     errs = []
@@ -88,6 +113,7 @@ def test_full_hd_callers_overlap_batches(engine):
         t.join(timeout=300)
     assert not errs and all(g is not None for g in got)
     for i in range(n):
+        assert np.array_equal(got[i][0], o_hash[i]), i
         assert np.array_equal(got[i][0], want[i]), i
     n_batches, n_clips = q.stats()
     assert n_clips == n and n_batches <= n // 4
@@ -105,7 +131,8 @@ def test_queue_on_a_multi_gpu_context_spreads_its_slots():
         rng = np.random.default_rng(5)
         n = 40
         frames = rng.integers(0, 256, size=(n, 16, 72, 96), dtype=np.uint8)
-        want = eng.hash_frames(frames)
+        want = orc.hash_clips(frames)
+        assert np.array_equal(eng.hash_frames(frames), want)
         q = HashQueue(eng, 96, 72, max_batch=4, max_wait_us=50000)
         got = [None] * n
         start = threading.Barrier(n)

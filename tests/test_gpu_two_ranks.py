@@ -22,7 +22,8 @@ def _bench(extra, env_extra=None):
     env = dict(os.environ, **(env_extra or {}))
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--hash-clips", "2000",
-                          "--hash-hd-clips", "0", "--ten-million", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs"] + extra,
+                          "--hash-hd-clips", "0", "--c4-hashes", "60000", "--c5-cands", "3000", "--c5-refs", "300", "--dup-heavy", "0",
+                          "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs"] + extra,
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -41,6 +42,22 @@ def test_bench_launches_its_own_ranks():
     assert two["match_groups"] == one["match_groups"] > 0
     assert two["config"]["pairs"] == one["config"]["pairs"] == n2 * (n2 - 1) // 2
     assert two["hash"]["n_gpus"] == 2 and two["value"] > 0
+    # the named legs: BASELINE configs[3] sharded over the ranks (strong scaling) and configs[4] end to end
+    for d in (one, two):
+        c4 = d["c4_10m_sharded"]
+        assert c4["n_hashes"] == 60000 and c4["pairs"] == 60000 * 59999 // 2 and c4["scaling"] == "strong"
+        assert c4["n_gpus"] == d["n_gpus"] and c4["ms_per_step"] > 0 and c4["match_groups"] >= c4["planted_pairs"] - 1
+        c5 = d["c5_end_to_end"]
+        assert c5["n_candidates"] == 3000 and c5["n_references"] == 300 and c5["groups"] == c5["planted_references"] > 0
+        assert c5["members"] == c5["groups"]  # every planted reference finds exactly its source
+        assert set(c5["phases_ms"]) == {"hash_ms", "all_gather_ms", "sort_ms", "search_ms", "group_ms"} and c5["ms_per_step"] > 0
+    assert "ten_million" in one and "ten_million" not in two
+    # after the ranks, the C ABI's single-process form ran in a fresh child and is carried in the same line
+    sp = two["single_process"]
+    assert sp["rccl"] == "ok", sp
+    assert sp["match_groups"] == two["match_groups"] and len(sp["per_device_kernel_ms"]) == 2 and sp["value"] > 0
+    assert sp["devices"] == [0, 0] and "device-to-device" in sp["replication"]  # one GPU here: the device list wraps
+    assert sp["c4_10m_sharded"]["n_hashes"] == 60000 and "single_process" not in one
 
 
 def _worker(rank, world, port, capacity, out_dir):

@@ -57,6 +57,13 @@ class VdfSearchStats(C.Structure):
     ]
 
 
+class VdfSearchTiming(C.Structure):
+    _fields_ = [
+        ("prep_ms", C.c_float), ("stream_ms", C.c_float), ("resolve_ms", C.c_float), ("download_ms", C.c_float),
+        ("replay_ms", C.c_float), ("total_ms", C.c_float), ("suspects", C.c_uint64), ("suspect_capacity", C.c_uint64),
+    ]
+
+
 class VdfCacheSoa(C.Structure):
     _fields_ = [
         ("n_entries", C.c_uint64), ("n_ok", C.c_uint64), ("n_err", C.c_uint64), ("n_key_differs", C.c_uint64),
@@ -84,6 +91,7 @@ SIGNATURES = {
     "vdf_ctx_device": (C.c_int, [_ctx]),
     "vdf_ctx_set_hit_capacity": (C.c_int, [_ctx, C.c_uint64]),
     "vdf_ctx_last_search_stats": (C.c_int, [_ctx, C.POINTER(VdfSearchStats)]),
+    "vdf_ctx_last_search_timing": (C.c_int, [_ctx, C.POINTER(VdfSearchTiming)]),
     "vdf_hamming_u1024": (C.c_uint32, [_u64p, _u64p]),
     "vdf_tolerance_int": (C.c_uint32, [C.c_double]),
     "vdf_count_pairs_self": (C.c_uint64, [_u32p, C.c_size_t]),
@@ -120,10 +128,13 @@ SIGNATURES = {
     "vdf_hash_frames_u8_shards": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]),
+    "vdf_sort_order_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "vdf_apply_order_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdf_row_tile_size": (C.c_uint32, []),
     "vdf_replay_self": (C.c_int, [C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.POINTER(VdfGroups)]),
     "vdf_groups_finish_self": (C.c_int, [C.POINTER(VdfGroups)]),
+    "vdf_sort_hits": (C.c_int, [C.c_void_p, C.c_uint64]),
     "vdf_groups_from_ref_hits": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(VdfGroups)]),
     "vdf_hash_queue_create": (C.c_int, [_ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                         C.POINTER(C.c_void_p)]),

@@ -3,6 +3,7 @@
 // in hamming.hip and dct_hash.hip.  There is deliberately NO CPU fallback for the compute path:
 // without a usable GPU every compute entry point fails with VDF_E_HIP.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,7 @@
 
 namespace {
 thread_local std::string g_create_error;
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }
 
 vdf_ctx::~vdf_ctx()
@@ -31,13 +33,15 @@ vdf_ctx::~vdf_ctx()
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
-                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables};
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &sort_scratch};
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
     pin_small.release();
+    pin_ctrl.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_mid) (void)hipEventDestroy(ev_mid);
     for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -70,6 +74,7 @@ bool is_sorted_u32(const uint32_t *d, size_t n)
 
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
 constexpr size_t kPinSmallBytes = 4u << 20;
+constexpr uint64_t kDeviceSortHits = 1u << 17;  // hit lists from this length on are sorted on the device
 
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
@@ -83,6 +88,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     if (n_rows >= 0xFFFFFFFFull || n_cols >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
     if (shard_count == 0 || shard_index >= shard_count) return fail(ctx, VDF_E_INVAL, "bad shard index/count");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
+    const double t_enter = now_ms();
 
     vdf::SearchLaunch L{};
     const bool mfma = ctx->search_backend == 1;
@@ -198,14 +204,16 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, sizeof init, hipMemcpyHostToDevice, stream));
     VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
                                            row_begin, row_end, shard_index, shard_count, L, stream));
-    uint32_t total_tiles = 0;
-    unsigned long long unsorted = 0;
-    VDF_HIP(ctx, hipMemcpyAsync(&total_tiles, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
+    // workgroup count, sortedness flag and admitted pairs come back through pinned memory (a pageable destination would make
+    // each of the copies a blocking round trip of its own)
+    if (!ctx->pin_ctrl.reserve(256)) return fail(ctx, VDF_E_OOM, "pinned staging");
+    unsigned long long *pre = ctx->pin_ctrl.as<unsigned long long>() + 8;
+    VDF_HIP(ctx, hipMemcpyAsync(pre, L.counters, 64, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipMemcpyAsync(pre + 8, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
                                 hipMemcpyDeviceToHost, stream));
-    VDF_HIP(ctx, hipMemcpyAsync(&unsorted, L.counters + 5, 8, hipMemcpyDeviceToHost, stream));
-    unsigned long long admitted = 0;
-    VDF_HIP(ctx, hipMemcpyAsync(&admitted, L.counters + 2, 8, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
+    const uint32_t total_tiles = *reinterpret_cast<const uint32_t *>(pre + 8);
+    const unsigned long long unsorted = pre[5], admitted = pre[2];
     // the windows are binary searches over the candidate durations (search_algorithm.rs:93-117,173-185 rely on Search::sort)
     if (unsorted) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
@@ -232,29 +240,64 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         L.cand_head = ctx->counters.as<unsigned long long>() + 6;
     }
 
+    ctx->timing.prep_ms += (float)(now_ms() - t_enter);
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    if (gen2) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma2(L, total_tiles, stream));
+    if (gen2) {
+        VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma2(L, total_tiles, stream));
+        VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
+        if (total_tiles) VDF_HIP(ctx, vdf::launch_resolve_candidates(L, stream));
+    }
     else if (mfma) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma(L, total_tiles, stream));
     else VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
+    if (!gen2) VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
     VDF_HIP(ctx, hipEventRecord(ctx->ev1, stream));
-    unsigned long long fin[8];
-    VDF_HIP(ctx, hipMemcpyAsync(fin, ctx->counters.p, sizeof fin, hipMemcpyDeviceToHost, stream));
+    // Counters and - speculatively - the head of the hit list come back behind ONE synchronisation: the list is usually
+    // about as long as the previous call's, and a second round trip costs more than copying a few KB too many.
+    if (!ctx->pin_ctrl.reserve(256)) return fail(ctx, VDF_E_OOM, "pinned staging");
+    unsigned long long *fin = ctx->pin_ctrl.as<unsigned long long>();
+    VDF_HIP(ctx, hipMemcpyAsync(fin, ctx->counters.p, 64, hipMemcpyDeviceToHost, stream));
+    const bool pin_ok = ctx->pin_small.reserve(kPinSmallBytes) && ctx->pin_small.pinned;
+    uint64_t spec = std::min<uint64_t>(capacity, std::max<uint64_t>(ctx->hits_guess + ctx->hits_guess / 4 + 1024, 8192));
+    if (!pin_ok || spec * sizeof(vdf_hit) > kPinSmallBytes) spec = 0;  // long lists go straight to the caller's buffer, once their length is known
+    if (spec) VDF_HIP(ctx, hipMemcpyAsync(ctx->pin_small.p, ctx->hits.p, (size_t)spec * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
-    float ms = 0.f;
+    const double t_synced = now_ms();
+    float ms = 0.f, ms_stream = 0.f;
     VDF_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    VDF_HIP(ctx, hipEventElapsedTime(&ms_stream, ctx->ev0, ctx->ev_mid));
+    ctx->timing.stream_ms += ms_stream;
+    ctx->timing.resolve_ms += ms - ms_stream;
+    if (gen2) { ctx->timing.suspects += fin[6]; ctx->timing.suspect_capacity = L.cand_capacity; }
 
     if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6], L.cand_capacity);  // slots this launch used
     const uint64_t produced = fin[0];
     const uint64_t stored = std::min<uint64_t>(produced, capacity);
+    ctx->hits_guess = stored;
     if (stored) {
-        // small lists come back through pinned memory (a pageable copy of 0.4 MB costs more than the search kernel)
-        const size_t bytes = (size_t)stored * sizeof(vdf_hit);
-        const bool staged = bytes <= kPinSmallBytes && ctx->pin_small.reserve(kPinSmallBytes) && ctx->pin_small.pinned;
-        VDF_HIP(ctx, hipMemcpyAsync(staged ? ctx->pin_small.p : (void *)hits, ctx->hits.p, bytes, hipMemcpyDeviceToHost, stream));
-        VDF_HIP(ctx, hipStreamSynchronize(stream));
-        if (staged) std::memcpy(hits, ctx->pin_small.p, bytes);
-        sort_hits(hits, (size_t)stored);
+        const uint64_t have = std::min(stored, spec);
+        if (have) std::memcpy(hits, ctx->pin_small.p, (size_t)have * sizeof(vdf_hit));
+        if (stored > have) {
+            // Long list (dense near-duplicates): it is put into (row, col) order on the device before it comes down - a host
+            // radix sort of 1e7 pairs costs about as much as the search kernel.
+            const bool dev_sort = stored >= kDeviceSortHits;
+            if (dev_sort) {
+                unsigned row_bits = 1;
+                while (row_bits < 32 && ((uint64_t)row_index_base + n_rows) >> row_bits) row_bits++;
+                VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_hits_scratch_bytes((size_t)stored)));
+                VDF_HIP(ctx, vdf::launch_sort_hits(ctx->hits.as<vdf_hit>(), (size_t)stored, row_bits, ctx->sort_scratch.p,
+                                                   ctx->sort_scratch.cap, stream));
+                VDF_HIP(ctx, hipMemcpyAsync(hits, ctx->hits.p, (size_t)stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
+            } else {
+                VDF_HIP(ctx, hipMemcpyAsync(hits + have, ctx->hits.as<vdf_hit>() + have, (size_t)(stored - have) * sizeof(vdf_hit),
+                                            hipMemcpyDeviceToHost, stream));
+            }
+            VDF_HIP(ctx, hipStreamSynchronize(stream));
+            if (!dev_sort) sort_hits(hits, (size_t)stored);
+        } else {
+            sort_hits(hits, (size_t)stored);
+        }
     }
+    ctx->timing.download_ms += (float)(now_ms() - t_synced);
     *n_hits_out = produced;
     *overflow_row_out = (uint32_t)fin[4];
     ctx->stats.pairs += fin[2];
@@ -658,19 +701,19 @@ int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const
                                      uint64_t capacity, uint64_t *n_hits, hipStream_t s)
 {
     ctx->stats = vdf_search_stats{};
+    ctx->timing = vdf_search_timing{};
     *n_hits = 0;
     if (n_ref == 0 || n_cand == 0) return VDF_OK;
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     // References arrive in the caller's order; tiles want neighbouring rows to share a duration window, so
     // rows are visited through a stable duration-sorted permutation (reported indices stay the caller's).
-    if (!ctx->pin_small.reserve(std::max<size_t>(n_ref * 8, kPinSmallBytes))) return fail(ctx, VDF_E_OOM, "pinned staging");
-    uint32_t *rdur = ctx->pin_small.as<uint32_t>(), *perm = rdur + n_ref;
-    VDF_HIP(ctx, hipMemcpyAsync(rdur, d_ref_durations, n_ref * 4, hipMemcpyDeviceToHost, s));
-    VDF_HIP(ctx, hipStreamSynchronize(s));
-    stable_argsort_u32(rdur, n_ref, perm);
-    int rc = upload(ctx, ctx->perm, perm, n_ref * 4, s);
-    if (rc) return rc;
-    VDF_HIP(ctx, hipStreamSynchronize(s));  // the staging buffer is reused for the hit list below
+    // (stable, on the device: the durations never leave HBM and nothing here waits for the GPU)
+    const size_t sbytes = vdf::sort_order_scratch_bytes((uint32_t)n_ref, false);
+    VDF_HIP(ctx, ctx->sort_scratch.reserve(sbytes));
+    VDF_HIP(ctx, ctx->perm.reserve(std::max<size_t>(n_ref * 4, 16)));
+    VDF_HIP(ctx, vdf::launch_sort_order(d_ref_durations, nullptr, (uint32_t)n_ref, ctx->perm.as<uint32_t>(), ctx->sort_scratch.p,
+                                        ctx->sort_scratch.cap, s));
+    int rc = VDF_OK;
     // Every hit is part of the output here (consume = false).  The hit buffer is the caller's to size (VDF_E_OVERFLOW with the
     // required size); the suspect queue of the matrix-core backend is the library's: if a launch dropped suspects, run it
     // again with a larger queue.
@@ -707,7 +750,8 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess;
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
+              hipEventCreate(&ctx->ev_mid) == hipSuccess;
     for (int i = 0; ok && i < 2; i++)
         ok = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) == hipSuccess;
@@ -773,7 +817,9 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     uint32_t row_begin = 0;
     uint64_t span = n;  // rows per launch; shrinks after an overflow, grows back afterwards
     ctx->stats = vdf_search_stats{};
-    for (int k = 0; k < G; k++) device_ctx(ctx, k)->stats = vdf_search_stats{};
+    const double t_call = now_ms();
+    double replay_ms = 0.0;
+    for (int k = 0; k < G; k++) { device_ctx(ctx, k)->stats = vdf_search_stats{}; device_ctx(ctx, k)->timing = vdf_search_timing{}; }
     while (row_begin < n) {
         const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
         int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
@@ -806,7 +852,9 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
             nh = merged.size();
         }
         const uint64_t old_members = out->n_groups ? out->offsets[out->n_groups] : 0;
+        const double t_replay = now_ms();
         rc = vdf_replay_self(n, hp, nh, row_begin, complete_end, matched.data(), out);
+        replay_ms += now_ms() - t_replay;
         if (rc) { vdf_groups_free(out); return fail(ctx, rc, "replay failed"); }
         if (overflow_row == 0xFFFFFFFFu) {
             row_begin = row_end;
@@ -860,7 +908,19 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
         agg.early_exit_bits = st.early_exit_bits;
     }
     ctx->stats = agg;
-    return vdf_groups_finish_self(out);
+    const double t_fin = now_ms();
+    const int rc_fin = vdf_groups_finish_self(out);
+    vdf_search_timing tm{};
+    for (int k = 0; k < G; k++) {  // device figures: the slowest device's
+        const vdf_search_timing &q = device_ctx(ctx, k)->timing;
+        tm.prep_ms = std::max(tm.prep_ms, q.prep_ms); tm.stream_ms = std::max(tm.stream_ms, q.stream_ms);
+        tm.resolve_ms = std::max(tm.resolve_ms, q.resolve_ms); tm.download_ms = std::max(tm.download_ms, q.download_ms);
+        tm.suspects += q.suspects; tm.suspect_capacity = std::max(tm.suspect_capacity, q.suspect_capacity);
+    }
+    tm.replay_ms = (float)(replay_ms + now_ms() - t_fin);
+    tm.total_ms = (float)(now_ms() - t_call);
+    ctx->timing = tm;
+    return rc_fin;
 }
 
 // search_with_references() with the sorted candidates resident on every device (up_hashes / up_dur) and device k holding
@@ -871,9 +931,11 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
 {
     const int G = device_count(ctx);
     const uint64_t capacity0 = ctx->hit_capacity;
+    const double t_call = now_ms();
     int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
         d->r_n_hits = 0;
         d->stats = vdf_search_stats{};
+        d->timing = vdf_search_timing{};
         if (ref_cnt[(size_t)k] == 0) return (int)VDF_OK;
         uint64_t capacity = capacity0;
         for (int attempt = 0; attempt < 6; attempt++) {
@@ -900,13 +962,29 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         agg.early_exit_bits = st.early_exit_bits;
     }
     ctx->stats = agg;
-    if (G == 1) return vdf_groups_from_ref_hits(device_ctx(ctx, 0)->host_hits.data(), device_ctx(ctx, 0)->r_n_hits, out);
-    std::vector<vdf_hit> all;
+    vdf_search_timing tm{};
     for (int k = 0; k < G; k++) {
-        const vdf_ctx *d = device_ctx(ctx, k);
-        all.insert(all.end(), d->host_hits.data(), d->host_hits.data() + d->r_n_hits);
+        const vdf_search_timing &q = device_ctx(ctx, k)->timing;
+        tm.prep_ms = std::max(tm.prep_ms, q.prep_ms); tm.stream_ms = std::max(tm.stream_ms, q.stream_ms);
+        tm.resolve_ms = std::max(tm.resolve_ms, q.resolve_ms); tm.download_ms = std::max(tm.download_ms, q.download_ms);
+        tm.suspects += q.suspects; tm.suspect_capacity = std::max(tm.suspect_capacity, q.suspect_capacity);
     }
-    return vdf_groups_from_ref_hits(all.data(), all.size(), out);
+    const double t_group = now_ms();
+    int rcg;
+    if (G == 1) {
+        rcg = vdf_groups_from_ref_hits(device_ctx(ctx, 0)->host_hits.data(), device_ctx(ctx, 0)->r_n_hits, out);
+    } else {
+        std::vector<vdf_hit> all;
+        for (int k = 0; k < G; k++) {
+            const vdf_ctx *d = device_ctx(ctx, k);
+            all.insert(all.end(), d->host_hits.data(), d->host_hits.data() + d->r_n_hits);
+        }
+        rcg = vdf_groups_from_ref_hits(all.data(), all.size(), out);
+    }
+    tm.replay_ms = (float)(now_ms() - t_group);
+    tm.total_ms = (float)(now_ms() - t_call);
+    ctx->timing = tm;
+    return rcg;
 }
 
 }  // namespace vdf_impl
@@ -946,6 +1024,13 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
 {
     if (!ctx || !out) return VDF_E_INVAL;
     *out = ctx->stats;
+    return VDF_OK;
+}
+
+int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out)
+{
+    if (!ctx || !out) return VDF_E_INVAL;
+    *out = ctx->timing;
     return VDF_OK;
 }
 
@@ -1103,6 +1188,7 @@ int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_
     std::lock_guard<std::mutex> lk(ctx->mu);
     VDF_SINGLE_DEVICE_ONLY(ctx);
     ctx->stats = vdf_search_stats{};
+    ctx->timing = vdf_search_timing{};
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return search_core(ctx, 0, d_hashes, d_durations, n, d_hashes, d_durations, nullptr, n, tol_int, shard_index,
                        shard_count, row_begin, row_end, d_matched, 0, hits, capacity, n_hits, overflow_row, s);
@@ -1119,6 +1205,38 @@ int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const ui
     return search_refs_device_locked(ctx, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
                                      n_ref, tol_int, ref_index_base, hits, capacity, n_hits,
                                      stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int vdf_sort_order_device(vdf_ctx *ctx, const uint32_t *d_durations, const uint32_t *d_path_rank, size_t n, uint32_t *d_perm_out,
+                          void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
+    if (n == 0) return VDF_OK;
+    if (!d_durations || !d_perm_out) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_order_scratch_bytes((uint32_t)n, d_path_rank != nullptr)));
+    VDF_HIP(ctx, vdf::launch_sort_order(d_durations, d_path_rank, (uint32_t)n, d_perm_out, ctx->sort_scratch.p, ctx->sort_scratch.cap,
+                                        stream ? (hipStream_t)stream : ctx->stream));
+    return VDF_OK;
+}
+
+int vdf_apply_order_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, const uint32_t *d_perm, size_t n,
+                           uint64_t *d_hashes_out, uint32_t *d_durations_out, void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
+    if (n == 0) return VDF_OK;
+    if (!d_hashes || !d_perm || !d_hashes_out || (d_durations_out && !d_durations)) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    if (d_hashes == d_hashes_out || (d_durations && d_durations == d_durations_out)) return fail(ctx, VDF_E_INVAL, "the gather is not in place");
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, vdf::launch_gather_hashes(d_hashes, d_durations, d_perm, (uint32_t)n, d_hashes_out, d_durations_out,
+                                           stream ? (hipStream_t)stream : ctx->stream));
+    return VDF_OK;
 }
 
 int vdf_search_self(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, size_t n, uint32_t tol_int,

@@ -65,6 +65,29 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// Append the hits of the calling wave (lanes with `hit`) behind ONE atomic on the shared counter; must be reached by all
+// active lanes together.  With dense near-duplicates (1e7 hits per search) per-hit atomics on one address serialise in L2.
+__device__ __forceinline__ void wave_append_hits(bool hit, uint32_t row, uint32_t col, vdf_hit *__restrict__ hits,
+                                                 unsigned long long capacity, unsigned long long *__restrict__ counters,
+                                                 uint32_t *__restrict__ overflow_row)
+{
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+    if (bal == 0ull) return;
+    const int leader = __builtin_ctzll(bal);
+    unsigned long long base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(bal));
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, leader, 64);
+    if (hit) {
+        const unsigned long long at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (at < capacity) {
+            vdf_hit hp; hp.row = row; hp.col = col;
+            hits[at] = hp;
+        } else {
+            atomicMin(overflow_row, row);
+        }
+    }
+}
+
 // One workgroup per row tile: per-row candidate windows, per-tile candidate range and chunk count.
 //   mode 0 (search_self): row i -> [i + 1, first j with dur[j] > (f64(dur[i]) * 1.1) as u32)
 //                         (search_algorithm.rs:93-117: rhs pointer; candidates are the later entries)
@@ -299,17 +322,8 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
             if (matched) col_ok = ((((const_u32_ptr)(uintptr_t)matched)[c >> 5] >> (c & 31)) & 1u) == 0u;
             if (col_ok) {
 #pragma unroll
-                for (int k = 0; k < R; k++) {
-                    if (d[k] <= tol && c >= rlo[k] && c < rhi[k]) {
-                        const unsigned long long idx = atomicAdd(&counters[0], 1ull);
-                        if (idx < capacity) {
-                            vdf_hit hpair; hpair.row = rid[k]; hpair.col = c;
-                            hits[idx] = hpair;
-                        } else {
-                            atomicMin(overflow_row, rid[k]);
-                        }
-                    }
-                }
+                for (int k = 0; k < R; k++)
+                    wave_append_hits(d[k] <= tol && c >= rlo[k] && c < rhi[k], rid[k], c, hits, capacity, counters, overflow_row);
             }
         }
     }
@@ -685,41 +699,49 @@ __global__ __launch_bounds__(256) void resolve_candidates_kernel(
     uint32_t *__restrict__ overflow_row)
 {
     const uint32_t n = (uint32_t)min(*cand_head, (unsigned long long)cand_capacity);
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        const CandEntry ce = cand[e];
-        if (ce.row_base == 0xFFFFFFFFu || ce.col >= n_cols) continue;
-        if (matched && ((matched[ce.col >> 5] >> (ce.col & 31)) & 1u)) continue;
-        const uint4 *cp = reinterpret_cast<const uint4 *>(col_hashes + (size_t)ce.col * 32);
-        uint4 cw[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) cw[q] = cp[q];
+    const uint32_t lane = threadIdx.x & 63;
+    // The loops are wave-uniform so that the hits of a round are appended with ONE atomic per wave: with dense
+    // near-duplicates (1e7 hits per search) a per-hit atomicAdd on the one counter serialises in L2.
+    for (uint32_t e0 = blockIdx.x * 256 + (threadIdx.x & ~63u); e0 < n; e0 += gridDim.x * 256) {
+        const uint32_t e = e0 + lane;
+        CandEntry ce;
+        ce.row_base = 0xFFFFFFFFu; ce.col = 0; ce.mask = 0; ce.pad = 0;
+        if (e < n) ce = cand[e];
         uint32_t m = ce.mask;
-        while (m) {
-            const uint32_t r = (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            const uint32_t p = ce.row_base + (r & 3) + 8 * (r >> 2);
-            if (p >= n_rows) continue;
-            const uint32_t lo = row_lo[p], hi = row_hi[p];
-            if (ce.col < lo || ce.col >= hi) continue;
-            const uint32_t src = row_perm ? row_perm[p] : p;
-            if (self_mode && matched && ((matched[src >> 5] >> (src & 31)) & 1u)) continue;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(row_hashes + (size_t)src * 32);
-            uint32_t d = 0;
+        if (ce.row_base == 0xFFFFFFFFu || ce.col >= n_cols) m = 0;
+        if (m && matched && ((matched[ce.col >> 5] >> (ce.col & 31)) & 1u)) m = 0;
+        uint4 cw[8];
+        if (m) {
+            const uint4 *cp = reinterpret_cast<const uint4 *>(col_hashes + (size_t)ce.col * 32);
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint4 v = rp[q];
-                d += __builtin_popcount(v.x ^ cw[q].x) + __builtin_popcount(v.y ^ cw[q].y) +
-                     __builtin_popcount(v.z ^ cw[q].z) + __builtin_popcount(v.w ^ cw[q].w);
-            }
-            if (d <= tol) {
-                const unsigned long long at = atomicAdd(&counters[0], 1ull);
-                if (at < capacity) {
-                    vdf_hit hp; hp.row = row_index_base + src; hp.col = ce.col;
-                    hits[at] = hp;
-                } else {
-                    atomicMin(overflow_row, row_index_base + src);
+            for (int q = 0; q < 8; q++) cw[q] = cp[q];
+        }
+        while (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+            bool hit = false;
+            uint32_t src = 0;
+            if (m) {
+                const uint32_t r = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t p = ce.row_base + (r & 3) + 8 * (r >> 2);
+                if (p < n_rows) {
+                    const uint32_t lo = row_lo[p], hi = row_hi[p];
+                    if (ce.col >= lo && ce.col < hi) {
+                        src = row_perm ? row_perm[p] : p;
+                        if (!(self_mode && matched && ((matched[src >> 5] >> (src & 31)) & 1u))) {
+                            const uint4 *rp = reinterpret_cast<const uint4 *>(row_hashes + (size_t)src * 32);
+                            uint32_t d = 0;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint4 v = rp[q];
+                                d += __builtin_popcount(v.x ^ cw[q].x) + __builtin_popcount(v.y ^ cw[q].y) +
+                                     __builtin_popcount(v.z ^ cw[q].z) + __builtin_popcount(v.w ^ cw[q].w);
+                            }
+                            hit = d <= tol;
+                        }
+                    }
                 }
             }
+            wave_append_hits(hit, row_index_base + src, ce.col, hits, capacity, counters, overflow_row);
         }
     }
 }
@@ -1139,7 +1161,12 @@ hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tile
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    // second pass: exact evaluation of the suspect pairs
+    return hipSuccess;
+}
+
+// second pass of the second-generation kernel: exact evaluation of the suspect pairs
+hipError_t launch_resolve_candidates(const SearchLaunch &L, hipStream_t stream)
+{
     hipLaunchKernelGGL(resolve_candidates_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<const CandEntry *>(L.cand),
                        L.cand_head, L.cand_capacity, L.row_hashes, L.row_perm, L.n_rows, L.row_index_base, L.col_hashes, L.n_cols,
                        L.row_lo, L.row_hi, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters, L.overflow_row);

@@ -47,3 +47,10 @@ void stable_argsort_u32(const uint32_t *keys, size_t n, uint32_t *perm)
 }
 
 }  // namespace vdf_impl
+
+extern "C" int vdf_sort_hits(vdf_hit *hits, uint64_t n_hits)
+{
+    if (n_hits && !hits) return VDF_E_INVAL;
+    vdf_impl::sort_hits(hits, (size_t)n_hits);
+    return VDF_OK;
+}

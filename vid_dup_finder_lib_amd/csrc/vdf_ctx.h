@@ -84,14 +84,19 @@ struct vdf_ctx {
     std::string err;
     uint64_t hit_capacity = 1ull << 24;
     vdf_search_stats stats{};
+    vdf_search_timing timing{};
+    hipEvent_t ev_mid = nullptr;  // between the distance kernel and the suspect resolution
     uint32_t tile_rows = 256 * vdf::kDefaultRowsPerLane;
     uint32_t chunk_cols = vdf::kDefaultChunkCols;
     // search scratch
     DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
     DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
+    DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side Search::sort
     // hash scratch
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables;
     PinBuf pin[2], pin_out[2];
+    PinBuf pin_ctrl;   // search: the counters of a launch (pageable destinations make hipMemcpyAsync synchronous)
+    uint64_t hits_guess = 0;  // hits of the previous launch: how much of the list is fetched together with the counters
     PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)

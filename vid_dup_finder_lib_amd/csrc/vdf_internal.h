@@ -74,7 +74,8 @@ constexpr uint32_t kMfmaRowPad = 32 * VDF_ROW_TILES * VDF_MFMA_WAVES, kMfmaColPa
 hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, int mode01, uint32_t k_steps,
                              float *pop3, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
-hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream + cleanup; tile_rows 512 or 256
+hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream; tile_rows 512 or 256
+hipError_t launch_resolve_candidates(const SearchLaunch &L, hipStream_t stream);  // its second pass: suspects evaluated exactly
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
                                      const unsigned long long *members, const uint32_t *ref_hashes,
                                      const long long *ref_index, uint32_t n_groups, uint32_t *out, hipStream_t stream);
@@ -149,6 +150,17 @@ hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t fram
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);
+// ---- Search::sort on the device (sort_order.hip) ----------------------------------------------------------------
+// perm_out = the stable order by (duration, path rank); rank nullable (all paths equal).  scratch from sort_order_scratch_bytes.
+size_t sort_order_scratch_bytes(uint32_t n, bool with_rank);
+hipError_t launch_sort_order(const uint32_t *dur, const uint32_t *rank, uint32_t n, uint32_t *perm_out, void *scratch,
+                             size_t scratch_bytes, hipStream_t stream);
+// hashes_out[k] = hashes[perm[k]], dur_out[k] = dur[perm[k]] (dur / dur_out nullable)
+// hit list into (row, col) order, in place on the device; rows < 2^row_bits
+size_t sort_hits_scratch_bytes(size_t n);
+hipError_t launch_sort_hits(vdf_hit *hits, size_t n, unsigned row_bits, void *scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_gather_hashes(const uint64_t *hashes, const uint32_t *dur, const uint32_t *perm, uint32_t n, uint64_t *hashes_out,
+                                uint32_t *dur_out, hipStream_t stream);
 hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream);
 

@@ -66,19 +66,31 @@ def all_gather_database(local_words: torch.Tensor, local_dur: torch.Tensor, grou
 
 
 def _gather_hits(hits: np.ndarray, group=None) -> Optional[np.ndarray]:
-    """Variable-length gather of [k, 2] uint32 hit lists to rank 0 (merged and sorted by (row, col))."""
+    """Variable-length gather of [k, 2] uint32 hit lists to rank 0 (merged and sorted by (row, col)): one all-gather of the
+    lengths, one all_gather_into_tensor of the lists padded to the longest - plain tensors on the collective's device (HBM
+    for RCCL), nothing is pickled."""
     rank, world = _world(group)
     if world == 1:
         return hits
-    bufs = [None] * world if rank == 0 else None
-    dist.gather_object(np.ascontiguousarray(hits), bufs, dst=0, group=group)
+    cdev = _coll_device(group)
+    hits = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    n_local = torch.tensor([hits.shape[0]], dtype=torch.int64, device=cdev)
+    sizes = torch.zeros(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(sizes, n_local, group=group)
+    sizes = [int(x) for x in sizes.tolist()]
+    m = max(sizes)
+    if m == 0:
+        return np.zeros((0, 2), np.uint32) if rank == 0 else None
+    pad = torch.zeros((m, 2), dtype=torch.int32, device=cdev)
+    if hits.shape[0]:
+        pad[: hits.shape[0]] = torch.from_numpy(hits.view(np.int32)).to(cdev)
+    out = torch.empty((world * m, 2), dtype=torch.int32, device=cdev)
+    dist.all_gather_into_tensor(out, pad, group=group)
     if rank != 0:
         return None
-    allh = np.concatenate([b.reshape(-1, 2) for b in bufs]) if bufs else hits
-    if len(allh):
-        order = np.lexsort((allh[:, 1], allh[:, 0]))
-        allh = allh[order]
-    return allh
+    allh = out.cpu().numpy().view(np.uint32).reshape(world, m, 2)
+    allh = np.concatenate([allh[r, : sizes[r]] for r in range(world)])
+    return _eng.sort_hits(allh)  # every rank's list is sorted already and the ranks own disjoint rows: C++ radix sort
 
 
 def _stream_for(t: torch.Tensor, stream: Optional[int]) -> int:
@@ -193,41 +205,85 @@ def search_refs_sharded(engine, d_cand_words: torch.Tensor, d_cand_dur: torch.Te
 
 
 def hash_and_search_refs(engine, cand_frames: torch.Tensor, cand_dur: torch.Tensor, ref_frames: torch.Tensor,
-                         ref_dur: torch.Tensor, tol_int: int, group=None, stream: Optional[int] = None):
+                         ref_dur: torch.Tensor, tol_int: int, group=None, stream: Optional[int] = None, as_lists: bool = True,
+                         timings: Optional[dict] = None):
     """BASELINE configs[4] end to end: every rank hashes ITS candidate clips and ITS reference clips (uint8 device
-    tensors [n, >=16, H, W]; no communication), the candidate hashes are replicated with one all-gather and sorted by
-    duration (stable; paths, if any, stay with the caller), references keep rank order, then
-    search_with_references runs sharded.  Rank 0 returns (groups, order): groups = [(global reference index,
-    [positions in the sorted candidate order])], order[k] = global candidate index (rank-major) at sorted position k."""
+    tensors [n, >=16, H, W]; no communication), the candidate hashes are replicated with one all-gather and put into
+    Search::sort order ON THE DEVICE (vdf_sort_order_device: stable by duration; paths, if any, stay with the caller),
+    references keep rank order, then search_with_references runs sharded.  Nothing but the hit list leaves HBM.
+    Rank 0 returns (groups, order): order[k] = global candidate index (rank-major) at sorted position k; groups =
+    [(global reference index, [positions in the sorted candidate order])] or, with as_lists=False, the CSR arrays
+    (offsets, members, ref_index) of vdf_groups.  timings (optional dict) receives wall ms per phase, each closed by a device
+    synchronisation."""
+    import time
+
     rank, world = _world(group)
     dev = cand_frames.device
     stream = _stream_for(cand_frames, stream)
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
+    def fence():
+        """stream handle 0 = the library's own stream, which torch's streams are not ordered with: drain the device
+        whenever work changes hands between torch and the library."""
+        if not stream and dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    cd32 = cand_dur.to(torch.int32).contiguous()
+    rd32 = ref_dur.to(torch.int32).contiguous()
 
     def _hash(frames):
         n, nf, h, w = frames.shape
-        out = torch.zeros((n, HASH_WORDS), dtype=torch.int64, device=dev)
+        out = torch.empty((n, HASH_WORDS), dtype=torch.int64, device=dev)
         if n:
-            _before_engine_call(frames, stream)
+            fence()
             engine.hash_frames_device(frames.data_ptr(), n, nf, w, h, out.data_ptr(), stream=stream)
         return out
 
-    cw = _hash(cand_frames.contiguous())
-    rw = _hash(ref_frames.contiguous())
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    full_w, full_d = all_gather_database(cw, cand_dur.to(torch.int32), group)
-    order = torch.sort(full_d, stable=True).indices  # Search::sort with equal paths: stable by duration
-    sorted_w = full_w.index_select(0, order).contiguous()
-    sorted_d = full_d.index_select(0, order).contiguous()
+    cw = _hash(cand_frames if cand_frames.is_contiguous() else cand_frames.contiguous())
+    rw = _hash(ref_frames if ref_frames.is_contiguous() else ref_frames.contiguous())
+    lap("hash_ms")
+    if world > 1:
+        fence()
+    full_w, full_d = all_gather_database(cw, cd32, group)
+    lap("all_gather_ms")
+    n = int(full_d.shape[0])
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    sorted_w = torch.empty_like(full_w)
+    sorted_d = torch.empty_like(full_d)
+    if n:
+        fence()
+        engine.sort_order_device(full_d.data_ptr(), n, order.data_ptr(), stream=stream)
+        engine.apply_order_device(full_w.data_ptr(), full_d.data_ptr(), order.data_ptr(), n, sorted_w.data_ptr(),
+                                  sorted_d.data_ptr(), stream=stream)
+    lap("sort_ms")
     # global index of this rank's first reference
-    n_ref = torch.tensor([rw.shape[0]], dtype=torch.int64, device=_coll_device(group) if world > 1 else dev)
     base = 0
     if world > 1:
-        counts = [torch.zeros_like(n_ref) for _ in range(world)]
-        dist.all_gather(counts, n_ref, group=group)
-        base = int(sum(int(c.item()) for c in counts[:rank]))
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    groups = search_refs_sharded(engine, sorted_w, sorted_d, rw, ref_dur.to(torch.int32).contiguous(), base, tol_int,
-                                 group=group, stream=stream)
-    return (groups, order.cpu().numpy()) if rank == 0 else (None, None)
+        cdev = _coll_device(group)
+        counts = torch.zeros(world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(counts, torch.tensor([rw.shape[0]], dtype=torch.int64, device=cdev), group=group)
+        base = int(counts[:rank].sum().item())
+    n_ref = int(ref_dur.shape[0])
+    if n_ref and n:
+        hits, _ = engine.search_refs_device(sorted_w.data_ptr(), sorted_d.data_ptr(), n, rw.data_ptr(), rd32.data_ptr(), n_ref, tol_int, ref_index_base=base,
+                                            stream=stream)
+    else:
+        hits = np.zeros((0, 2), np.uint32)
+    lap("search_ms")
+    merged = _gather_hits(hits, group)
+    if rank != 0:
+        lap("group_ms")
+        return None, None
+    groups = _eng.groups_from_ref_hits(merged) if as_lists else _eng.ref_groups_csr(merged)
+    fence()
+    order_h = order.cpu().numpy().view(np.uint32)
+    lap("group_ms")
+    return groups, order_h

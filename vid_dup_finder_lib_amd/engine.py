@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _capi
-from ._capi import HASH_WORDS, VdfError, VdfGroups, VdfHit, VdfSearchStats
+from ._capi import HASH_WORDS, VdfError, VdfGroups, VdfHit, VdfSearchStats, VdfSearchTiming
 
 UINT32_MAX = 0xFFFFFFFF
 
@@ -102,6 +102,12 @@ class Engine:
         s = VdfSearchStats()
         self._check(self.lib.vdf_ctx_last_search_stats(self.ctx, C.byref(s)))
         return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
+
+    def last_timing(self) -> dict:
+        """Where the time of the last search call went (vdf_search_timing: ms per phase, suspect-queue fill)."""
+        t = VdfSearchTiming()
+        self._check(self.lib.vdf_ctx_last_search_timing(self.ctx, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in VdfSearchTiming._fields_}
 
     def device_stats(self, slot: int) -> dict:
         s = VdfSearchStats()
@@ -259,6 +265,15 @@ class Engine:
                                                      len(rh) if rh is not None else 0, C.byref(g), out.ctypes.data))
         return out
 
+    def sort_order_device(self, d_durations: int, n: int, d_perm_out: int, d_path_rank: int = 0, stream: int = 0):
+        """Search::sort's permutation (stable by (duration, path rank)) of n device-resident entries into d_perm_out (u32)."""
+        self._check(self.lib.vdf_sort_order_device(self.ctx, d_durations, d_path_rank or None, n, d_perm_out, stream or None))
+
+    def apply_order_device(self, d_hashes: int, d_durations: int, d_perm: int, n: int, d_hashes_out: int,
+                           d_durations_out: int = 0, stream: int = 0):
+        self._check(self.lib.vdf_apply_order_device(self.ctx, d_hashes, d_durations or None, d_perm, n, d_hashes_out,
+                                                    d_durations_out or None, stream or None))
+
     def search_self_device(self, d_hashes: int, d_durations: int, n: int, tol_int: int, shard_index: int = 0,
                            shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
                            capacity: int = 1 << 22, stream: int = 0):
@@ -338,6 +353,31 @@ def finish_self(groups: VdfGroups) -> List[List[int]]:
         return [m for _, m in _groups_to_lists(groups)]
     finally:
         lib.vdf_groups_free(C.byref(groups))
+
+
+def sort_hits(hits: np.ndarray) -> np.ndarray:
+    """[k, 2] uint32 hits into (row, col) order (C++ radix sort; np.lexsort needs seconds for 1e7 hits)."""
+    hits = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    if not hits.flags.writeable:
+        hits = hits.copy()
+    rc = _capi.load().vdf_sort_hits(hits.ctypes.data, len(hits))
+    if rc:
+        raise VdfError(rc, "vdf_sort_hits failed")
+    return hits
+
+
+def ref_groups_csr(hits: np.ndarray):
+    """search_with_references groups as arrays (offsets u64[g + 1], members u64[m], ref_index i64[g]) from sorted hits."""
+    lib = _capi.load()
+    hits = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    g = VdfGroups()
+    rc = lib.vdf_groups_from_ref_hits(hits.ctypes.data, len(hits), C.byref(g))
+    if rc:
+        raise VdfError(rc, "vdf_groups_from_ref_hits failed")
+    try:
+        return groups_to_arrays(g)
+    finally:
+        lib.vdf_groups_free(C.byref(g))
 
 
 def groups_from_ref_hits(hits: np.ndarray) -> List[Tuple[int, List[int]]]:
