@@ -129,14 +129,19 @@ def cpu_baseline(words, tol_int, target_seconds=12.0):
     out = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
            "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    rows_per = 256
-    n_cols = int(min(len(words), 200_000))
-    n_rows = int(min(n_cols, max(cores * rows_per, rate * 4.0 * cores / n_cols // rows_per * rows_per)))  # ~4 s
+    rows_per = 64
+    n_cols = int(min(len(words), 100_000))
     cw, cd = words[:n_cols], np.zeros(n_cols, np.uint32)
-    chunks = [(a, min(a + rows_per, n_rows)) for a in range(0, n_rows, rows_per)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL
-        list(ex.map(lambda ab: orc.search_refs_sorted(cw, cd, cw[ab[0]:ab[1]], cd[ab[0]:ab[1]], tol_int), chunks))
+
+    def block(a):
+        rows = np.arange(a, a + rows_per) % n_cols
+        orc.search_refs_sorted(cw, cd, cw[rows], cd[rows], tol_int)
+
+    n_rows, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL; rounds of one 64-row block per thread for ~5 s
+        while time.perf_counter() - t0 < 5.0:
+            list(ex.map(block, range(n_rows, n_rows + cores * rows_per, rows_per)))
+            n_rows += cores * rows_per
     dta = time.perf_counter() - t0
     out["all_cores"] = {"value": n_rows * n_cols / dta, "unit": "pairs/s", "cores": cores, "in_reference": False,
                         "sample": f"oracle search_one loop, {n_rows} target rows x {n_cols} candidates over a {cores}-thread pool "
@@ -923,12 +928,12 @@ def leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, sparse_words, leg_
             wall, tms, sts, ng = [], [], [], 0
             for _ in range(reps):
                 t0 = time.perf_counter()
-                groups = eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int)
+                offsets, mem = eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int, as_arrays=True)
                 wall.append((time.perf_counter() - t0) * 1e3)
                 tms.append(eng1.last_timing())
                 sts.append(eng1.last_stats())
-                ng = len(groups)
-                members = sum(len(g) for g in groups)
+                ng = len(offsets) - 1
+                members = len(mem)
             tm = {k: float(np.mean([t[k] for t in tms])) for k in tms[0]}
             return float(np.mean(wall)), tm, sts[-1], ng, members
 

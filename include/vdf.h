@@ -103,6 +103,8 @@ typedef struct vdf_search_timing {
     float total_ms;     /* host wall of the whole call (host-level calls only) */
     uint64_t suspects;          /* suspect-queue entries written (matrix-core backend) */
     uint64_t suspect_capacity;  /* size of that queue in the last launch */
+    uint64_t hits_filtered;     /* thresholded pairs dropped on the device because their row can never become a target of the
+                                   greedy replay (search() on one device; they are counted in vdf_search_stats.n_hits) */
 } vdf_search_timing;
 
 /* ---- context ------------------------------------------------------------------------------ */

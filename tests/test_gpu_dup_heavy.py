@@ -24,7 +24,58 @@ def test_dup_heavy_generator_prefix_matches_the_oracle(engine):
     assert got == want
     assert len(got) == n_clusters and sum(len(g) for g in got) == 5000
     st = engine.last_stats()
-    assert st["n_hits"] >= cluster_pairs  # the device emits the whole thresholded adjacency, the replay consumes it
+    assert st["n_hits"] >= cluster_pairs  # the device evaluates the whole thresholded adjacency ...
+    tm = engine.last_timing()
+    # ... and, on one device, drops the pairs of rows that can never become targets of the greedy replay before they are
+    # sorted, downloaded and replayed: a cluster of s mutual duplicates sends down s - 1 pairs, not s (s - 1) / 2
+    assert 0 < st["n_hits"] - tm["hits_filtered"] < 3 * 5000
+
+
+def test_replay_filter_never_changes_the_groups(monkeypatch):
+    """The device-side filter of replay-irrelevant hits against the unfiltered path and the oracle, on data built to stress
+    its argument: chains (a ~ b ~ c with a !~ c: b is consumed by a, so c must stay a target), clusters whose smallest member
+    is consumed by an EARLIER unrelated target, duration windows that cut clusters, all-identical runs."""
+    import vid_dup_finder_lib_amd as vdf
+    import hashgen as hg
+
+    rng = np.random.default_rng(11)
+    n = 24_000
+    w = hg.random_hashes(rng, n)
+    d = np.sort(rng.integers(100, 130, size=n).astype(np.uint32))
+
+    def near(src, k):
+        bits = np.unpackbits(w[src].view(np.uint8), bitorder="little")
+        bits[rng.choice(1024, size=k, replace=False)] ^= 1
+        return np.packbits(bits, bitorder="little").view(np.uint64)
+
+    for c in range(300):  # chains: each link 200 bits from the previous one, so links two apart are ~360 > 350 apart
+        at = np.sort(rng.choice(n, size=int(rng.integers(3, 40)), replace=False))
+        for a, b in zip(at[:-1], at[1:]):
+            w[b] = near(a, 200)
+    for c in range(60):  # dense balls (everything within 2 x 150 of everything) spread over the duration range
+        at = rng.choice(n, size=int(rng.integers(50, 300)), replace=False)
+        for b in at[1:]:
+            w[b] = near(at[0], int(rng.integers(0, 150)))
+    w[5000:5400] = w[5000]  # identical run
+    want = orc.search_self_sorted(w, d, 350)
+    for no_filter in ("0", "1"):
+        monkeypatch.setenv("VDF_NO_HIT_FILTER", no_filter)
+        for backend in ("mfma", "valu"):
+            monkeypatch.setenv("VDF_SEARCH_BACKEND", backend)
+            eng = vdf.Engine(0)
+            try:
+                assert eng.search_self_sorted(w, d, 350) == want, (no_filter, backend)
+                st, tm = eng.last_stats(), eng.last_timing()
+                assert st["n_hits"] > (1 << 16)
+                assert (tm["hits_filtered"] > 0) == (no_filter == "0")
+            finally:
+                eng.close()
+    monkeypatch.setenv("VDF_NO_HIT_FILTER", "0")
+    two = vdf.Engine(devices=[0, 0])  # two slots: each sees only its own rows' hits, so nothing is filtered
+    try:
+        assert two.search_self_sorted(w, d, 350) == want and two.last_timing()["hits_filtered"] == 0
+    finally:
+        two.close()
 
 
 def test_dense_hits_take_the_device_sort_and_the_overflow_protocol(engine):

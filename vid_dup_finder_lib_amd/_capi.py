@@ -60,7 +60,7 @@ class VdfSearchStats(C.Structure):
 class VdfSearchTiming(C.Structure):
     _fields_ = [
         ("prep_ms", C.c_float), ("stream_ms", C.c_float), ("resolve_ms", C.c_float), ("download_ms", C.c_float),
-        ("replay_ms", C.c_float), ("total_ms", C.c_float), ("suspects", C.c_uint64), ("suspect_capacity", C.c_uint64),
+        ("replay_ms", C.c_float), ("total_ms", C.c_float), ("suspects", C.c_uint64), ("suspect_capacity", C.c_uint64), ("hits_filtered", C.c_uint64),
     ]
 
 

@@ -33,12 +33,13 @@ vdf_ctx::~vdf_ctx()
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
-                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &sort_scratch};
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &sort_scratch, &hits2, &hit_bitmaps};
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
     pin_small.release();
     pin_ctrl.release();
+    host_hits.buf.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_mid) (void)hipEventDestroy(ev_mid);
@@ -74,13 +75,14 @@ bool is_sorted_u32(const uint32_t *d, size_t n)
 
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
 constexpr size_t kPinSmallBytes = 4u << 20;
-constexpr uint64_t kDeviceSortHits = 1u << 17;  // hit lists from this length on are sorted on the device
+constexpr uint64_t kDeviceSortHits = 1u << 17;
+constexpr uint64_t kFilterHits = 1u << 16;      // from this many hits on, a replay-only launch drops the rows that cannot become targets  // hit lists from this length on are sorted on the device
 
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
-                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream)
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only)
 {
     *n_hits_out = 0;
     *overflow_row_out = 0xFFFFFFFFu;
@@ -271,25 +273,43 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6], L.cand_capacity);  // slots this launch used
     const uint64_t produced = fin[0];
-    const uint64_t stored = std::min<uint64_t>(produced, capacity);
+    uint64_t stored = std::min<uint64_t>(produced, capacity);
     ctx->hits_guess = stored;
+    uint64_t n_out = produced;
     if (stored) {
-        const uint64_t have = std::min(stored, spec);
+        vdf_hit *d_list = ctx->hits.as<vdf_hit>();
+        uint64_t have = std::min(stored, spec);
+        // Dense near-duplicates: most of the thresholded pairs belong to rows the greedy replay never uses as targets
+        // (hamming.hip: launch_filter_replay_hits).  With the COMPLETE hit set of an unsharded launch in hand they are
+        // dropped here, before the sort, the download and the host replay - a cluster of s mutual duplicates sends down
+        // s - 1 pairs instead of s (s - 1) / 2.
+        if (replay_only && mode == 0 && shard_count == 1 && produced <= capacity && (uint32_t)fin[4] == 0xFFFFFFFFu &&
+            stored >= kFilterHits && !ctx->no_hit_filter) {
+            VDF_HIP(ctx, ctx->hits2.reserve((size_t)stored * sizeof(vdf_hit)));
+            VDF_HIP(ctx, ctx->hit_bitmaps.reserve(2 * (((size_t)n_cols + 31) / 32) * 4 + 16));
+            VDF_HIP(ctx, vdf::launch_filter_replay_hits(d_list, stored, (uint32_t)n_cols, ctx->hit_bitmaps.as<uint32_t>(),
+                                                        ctx->hits2.as<vdf_hit>(), L.counters + 7, stream));
+            VDF_HIP(ctx, hipMemcpyAsync(fin + 7, L.counters + 7, 8, hipMemcpyDeviceToHost, stream));
+            VDF_HIP(ctx, hipStreamSynchronize(stream));
+            d_list = ctx->hits2.as<vdf_hit>();
+            stored = fin[7];
+            n_out = stored;
+            have = 0;  // the speculative copy held unfiltered pairs
+            ctx->timing.hits_filtered += produced - stored;
+        }
         if (have) std::memcpy(hits, ctx->pin_small.p, (size_t)have * sizeof(vdf_hit));
         if (stored > have) {
-            // Long list (dense near-duplicates): it is put into (row, col) order on the device before it comes down - a host
-            // radix sort of 1e7 pairs costs about as much as the search kernel.
+            // Long list: it is put into (row, col) order on the device before it comes down - a host radix sort of 1e7
+            // pairs costs about as much as the search kernel.
             const bool dev_sort = stored >= kDeviceSortHits;
             if (dev_sort) {
                 unsigned row_bits = 1;
                 while (row_bits < 32 && ((uint64_t)row_index_base + n_rows) >> row_bits) row_bits++;
                 VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_hits_scratch_bytes((size_t)stored)));
-                VDF_HIP(ctx, vdf::launch_sort_hits(ctx->hits.as<vdf_hit>(), (size_t)stored, row_bits, ctx->sort_scratch.p,
-                                                   ctx->sort_scratch.cap, stream));
-                VDF_HIP(ctx, hipMemcpyAsync(hits, ctx->hits.p, (size_t)stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
+                VDF_HIP(ctx, vdf::launch_sort_hits(d_list, (size_t)stored, row_bits, ctx->sort_scratch.p, ctx->sort_scratch.cap, stream));
+                VDF_HIP(ctx, hipMemcpyAsync(hits, d_list, (size_t)stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
             } else {
-                VDF_HIP(ctx, hipMemcpyAsync(hits + have, ctx->hits.as<vdf_hit>() + have, (size_t)(stored - have) * sizeof(vdf_hit),
-                                            hipMemcpyDeviceToHost, stream));
+                VDF_HIP(ctx, hipMemcpyAsync(hits + have, d_list + have, (size_t)(stored - have) * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
             }
             VDF_HIP(ctx, hipStreamSynchronize(stream));
             if (!dev_sort) sort_hits(hits, (size_t)stored);
@@ -298,7 +318,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         }
     }
     ctx->timing.download_ms += (float)(now_ms() - t_synced);
-    *n_hits_out = produced;
+    *n_hits_out = n_out;
     *overflow_row_out = (uint32_t)fin[4];
     ctx->stats.pairs += fin[2];
     ctx->stats.pairs_computed += fin[1];
@@ -787,6 +807,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
         long c = std::atol(s);
         if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;
     }
+    if (const char *s = std::getenv("VDF_NO_HIT_FILTER")) ctx->no_hit_filter = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {
         int v = std::atoi(s);
@@ -823,11 +844,11 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     while (row_begin < n) {
         const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
         int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
-            if (d->host_hits.size() < capacity) d->host_hits.resize(capacity);
+            if (d->host_hits.size() < capacity && !d->host_hits.resize(capacity)) return fail(d, VDF_E_OOM, "hit staging");
             return search_core(d, 0, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n, d->up_hashes.as<uint64_t>(),
                                d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
                                use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, d->host_hits.data(), capacity,
-                               &d->r_n_hits, &d->r_overflow, d->stream);
+                               &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/G == 1);
         });
         if (rc) { vdf_groups_free(out); return rc; }
         uint32_t overflow_row = 0xFFFFFFFFu;
@@ -916,6 +937,7 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
         tm.prep_ms = std::max(tm.prep_ms, q.prep_ms); tm.stream_ms = std::max(tm.stream_ms, q.stream_ms);
         tm.resolve_ms = std::max(tm.resolve_ms, q.resolve_ms); tm.download_ms = std::max(tm.download_ms, q.download_ms);
         tm.suspects += q.suspects; tm.suspect_capacity = std::max(tm.suspect_capacity, q.suspect_capacity);
+        tm.hits_filtered += q.hits_filtered;
     }
     tm.replay_ms = (float)(replay_ms + now_ms() - t_fin);
     tm.total_ms = (float)(now_ms() - t_call);
@@ -939,7 +961,7 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         if (ref_cnt[(size_t)k] == 0) return (int)VDF_OK;
         uint64_t capacity = capacity0;
         for (int attempt = 0; attempt < 6; attempt++) {
-            if (d->host_hits.size() < capacity) d->host_hits.resize(capacity);
+            if (d->host_hits.size() < capacity && !d->host_hits.resize(capacity)) return fail(d, VDF_E_OOM, "hit staging");
             int r = search_refs_device_locked(d, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n_cand,
                                               d->up_ref_hashes.as<uint64_t>(), d->up_ref_dur.as<uint32_t>(),
                                               ref_cnt[(size_t)k], tol_int, (uint32_t)ref_base[(size_t)k], d->host_hits.data(),
@@ -968,6 +990,7 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         tm.prep_ms = std::max(tm.prep_ms, q.prep_ms); tm.stream_ms = std::max(tm.stream_ms, q.stream_ms);
         tm.resolve_ms = std::max(tm.resolve_ms, q.resolve_ms); tm.download_ms = std::max(tm.download_ms, q.download_ms);
         tm.suspects += q.suspects; tm.suspect_capacity = std::max(tm.suspect_capacity, q.suspect_capacity);
+        tm.hits_filtered += q.hits_filtered;
     }
     const double t_group = now_ms();
     int rcg;

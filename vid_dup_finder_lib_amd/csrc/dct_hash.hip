@@ -293,6 +293,13 @@ __global__ __launch_bounds__(256) void dct_hash_kernel(const uint8_t *__restrict
 //   horizontal: A = pixels  (byte j <-> x = 64 kt + 16 g + j: one 16-byte load per lane), B = Ch table
 //   vertical:   B = tmp     (byte 4 m + r <-> y = 64 rg + 16 m + 4 g + r: exactly the C layout of the four
 //               horizontal blocks m = 0..3 of a 64-row group, so tmp never leaves registers), A = Cv table
+// Cache policy of the frame streams: every byte is read exactly once, so the LDS-DMA loads carry the gfx950 `nt` bit
+// (aux = 2) and stay out of L2 / the Infinity Cache.  Same box, plain -> nt, TB/s of frame bytes: 1280 x 720 6.04 -> 6.40-6.61,
+// 1024 x 576 5.99 -> 6.63, 3840 x 2160 6.24 -> 6.60, 480 x 270 5.96 -> 6.29, 1920 x 1080 6.08 -> 6.19, 854 x 480 6.04 -> 6.15
+// (profiles/r03_hash_nt_ab.txt).  -DVDF_STREAM_AUX=0 builds the plain form.
+#ifndef VDF_STREAM_AUX
+#define VDF_STREAM_AUX 2
+#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 
@@ -306,11 +313,17 @@ struct MfmaResizeTables {
     int32_t band_stride;
 };
 
-template <bool CAREFUL>
+// NT: non-temporal load.  Frames are read exactly once; where one wave instruction consumes whole 128-byte lines (the
+// persistent 64 x 64 kernel: 16 rows x 64 B = 1 KB contiguous) keeping them out of L2 / the Infinity Cache is worth 7 % of the
+// stream (1.120 -> 1.043 ms per 100 k clips in one run).  Where two instructions share a line (128-wide frames read as
+// 16 rows x 64 B) it is 30 % SLOWER (1.058 -> 1.376 ms per 20 k clips): those kernels keep plain loads.
+template <bool CAREFUL, bool NT = false>
 __device__ __forceinline__ v4i load_pixels16(const uint8_t *p, const uint8_t *buf_end)
 {
     if (!CAREFUL || p + 16 <= buf_end) {
-        const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned *>(p);
+        u32x4_unaligned v;
+        if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned *>(p));
+        else v = *reinterpret_cast<const u32x4_unaligned *>(p);
         v4i r = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
         return r;
     }
@@ -538,26 +551,36 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
     const bool col_ok = 16u * g < W;
     const size_t lane_off = (size_t)r16 * W + 16u * g;  // row r16 of row block m is at + 16 m W
 
+#ifndef VDF_HASH_STRIDED  // wave w takes frames 4 w .. 4 w + 3: 16 KB contiguous per wave (frames w, w + 4, .. measured 2 % slower)
+    const uint32_t f0 = 4 * wave, fstep = 1;
+#else
+    const uint32_t f0 = wave, fstep = 4;
+#endif
+#ifdef VDF_HASH_NO_NT
+    constexpr bool kNT = false;
+#else
+    constexpr bool kNT = true;
+#endif
     v4i px[4][4];
     auto issue_loads = [&](size_t clip) {
-        const uint8_t *base = frames + clip * clip_stride + (size_t)wave * frame_stride + lane_off;
+        const uint8_t *base = frames + clip * clip_stride + (size_t)f0 * frame_stride + lane_off;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 if (!FULL) px[q][m] = (v4i){0, 0, 0, 0};
                 if (FULL || (16u * m + r16 < H && col_ok))
-                    px[q][m] = load_pixels16<false>(base + (size_t)(4 * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
+                    px[q][m] = load_pixels16<false, kNT>(base + (size_t)(fstep * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
             }
         }
     };
     auto issue_loads_q = [&](size_t clip, int q) {
-        const uint8_t *base = frames + clip * clip_stride + (size_t)wave * frame_stride + lane_off;
+        const uint8_t *base = frames + clip * clip_stride + (size_t)f0 * frame_stride + lane_off;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             if (!FULL) px[q][m] = (v4i){0, 0, 0, 0};
             if (FULL || (16u * m + r16 < H && col_ok))
-                px[q][m] = load_pixels16<false>(base + (size_t)(4 * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
+                px[q][m] = load_pixels16<false, kNT>(base + (size_t)(fstep * q) * frame_stride + (size_t)(16 * m) * W, nullptr);
         }
     };
     uint32_t clip = blockIdx.x;
@@ -583,7 +606,7 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
             v4i vh = {0, 0, 0, 0}, vl = bias_v;
             vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, vh, 0, 0, 0);
             vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, vl, 0, 0, 0);
-            sh.cube[(wave + 4 * q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+            sh.cube[(f0 + fstep * q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
             if (next < n_clips) issue_loads_q(next, q);  // in flight during the whole DCT below
         }
         __builtin_amdgcn_s_setprio(0);
@@ -676,7 +699,11 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
         for (int oct = 0; oct < 4; oct++) {
             const uint32_t row = 32u * q + 8u * oct + row8;
             px[oct] = zero4;
+#ifndef VDF_WIDE_NO_NT  // whole 128-byte lines per instruction, read once: non-temporal (1536 x 864: 5.66 -> 5.96 TB/s)
+            if (row < H && x < W) px[oct] = load_pixels16<CAREFUL, true>(src + (size_t)row * pitch + x, buf_end);
+#else
             if (row < H && x < W) px[oct] = load_pixels16<CAREFUL>(src + (size_t)row * pitch + x, buf_end);
+#endif
         }
     };
     v4i eh[4], el[4], oh[4], ol[4];
@@ -855,9 +882,9 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
             if constexpr (MODE == 0) {
                 // the whole byte offset goes into the VGPR offset: that is the field the frame-sized range check surely covers
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, VDF_STREAM_AUX);
                 x += step_x;
                 ro += step_rows * W;
                 if (x >= Wp) { x -= Wp; ro += W; }
@@ -1067,7 +1094,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         uint32_t x = lane_x0, ro = lane_ro0;
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + ro + x), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + ro + x), 0, 0, VDF_STREAM_AUX);
             x += step_x;
             ro += step_rows * W;
             if (x >= Wp) { x -= Wp; ro += W; }
@@ -1278,14 +1305,14 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
             const uint32_t first_al = SHIFT ? first & ~3u : first;
             for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
                 auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(first_al + off + 16u * lane), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(first_al + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
             }
             return;
         }
         uint32_t x = lx0, ro = first + lro0;
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)((SHIFT ? ro & ~3u : ro) + x), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)((SHIFT ? ro & ~3u : ro) + x), 0, 0, VDF_STREAM_AUX);
             x += q.step_x;
             ro += q.step_rows * pitch;
             if (x >= q.wp) { x -= q.wp; ro += pitch; }

@@ -699,9 +699,30 @@ __global__ __launch_bounds__(256) void resolve_candidates_kernel(
     uint32_t *__restrict__ overflow_row)
 {
     const uint32_t n = (uint32_t)min(*cand_head, (unsigned long long)cand_capacity);
-    const uint32_t lane = threadIdx.x & 63;
-    // The loops are wave-uniform so that the hits of a round are appended with ONE atomic per wave: with dense
-    // near-duplicates (1e7 hits per search) a per-hit atomicAdd on the one counter serialises in L2.
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Hits are staged per wave in LDS and appended kStage at a time: ONE atomic on the shared counter and a coalesced copy
+    // per ~500 hits.  With dense near-duplicates (1e7 hits per search) even one atomic per wave-round on the one address
+    // is what the kernel waits for (measured: 3.6 ms for 6.6 M hits, 0.05 ms for 4 k).  The loops are wave-uniform.
+    constexpr uint32_t kStage = 512;
+    __shared__ vdf_hit s_stage[4][kStage];
+    uint32_t staged = 0;  // wave-uniform
+    auto flush = [&]() {
+        if (staged == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's own LDS writes, read back by other lanes
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&counters[0], (unsigned long long)staged);
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        for (uint32_t k = lane; k < staged; k += 64) {
+            const vdf_hit hp = s_stage[wave][k];
+            if (base + k < capacity) hits[base + k] = hp;
+            else atomicMin(overflow_row, hp.row);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        staged = 0;
+    };
     for (uint32_t e0 = blockIdx.x * 256 + (threadIdx.x & ~63u); e0 < n; e0 += gridDim.x * 256) {
         const uint32_t e = e0 + lane;
         CandEntry ce;
@@ -741,9 +762,18 @@ __global__ __launch_bounds__(256) void resolve_candidates_kernel(
                     }
                 }
             }
-            wave_append_hits(hit, row_index_base + src, ce.col, hits, capacity, counters, overflow_row);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+            if (bal == 0ull) continue;
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
+            if (staged + cnt > kStage) flush();
+            if (hit) {
+                vdf_hit hp; hp.row = row_index_base + src; hp.col = ce.col;
+                s_stage[wave][staged + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = hp;
+            }
+            staged += cnt;
         }
     }
+    flush();
 }
 
 template <int CHK, int WAVES>
@@ -878,7 +908,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     // to the candidate queue.  Slots come in chunks of kCandChunk per wave (one returning atomic per chunk, not per entry; a wave sees ~12 suspects in
     // its 512 x 65536 share of unrelated hashes, so small chunks strand little),
     // the entries are fire-and-forget stores; resolve_candidates_kernel evaluates them exactly.
-    constexpr uint32_t kCandChunk = 8;
+    constexpr uint32_t kCandChunk = 8, kCandChunkMax = 512;
+    uint32_t q_chunk = kCandChunk, q_taken = 0;  // chunk size (grows, see emit) and chunks taken so far
     unsigned long long q_next = 0, q_end = 0;  // this wave's slots [q_next, q_end); 64 bit: the head keeps counting past a full queue
     auto emit = [&](const v16f &c, float thrv, uint32_t live_rows, uint32_t rows_first, uint32_t col_first) __attribute__((always_inline)) {
         uint32_t mask = 0;
@@ -891,7 +922,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         if (bal == 0ull) return;
         const uint32_t need = (uint32_t)__builtin_popcountll(bal);
         if (q_next + need > q_end) {  // new chunk (the rest of the old one stays empty: slots are pre-filled with 0xFF)
-            const uint32_t take = (need + kCandChunk - 1) / kCandChunk * kCandChunk;
+            // A wave that keeps coming back for slots is inside near-duplicate territory (unrelated hashes give a wave ~12
+            // suspects in its whole 512 x 65536 share: two chunks), and there one returning atomic on the one head counter
+            // per chunk is what the whole search then waits for (6.6 M hits: stream 4.1 -> 7.3 ms with fixed chunks of 8 -
+            // 800 k same-address atomics).  From the third chunk on the chunks double, up to kCandChunkMax.
+            if (q_taken >= 2) q_chunk = min(2u * q_chunk, kCandChunkMax);
+            q_taken++;
+            const uint32_t take = max((need + kCandChunk - 1) / kCandChunk * kCandChunk, q_chunk);
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(cand_head, (unsigned long long)take);
             q_next = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
@@ -1015,6 +1052,69 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     }
     if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kTileRows);
     if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u));
+}
+
+// ---- hits that cannot matter to the greedy replay (search_algorithm.rs:131-170) -------------------------------------
+// The replay walks the targets in ascending order; a target's hit list is looked at only if the target is still unmatched
+// when its turn comes.  Call k a ROOT if no hit (x, k) exists: nothing can consume a root before its turn, so it IS a target,
+// and every candidate i of one of its hits (k, i) is matched once k's turn is over (by k, or earlier by someone else).  i > k,
+// so i is never a target: its own hit list is dead weight.  In a cluster of s mutual near-duplicates that leaves the
+// smallest member's s - 1 hits of the s (s - 1) / 2 - what the reference's consuming loop looks at, too.  Needs the COMPLETE
+// hit set of the launch (no buffer overflow, one shard): the caller checks that.  Bitmaps are 1 bit per entry, zeroed.
+__global__ __launch_bounds__(256) void hits_mark_incoming_kernel(const vdf_hit *__restrict__ hits, unsigned long long n,
+                                                                 uint32_t *__restrict__ has_in)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t j = hits[i].col;
+        atomicOr(&has_in[j >> 5], 1u << (j & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void hits_mark_covered_kernel(const vdf_hit *__restrict__ hits, unsigned long long n,
+                                                                const uint32_t *__restrict__ has_in, uint32_t *__restrict__ covered)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const vdf_hit h = hits[i];
+        if (!((has_in[h.row >> 5] >> (h.row & 31)) & 1u)) atomicOr(&covered[h.col >> 5], 1u << (h.col & 31));
+    }
+}
+
+__global__ __launch_bounds__(256) void hits_compact_kernel(const vdf_hit *__restrict__ hits, unsigned long long n,
+                                                           const uint32_t *__restrict__ covered, vdf_hit *__restrict__ out,
+                                                           unsigned long long *__restrict__ counter)
+{
+    const size_t n_round = (n + 63) & ~(size_t)63;  // whole waves reach the ballot
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_round; i += (size_t)gridDim.x * 256) {
+        vdf_hit h{0u, 0u};
+        bool keep = false;
+        if (i < n) {
+            h = hits[i];
+            keep = !((covered[h.row >> 5] >> (h.row & 31)) & 1u);
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+        if (bal == 0ull) continue;
+        const int leader = __builtin_ctzll(bal);
+        unsigned long long base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(counter, (unsigned long long)__builtin_popcountll(bal));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, leader, 64);
+        if (keep) out[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = h;
+    }
+}
+
+// bitmaps: 2 x ceil(n_entries / 32) words (has_in | covered), zeroed here; *counter (device) receives the survivors' count
+hipError_t launch_filter_replay_hits(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps,
+                                     vdf_hit *out, unsigned long long *counter, hipStream_t stream)
+{
+    const size_t words = ((size_t)n_entries + 31) / 32;
+    hipError_t e = hipMemsetAsync(bitmaps, 0, 2 * words * 4, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(counter, 0, 8, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t grid = (uint32_t)std::min<unsigned long long>((n_hits + 255) / 256, 8192ull);
+    hipLaunchKernelGGL(hits_mark_incoming_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps);
+    hipLaunchKernelGGL(hits_mark_covered_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps, bitmaps + words);
+    hipLaunchKernelGGL(hits_compact_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps + words, out, counter);
+    return hipGetLastError();
 }
 
 hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_cols, const uint32_t *row_dur,

@@ -91,11 +91,13 @@ struct vdf_ctx {
     // search scratch
     DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
     DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
+    DevBuf hits2, hit_bitmaps;  // replay filter: surviving hits, has-incoming / covered bitmaps
     DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side Search::sort
     // hash scratch
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables;
     PinBuf pin[2], pin_out[2];
     PinBuf pin_ctrl;   // search: the counters of a launch (pageable destinations make hipMemcpyAsync synchronous)
+    bool no_hit_filter = false;  // VDF_NO_HIT_FILTER: host-level search() downloads and replays every thresholded pair
     uint64_t hits_guess = 0;  // hits of the previous launch: how much of the list is fetched together with the counters
     PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
@@ -115,7 +117,14 @@ struct vdf_ctx {
     DevBuf exp_cols, exp_rows, pop_cols, pop_rows, cand;
     size_t cand_dirty = SIZE_MAX;  // slots of the candidate queue the last launch may have written (SIZE_MAX: never initialised)
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads, 5 MFMA linear-stream kernel where it applies, 6 its K-split form where it applies
-    std::vector<vdf_hit> host_hits;
+    // hit list of the host-level calls: pinned (a 50 MB list comes down at the link rate; a std::vector of the default
+    // 16 M entries would also be zero-filled, page by page, on first use)
+    struct HostHits {
+        PinBuf buf;
+        size_t size() const { return buf.cap / sizeof(vdf_hit); }
+        bool resize(size_t n) { return buf.reserve(n * sizeof(vdf_hit)); }
+        vdf_hit *data() const { return buf.as<vdf_hit>(); }
+    } host_hits;
     vdf_impl::CopyPool *copy_pool = nullptr;
     // results of the last fan-out round on this device (multi-GPU parent reads them after the workers join)
     uint64_t r_n_hits = 0;
@@ -159,11 +168,13 @@ inline bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row
 int create_single(int device_id, vdf_ctx **out, std::string *err);
 int upload(vdf_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, hipStream_t stream);
 // windows + tiles, distance kernel, hit download (sorted by (row, col)); mode 0 = self, 1 = references
+// replay_only: the hits feed nothing but the greedy replay of search(), so hits that provably cannot matter to it may be
+// dropped on the device (then *n_hits_out = the number kept; stats.n_hits still counts every thresholded pair)
 int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint32_t *d_col_dur, size_t n_cols,
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
-                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream);
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only = false);
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                               size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations, size_t n_ref,
                               uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits, uint64_t capacity,
