@@ -85,6 +85,73 @@ def test_malformed_input_is_rejected():
         vc.decode_cache(bytes([254]))              # u128 marker: not a valid length
 
 
+def _check_against_cases(c, cases):
+    """decoded cache `c` against the entries of tools/ref_vectors/cache_cases.py (a HashMap's order is arbitrary)."""
+    ok = [x for x in cases if x[1] == 0]
+    assert c["n_entries"] == len(cases) and c["n_err"] == len(cases) - len(ok) and c["n_key_differs"] == 0
+    assert len(c["paths"]) == len(ok) == len(set(c["paths"]))
+    at = {p: i for i, p in enumerate(c["paths"])}
+    for path, _, words, dur, secs, nanos, _ in ok:
+        i = at[path]
+        assert np.array_equal(c["hashes"][i], words), path
+        assert (int(c["durations"][i]), int(c["mtime_secs"][i]), int(c["mtime_nanos"][i])) == (dur, secs, nanos), path
+
+
+def _cases():
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ref_vectors"))
+    from cache_cases import cache_cases
+
+    return cache_cases()
+
+
+def test_app_written_cache_decodes():
+    """tests/golden/ref_cache.bin = the cache_cases.py entries written by the APP'S OWN cache writer (tools/ref_vectors/
+    cache_dump.rs: BaseFsCache::insert + save, base_fs_cache.rs:56-165).  Skips until a maintainer with cargo has generated it."""
+    import os
+
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cache.bin")
+    if not os.path.exists(p):
+        pytest.skip("ref_cache.bin not present: generate it with the real app (tools/ref_vectors/README.md)")
+    _check_against_cases(vc.decode_cache(open(p, "rb").read()), _cases())
+
+
+def test_cache_handoff_comparison_is_sound():
+    """The same comparison on a file synthesised here: the Ok entries through the library's encoder, the three Err entries
+    appended by hand from the bincode rules (variant index as a varint, VidProc's string length-prefixed)."""
+    cases = _cases()
+    ok = [x for x in cases if x[1] == 0]
+    body = vc.encode_cache(np.stack([x[2] for x in ok]), [x[3] for x in ok], [x[0] for x in ok], [x[4] for x in ok],
+                           [x[5] for x in ok])
+    assert body[0] == len(ok) < 251  # one-byte map length
+
+    def varint(v):
+        if v < 251:
+            return bytes([v])
+        if v < 1 << 16:
+            return bytes([251]) + v.to_bytes(2, "little")
+        if v < 1 << 32:
+            return bytes([252]) + v.to_bytes(4, "little")
+        return bytes([253]) + v.to_bytes(8, "little")
+
+    extra = b""
+    for path, kind, _, _, secs, nanos, msg in cases:
+        if kind == 0:
+            continue
+        pb = path.encode()
+        extra += varint(len(pb)) + pb + varint(secs) + varint(nanos) + bytes([1, kind - 1])
+        if kind == 2:
+            extra += varint(len(msg.encode())) + msg.encode()
+    data = bytes([len(cases)]) + body[1:] + extra
+    _check_against_cases(vc.decode_cache(data), cases)
+    with pytest.raises(AssertionError):
+        bad = list(cases)
+        bad[3] = (bad[3][0], 0, bad[3][2], bad[3][3] + 1, bad[3][4], bad[3][5], "")
+        _check_against_cases(vc.decode_cache(data), bad)
+
+
 @pytest.mark.gpu
 def test_cache_to_search_end_to_end(engine):
     """cache bytes -> SoA -> search(): the route a 10 M-hash user cache takes to the GPU."""

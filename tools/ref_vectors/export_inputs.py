@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Flat little-endian copies of the committed fixture INPUTS for the Rust harness (ref_vectors.rs).
 hash_inputs.bin:   u32 n_cases, then per case: u32 name_len, name, u32 n_clips, n_frames, h, w, then n_clips*n_frames*h*w bytes.
-search_inputs.bin: u32 n, n*16 u64 hash words, n u32 durations, u32 n_ref, n_ref*16 u64, n_ref u32."""
+search_inputs.bin: u32 n, n*16 u64 hash words, n u32 durations, u32 n_ref, n_ref*16 u64, n_ref u32.
+cache_inputs.bin:  u32 n, then per entry: u32 kind (0 Ok, 1 Err(NotVideo), 2 Err(VidProc), 3 Err(NotEnoughFrames)), 16 u64 words,
+                   u32 duration, u64 mtime secs, u32 mtime nanos, u32 path_len, path (UTF-8), u32 msg_len, msg (cache_dump.rs)."""
 import os
 import struct
 
@@ -27,4 +29,16 @@ with open(os.path.join(OUT, "search_inputs.bin"), "wb") as f:
         f.write(struct.pack("<I", len(d)))
         f.write(np.ascontiguousarray(h, dtype="<u8").tobytes())
         f.write(np.ascontiguousarray(d, dtype="<u4").tobytes())
-print("wrote", OUT, "cases:", names)
+import sys
+
+sys.path.insert(0, HERE)
+from cache_cases import cache_cases  # noqa: E402
+
+cases = cache_cases()
+with open(os.path.join(OUT, "cache_inputs.bin"), "wb") as f:
+    f.write(struct.pack("<I", len(cases)))
+    for path, kind, words, dur, secs, nanos, msg in cases:
+        pb, mb = path.encode(), msg.encode()
+        f.write(struct.pack("<I", kind) + np.ascontiguousarray(words, dtype="<u8").tobytes() + struct.pack("<IQI", dur, secs, nanos))
+        f.write(struct.pack("<I", len(pb)) + pb + struct.pack("<I", len(mb)) + mb)
+print("wrote", OUT, "cases:", names, "+", len(cases), "cache entries")
