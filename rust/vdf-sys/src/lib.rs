@@ -96,4 +96,14 @@ extern "C" {
         n: usize, hits: *const vdf_hit, n_hits: u64, row_begin: u32, row_end: u32, matched: *mut u8, out: *mut vdf_groups,
     ) -> c_int;
     pub fn vdf_groups_finish_self(g: *mut vdf_groups) -> c_int;
+    // Search::sort on the device for a database that stays in HBM between hashing and searching
+    // (search_algorithm.rs:55-61; d_path_rank = each entry's rank among the caller's paths in PathBuf order, or null).
+    pub fn vdf_sort_order_device(
+        ctx: *mut vdf_ctx, d_durations: *const u32, d_path_rank: *const u32, n: usize, d_perm_out: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    pub fn vdf_apply_order_device(
+        ctx: *mut vdf_ctx, d_hashes: *const u64, d_durations: *const u32, d_perm: *const u32, n: usize, d_hashes_out: *mut u64,
+        d_durations_out: *mut u32, stream: *mut c_void,
+    ) -> c_int;
+    pub fn vdf_sort_hits(hits: *mut vdf_hit, n_hits: u64) -> c_int;
 }

@@ -301,7 +301,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         if (stored > have) {
             // Long list: it is put into (row, col) order on the device before it comes down - a host radix sort of 1e7
             // pairs costs about as much as the search kernel.
-            const bool dev_sort = stored >= kDeviceSortHits;
+            const bool dev_sort = stored >= (d_list == ctx->hits.as<vdf_hit>() ? kDeviceSortHits : kDeviceSortHits / 16);  // after the filter nothing of the list is on the host yet
             if (dev_sort) {
                 unsigned row_bits = 1;
                 while (row_bits < 32 && ((uint64_t)row_index_base + n_rows) >> row_bits) row_bits++;
@@ -488,7 +488,7 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         const bool ksplit = !fused && ((ctx->resize_mode == 0 && !streamed && w >= 2048) || ctx->resize_mode == 6) &&
                             vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         if (ksplit) { streamed = false; mh = nullptr; }
-        const bool wide = !fused && !streamed && !ksplit && ctx->resize_mode != 2;
+        const bool wide = !fused && !streamed && !ksplit;
         if (!mh) mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
         DeviceMfmaTable *mv = mfma_table(ctx, h, wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, &rc);
@@ -786,7 +786,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     }
     if (const char *s = std::getenv("VDF_RESIZE_MODE")) {
         int m = std::atoi(s);
-        if (m >= 0 && m <= 6) ctx->resize_mode = m;
+        if (m >= 0 && m <= 6 && m != 2) ctx->resize_mode = m;  // 2 was the per-frame 16 x 64 B kernel, removed in round 3
     }
     if (const char *s = std::getenv("VDF_SEARCH_BACKEND")) {
         if (!std::strcmp(s, "valu")) ctx->search_backend = 0;

@@ -621,43 +621,10 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
     }
 }
 
-// Large frames: one workgroup per frame, the four waves take equal contiguous shares of its 16-row blocks and their
-// vertical partial sums (exact i32) are added through LDS.  Writes the 16 x 16 u8 frame to `small`.
-__global__ __launch_bounds__(256) void resize_mfma_frame_kernel(const uint8_t *__restrict__ frames, uint32_t W,
-                                                                uint32_t H, size_t frame_stride, size_t clip_stride,
-                                                                const uint8_t *buf_end, MfmaResizeTables T,
-                                                                uint8_t *__restrict__ small)
-{
-    __shared__ int32_t s_part[3][2][64][4];
-    const size_t clip = blockIdx.x >> 4;
-    const uint32_t f = blockIdx.x & 15;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
-    v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-    const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride;
-    const int n_blk = (int)((H + 15) / 16), b0 = n_blk * (int)wave / 4, b1 = n_blk * ((int)wave + 1) / 4;
-    if (src + (size_t)W * H + 64 > buf_end) resize_row_blocks<true>(src, W, H, buf_end, T, b0, b1, vh, vl);
-    else resize_row_blocks<false>(src, W, H, buf_end, T, b0, b1, vh, vl);
-    if (wave > 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) { s_part[wave - 1][0][lane][r] = vh[r]; s_part[wave - 1][1][lane][r] = vl[r]; }
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            vl[r] += T.bias_v[4 * g + r];
-#pragma unroll
-            for (int w = 0; w < 3; w++) { vh[r] += s_part[w][0][lane][r]; vl[r] += s_part[w][1][lane][r]; }
-        }
-        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
-        uint8_t *dst = small + (clip * 16 + f) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
-    }
-}
-
 // ---- large frames, coalesced ------------------------------------------------------------------------------
-// The A-operand shape above makes every wave load touch 16 rows x 64 B: half lines at the frame's pitch, which caps
+// Large frames, one workgroup per frame; the four waves' vertical partial sums (exact i32) are added through LDS and the 16 x 16
+// u8 frame goes to `small`.  The natural A-operand shape (lane = row, 16 bytes of one K tile: resize_row_blocks) makes every
+// wave load touch 16 rows x 64 B: half lines at the frame's pitch, which caps
 // a 1080p stream at 5.3 TB/s (tools/ubench_rowload.hip; 8 rows x 128 B reads at 6.2, a linear sweep at 6.24).
 // Here one wave load covers 8 rows x 128 B (whole lines) and still lands directly in MFMA operand registers: lane
 // (a = lane & 15, g = lane >> 4) loads row R0 + (a >> 1), bytes 128 T + 64 (a & 1) + 16 g .. +15, i.e. the 16 A rows of
@@ -1645,13 +1612,10 @@ hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint
                                      const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    if (wide) {  // a.av is in kMfmaLayoutVerticalWide order
-        hipLaunchKernelGGL(resize_mfma_frame_wide_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, w,
-                           h, frame_stride, clip_stride, buf_end, make_tables(a), small);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(resize_mfma_frame_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, w, h,
-                       frame_stride, clip_stride, buf_end, make_tables(a), small);
+    if (!wide) return hipErrorInvalidValue;  // round 3: the per-frame 16 x 64 B kernel is gone (dominated at every size, profiles/r03_resize_sweep.txt)
+    // a.av is in kMfmaLayoutVerticalWide order
+    hipLaunchKernelGGL(resize_mfma_frame_wide_kernel, dim3((uint32_t)(n_clips * 16)), dim3(256), 0, stream, frames, w,
+                       h, frame_stride, clip_stride, buf_end, make_tables(a), small);
     return hipGetLastError();
 }
 

@@ -1066,7 +1066,9 @@ __global__ __launch_bounds__(256) void hits_mark_incoming_kernel(const vdf_hit *
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const uint32_t j = hits[i].col;
-        atomicOr(&has_in[j >> 5], 1u << (j & 31));
+        // bits only ever go 0 -> 1: a plain look first skips the atomic for the ~98 % of hits whose column is already marked
+        // (measured 0.59 ms for 6.6 M hits with unconditional atomics: thousands of them per word); a stale 0 only costs the atomic
+        if (!((has_in[j >> 5] >> (j & 31)) & 1u)) atomicOr(&has_in[j >> 5], 1u << (j & 31));
     }
 }
 
@@ -1075,7 +1077,8 @@ __global__ __launch_bounds__(256) void hits_mark_covered_kernel(const vdf_hit *_
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const vdf_hit h = hits[i];
-        if (!((has_in[h.row >> 5] >> (h.row & 31)) & 1u)) atomicOr(&covered[h.col >> 5], 1u << (h.col & 31));
+        if (!((has_in[h.row >> 5] >> (h.row & 31)) & 1u) && !((covered[h.col >> 5] >> (h.col & 31)) & 1u))
+            atomicOr(&covered[h.col >> 5], 1u << (h.col & 31));
     }
 }
 

@@ -4,7 +4,11 @@ namespace vdf {
 
 uint32_t stream_pitch(uint32_t w)
 {
+#ifdef VDF_STREAM_REPITCH_ALL  // experiment: every line-aligned pitch from 640 columns up is re-pitched to an odd multiple of 16 bytes
+    if (w % 16 == 0) return ((w % 256 == 0 && w >= 768) || (w % 128 == 0 && w >= 640 && (w / 16) % 2 == 0)) ? w + 16 : w;
+#else
     if (w % 16 == 0) return (w % 256 == 0 && w >= 768) ? w + 16 : w;
+#endif
     uint32_t wp = (w + (w % 4 ? 3u : 0u) + 15u) & ~15u;
     if ((wp / 16) % 2 == 0) wp += 16;
     return wp;

@@ -116,7 +116,7 @@ struct vdf_ctx {
     int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows, pop_cols, pop_rows, cand;
     size_t cand_dirty = SIZE_MAX;  // slots of the candidate queue the last launch may have written (SIZE_MAX: never initialised)
-    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 2 MFMA per-frame kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads, 5 MFMA linear-stream kernel where it applies, 6 its K-split form where it applies
+    int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads, 5 MFMA linear-stream kernel where it applies, 6 its K-split form where it applies
     // hit list of the host-level calls: pinned (a 50 MB list comes down at the link rate; a std::vector of the default
     // 16 M entries would also be zero-filled, page by page, on first use)
     struct HostHits {
