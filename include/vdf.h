@@ -239,6 +239,13 @@ int vdf_sort_order_device(vdf_ctx *ctx, const uint32_t *d_durations, const uint3
 int vdf_apply_order_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, const uint32_t *d_perm, size_t n,
                            uint64_t *d_hashes_out, uint32_t *d_durations_out, void *stream);
 
+/* A promise that lets searches against ONE resident database skip work: until the next call of this function the n x 16 words at
+ * d_hashes will not change.  Searches whose candidate database is exactly (d_hashes, n) then reuse the operand expansion the
+ * matrix-core backend makes of it (0.15 ms per million hashes - a sixth of a reference search at the BASELINE configs[4] shape:
+ * the app searches its one cache database with reference set after reference set, app_fns.rs:428-482).  d_hashes = NULL withdraws the
+ * promise.  Single-device contexts. */
+int vdf_ctx_pin_database(vdf_ctx *ctx, const uint64_t *d_hashes, size_t n);
+
 uint32_t vdf_row_tile_size(void); /* rows per tile of the default backend (informational: any shard_count works) */
 
 /* Host replay of search_self's consumption order (search_algorithm.rs:131-170) over hits sorted

@@ -313,3 +313,44 @@ def test_suspect_queue_slots_beyond_a_smaller_launch_are_not_read_stale(monkeypa
             assert eng.search_self_sorted(tiny_w, tiny_d, 350) == orc.search_self_sorted(tiny_w, tiny_d, 350)
     finally:
         eng.close()
+
+
+def test_pinned_database_reuses_its_expansion_and_never_goes_stale(engine):
+    """vdf_ctx_pin_database: searches against the pinned candidate database skip the operand expansion (matrix-core backend) -
+    same results as unpinned, for changing reference sets and tolerances (another tolerance = another tested prefix = a fresh
+    expansion); once the promise is withdrawn a changed database is seen again.  Also drives the speculative device-side sort
+    of the hit list (second and later calls with >= 16 k hits)."""
+    import torch
+
+    rng = np.random.default_rng(123)
+    words, dur = hg.planted_set(rng, 30_000, n_clusters=600, max_copies=40, max_flips=200, durations="windowed")
+    w, d, _ = hg.sort_by_duration(words, dur)
+    tw = torch.from_numpy(w.view(np.int64).copy()).cuda()
+    td = torch.from_numpy(d.view(np.int32).copy()).cuda()
+    torch.cuda.synchronize()
+
+    def refs(rw, rd, tol):
+        a = torch.from_numpy(rw.view(np.int64).copy()).cuda()
+        b = torch.from_numpy(rd.view(np.int32).copy()).cuda()
+        torch.cuda.synchronize()
+        hits, n = engine.search_refs_device(tw.data_ptr(), td.data_ptr(), len(d), a.data_ptr(), b.data_ptr(), len(rd), tol)
+        assert n == len(hits)
+        from vid_dup_finder_lib_amd import engine as ve
+        return ve.groups_from_ref_hits(hits)
+
+    engine.pin_database(tw.data_ptr(), len(d))
+    try:
+        for k, tol in enumerate([350, 350, 350, 200, 350]):
+            pick = np.random.default_rng(k).choice(len(d), size=9000, replace=False)
+            got = refs(w[pick], d[pick], tol)
+            assert got == orc.search_refs_sorted(w, d, w[pick], d[pick], tol), (k, tol)
+            assert tol < 350 or sum(len(m) for _, m in got) > (1 << 14)  # long enough for the speculative device sort
+    finally:
+        engine.pin_database(0, 0)
+    # promise withdrawn: overwrite part of the database in place and search again
+    w2 = w.copy()
+    w2[:5000] = hg.random_hashes(np.random.default_rng(9), 5000)
+    tw.copy_(torch.from_numpy(w2.view(np.int64)))
+    torch.cuda.synchronize()
+    pick = np.random.default_rng(77).choice(len(d), size=2000, replace=False)
+    assert refs(w2[pick], d[pick], 350) == orc.search_refs_sorted(w2, d, w2[pick], d[pick], 350)

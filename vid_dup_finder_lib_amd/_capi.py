@@ -130,6 +130,7 @@ SIGNATURES = {
                                             C.POINTER(C.c_void_p)]),
     "vdf_sort_order_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "vdf_apply_order_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdf_ctx_pin_database": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
     "vdf_row_tile_size": (C.c_uint32, []),
     "vdf_replay_self": (C.c_int, [C.c_size_t, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.POINTER(VdfGroups)]),

@@ -74,6 +74,16 @@ struct RcclState;  // communicators of a multi-GPU context (multi.cpp)
 struct CopyPool;   // host threads that gather caller frames into pinned staging (hash_host.cpp)
 }
 
+// What the fp4 expansion in exp_cols was made from (reused only for a database the caller pinned)
+struct ExpOwner {
+    const void *hashes = nullptr;
+    size_t n = 0;
+    uint32_t k_steps = 0;
+    int mode01 = -1;
+    const void *buffer = nullptr;  // exp_cols.p at the time: a reallocation invalidates
+    bool operator==(const ExpOwner &o) const { return hashes == o.hashes && n == o.n && k_steps == o.k_steps && mode01 == o.mode01 && buffer == o.buffer && hashes; }
+};
+
 struct vdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -97,6 +107,9 @@ struct vdf_ctx {
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables;
     PinBuf pin[2], pin_out[2];
     PinBuf pin_ctrl;   // search: the counters of a launch (pageable destinations make hipMemcpyAsync synchronous)
+    const void *pinned_db = nullptr;  // vdf_ctx_pin_database: the caller promises these n x 16 words do not change until unpinned
+    size_t pinned_n = 0;
+    ExpOwner exp_owner;
     bool no_hit_filter = false;  // VDF_NO_HIT_FILTER: host-level search() downloads and replays every thresholded pair
     uint64_t hits_guess = 0;  // hits of the previous launch: how much of the list is fetched together with the counters
     PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)

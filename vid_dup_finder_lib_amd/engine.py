@@ -268,6 +268,11 @@ class Engine:
                                                      len(rh) if rh is not None else 0, C.byref(g), out.ctypes.data))
         return out
 
+    def pin_database(self, d_hashes: int, n: int):
+        """Promise that the n x 16 words at d_hashes stay unchanged (until pin_database(0, 0)): searches against exactly this
+        database reuse its operand expansion."""
+        self._check(self.lib.vdf_ctx_pin_database(self.ctx, d_hashes or None, int(n)))
+
     def sort_order_device(self, d_durations: int, n: int, d_perm_out: int, d_path_rank: int = 0, stream: int = 0):
         """Search::sort's permutation (stable by (duration, path rank)) of n device-resident entries into d_perm_out (u32)."""
         self._check(self.lib.vdf_sort_order_device(self.ctx, d_durations, d_path_rank or None, n, d_perm_out, stream or None))
