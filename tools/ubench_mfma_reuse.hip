@@ -1,0 +1,125 @@
+// Round 3 probe for the search kernel's structural candidate (b): does the matrix pipe finish the same {0,1} fp4 work sooner when
+// one B fragment feeds more consecutive MFMAs (less operand toggling = less energy at the power cap), and can the target
+// fragments live in AGPRs (one 512-register wave per SIMD) without a v_accvgpr_read per use?
+// Work unit per iteration and wave: TILES 32-row target tiles x one 32-candidate sub-tile x 13 k-steps (832 bits) = 13 TILES MFMAs.
+//   mode 0  TILES = 2, 2 waves per SIMD, k-step-major (B_s feeds both tiles back to back)           <- tools/ubench_mfma_energy.hip mode 8
+//   mode 1  TILES = 2, 2 waves per SIMD, tile-major (13 MFMAs of tile 0, then 13 of tile 1: B changes every MFMA) <- the kernel's order today
+//   mode 2  TILES = 4, 1 wave per SIMD, k-step-major, A fragments as inline-asm AGPR operands
+//   mode 3  TILES = 6, 1 wave per SIMD, k-step-major, 64 A fragments in AGPRs + 14 in VGPRs
+//   mode 4  TILES = 4, 1 wave per SIMD, k-step-major, A in VGPRs (compiler's choice) - is the AGPR source itself slower?
+// >= 150 ms per mode so the clock settles.  ns per MFMA per SIMD is the figure to compare.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/ubench_mfma_reuse.hip -o tools/ubench_mfma_reuse
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int N> struct IntC { static constexpr int value = N; };
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) { f(IntC<I>{}); static_for<I + 1, N>(f); }
+}
+
+__device__ __forceinline__ void mfma_v(v16f &acc, const v4i &a, const v4i &b)
+{  // inline asm like the AGPR form, so that the SOURCE order is the issue order in every mode
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_a(v16f &acc, const v4i &a, const v4i &b)
+{  // A operand from the accumulator half of the register file
+    asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(acc) : "a"(a), "v"(b));
+}
+
+__device__ __forceinline__ void home_agpr(v4i &x) { asm volatile("" : "+a"(x)); }
+
+template <int MODE>
+__global__ __launch_bounds__(MODE <= 1 ? 512 : 256, 1) void mfma_loop(const uint4 *__restrict__ data, uint32_t iters, float *out)
+{
+    constexpr int TILES = MODE <= 1 ? 2 : MODE == 3 ? 6 : 4;
+    constexpr int K = 13;
+    constexpr int NA = TILES * K;
+    constexpr int N_AGPR = MODE == 2 ? NA : MODE == 3 ? 64 : 0;  // fragments handed over as AGPR operands
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v4i a[NA], b[8];
+    const uint4 *p = data + ((size_t)(blockIdx.x * 8 + wave) * 64 + lane) * 96;
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const uint4 v = p[i]; a[i] = (v4i){(int)(v.x & 0x22222222u), (int)(v.y & 0x22222222u), (int)(v.z & 0x22222222u), (int)(v.w & 0x22222222u)}; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint4 v = p[88 + i]; b[i] = (v4i){(int)(v.x & 0x22222222u), (int)(v.y & 0x22222222u), (int)(v.z & 0x22222222u), (int)(v.w & 0x22222222u)}; }
+    // Make the AGPR half the fragments' HOME: an empty asm that ties the value to an accumulator-register operand turns it into
+    // an AGPR-class value from here on.  Without it the register allocator keeps the loop-invariant fragments in VGPRs and copies
+    // each one into a shuttle AGPR (4 v_accvgpr_write) before every use.
+#pragma unroll
+    for (int i = 0; i < N_AGPR; i++) home_agpr(a[i]);
+    float m = -1e30f;
+    for (uint32_t it = 0; it < iters; it++) {
+        v16f acc[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; t++) acc[t] = v16f{};
+        if constexpr (MODE == 1) {
+            static_for<0, TILES>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                static_for<0, K>([&](auto sc) { constexpr int s = decltype(sc)::value; mfma_v(acc[t], a[t * K + s], b[s & 7]); });
+            });
+        } else {
+            static_for<0, K>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                static_for<0, TILES>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t * K + s < N_AGPR) mfma_a(acc[t], a[t * K + s], b[s & 7]);
+                    else mfma_v(acc[t], a[t * K + s], b[s & 7]);
+                });
+            });
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; t++) m = fmaxf(m, acc[t][t]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) b[i].x = __builtin_amdgcn_alignbit(b[i].x, b[i].x, 4);  // B changes from unit to unit (stays {0, 1} nibbles)
+    }
+    if (m == 12345.0f) out[threadIdx.x] = m;
+}
+
+int main(int argc, char **argv)
+{
+    const int n_cu = 256;
+    const uint32_t iters = argc > 1 ? (uint32_t)atoi(argv[1]) : 200000;
+    const size_t n_vec = (size_t)n_cu * 8 * 64 * 96;
+    std::vector<uint32_t> h(n_vec * 4);
+    uint64_t x = 88172645463325252ull;
+    for (auto &w : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = (uint32_t)x; }
+    uint4 *d; float *o;
+    hipMalloc(&d, n_vec * 16); hipMalloc(&o, 4096);
+    hipMemcpy(d, h.data(), n_vec * 16, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const char *names[5] = {"2 tiles, 2 waves/SIMD, k-step-major (B x2)  ", "2 tiles, 2 waves/SIMD, tile-major (B x1)     ",
+                            "4 tiles, 1 wave/SIMD, B x4, A in AGPRs       ", "6 tiles, 1 wave/SIMD, B x6, A 64 AGPR + 14 V ",
+                            "4 tiles, 1 wave/SIMD, B x4, A compiler-placed"};
+    for (int rep = 0; rep < 2; rep++)
+        for (int mode = 0; mode < 5; mode++) {
+            const int tiles = mode <= 1 ? 2 : mode == 3 ? 6 : 4, waves_per_simd = mode <= 1 ? 2 : 1;
+            const uint32_t n = iters * 2 / tiles * (mode <= 1 ? 1 : 2);  // the same MFMA count per SIMD in every mode
+            auto launch = [&](uint32_t k) {
+                switch (mode) {
+                case 0: hipLaunchKernelGGL(mfma_loop<0>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
+                case 1: hipLaunchKernelGGL(mfma_loop<1>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
+                case 2: hipLaunchKernelGGL(mfma_loop<2>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
+                case 3: hipLaunchKernelGGL(mfma_loop<3>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
+                default: hipLaunchKernelGGL(mfma_loop<4>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
+                }
+            };
+            launch(n / 10);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            launch(n);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double mfma_per_simd = (double)n * 13.0 * tiles * waves_per_simd;
+            printf("rep %d mode %d %s: %.1f ms  %.2f ns per MFMA per SIMD -> %.3e pairs/s chip-wide (832-bit blocks)\n", rep, mode, names[mode], ms,
+                   ms * 1e6 / mfma_per_simd, (double)n_cu * 4 * mfma_per_simd / 13.0 * 1024.0 / (ms * 1e-3));
+        }
+    return 0;
+}
