@@ -835,8 +835,8 @@ def main():
                                                   "traffic": scaled_traffic(key, n, profiled)}}
                 del buf, oh
 
-            big_leg("full_hd", args.hash_hd_clips, 1920, 1080, "resize_mfma_frame_stream_kernel",
-                    "resize_mfma_frame_stream_kernel@1920x1080", 1000)
+            big_leg("full_hd", args.hash_hd_clips, 1920, 1080, "resize_mfma_frame_wavestream_kernel",
+                    "resize_mfma_frame_wavestream_kernel@1920x1080", 1000)
             # a pitch that is not a multiple of the 128-byte line: the linear-stream kernel (LDS-DMA of whole chunks)
             big_leg("pitch_480x270", 4000, 480, 270, "resize_mfma_frame_stream_kernel", "resize_mfma_frame_stream_kernel@480x270", 4000)
             # 4K: the K-split form of the stream kernel (horizontal table in registers)

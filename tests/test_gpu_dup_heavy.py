@@ -120,3 +120,28 @@ def test_dense_hits_take_the_device_sort_and_the_overflow_protocol(engine):
     # references against the dense database: every hit is output
     pick = np.random.default_rng(3).choice(len(d), size=500, replace=False)
     assert engine.search_refs_sorted(w, d, w[pick], d[pick], 350) == orc.search_refs_sorted(w, d, w[pick], d[pick], 350)
+
+
+def test_dup_heavy_at_the_bench_size_matches_the_oracle(engine):
+    """The bench leg's own database (1 M hashes, 1015 clusters, 6.59 M thresholded pairs) through the whole host-level search()
+    - stream, suspect queue, wave-staged appends, replay filter, device sort, replay - against the oracle's literal search_self
+    (1.28e10 windowed comparisons on one host thread: ~35 s)."""
+    if engine.backend != "mfma":
+        pytest.skip("one backend is enough at this size (the VALU backend runs the 50 k and 30 k cases above)")
+    import bench
+
+    w, d, n_clusters, cluster_pairs = bench.make_dup_heavy(1_000_000)
+    got = engine.search_self_sorted(w, d, 350)
+    st, tm = engine.last_stats(), engine.last_timing()
+    assert st["n_hits"] == cluster_pairs == 6_590_299 and st["n_launches"] == 1
+    assert tm["hits_filtered"] > 6_000_000
+    # structure first (cheap, size-independent): disjoint groups, every member within tolerance of its group's target (last member)
+    seen = np.zeros(len(d), bool)
+    for g in got[::37]:
+        t = g[-1]
+        assert all(orc.hamming(w[t], w[m]) <= 350 for m in g[:-1]) and g[:-1] == sorted(g[:-1]) and all(m > t for m in g[:-1])
+    for g in got:
+        assert not seen[g].any()
+        seen[g] = True
+    assert seen.sum() == 100_000 and len(got) == n_clusters
+    assert got == orc.search_self_sorted(w, d, 350)

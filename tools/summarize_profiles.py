@@ -71,7 +71,7 @@ for k in summary.get("fetch_hash", {}):
     if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
         t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
                                                     "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
-for tag_, fd, wd in (("resize_mfma_frame_stream_kernel@1920x1080", "fetch_hd", "write_hd"),
+for tag_, fd, wd in (("resize_mfma_frame_wavestream_kernel@1920x1080", "fetch_hd", "write_hd"),
                      ("resize_mfma_frame_stream_kernel@480x270", "fetch_sd", "write_sd"),
                      ("resize_mfma_frame_ksplit_kernel@3840x2160", "fetch_uhd", "write_uhd")):
     for k in summary.get(fd, {}):

@@ -964,6 +964,122 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     write_pending();
 }
 
+// ---- linear-stream form, one 16-row block stream PER WAVE (round 3; wide band-class frames such as 1920 x 1080) -------------
+// The kernel above keeps ONE chunk per workgroup in flight.  For frames whose chunk holds only two 16-row blocks (1440..1984
+// columns: 32 rows = 60 KB) that is the bandwidth-delay product and nothing more - two of the four waves idle through every
+// product phase, and every bubble (barrier, DMA issue) shows: 1920 x 1080 stayed at 6.0-6.2 TB/s while 1280 x 720 (three blocks per
+// chunk) reached 6.4-6.6 with the same non-temporal loads.  Here every wave owns one 30 KB buffer and walks the frame's blocks
+// wave, wave + 4, ...: compute block i (30 K tiles from its own buffer), then DMA block i + 4 over it, wait for it alone
+// (s_waitcnt vmcnt(0): no workgroup barrier), compute ...  Up to four blocks (120 KB) are in flight per CU, the waves drift out of
+// phase by themselves, and the only barrier left is the LDS-only one at the end of a frame where the four vertical partial
+// sums meet (double-buffered by frame parity, so wave 0 adds and writes frame F while the others already stream frame F + G).
+// Same products in the same order per output as the other kernels (exact integers): bit-identical.  W % 16 == 0, rows at the
+// frame's own pitch (MODE 0 addressing), table in band form.
+template <int BUF_BYTES, int TAB_BYTES>
+__global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+                                                                           uint32_t H, size_t frame_stride,
+                                                                           size_t clip_stride, uint32_t n_frames,
+                                                                           MfmaResizeTables T, uint8_t *__restrict__ small)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
+    __shared__ int32_t s_part[2][3][64][4];  // [frame parity][wave 1..3]: 256 hi + lo
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t n_blk = (H + 15u) / 16u, frame_bytes = W * H;
+    const int32_t bias_h = T.bias_h[r16];
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    const uint32_t tab_vecs = (uint32_t)T.band_stride;  // 16 outputs x stride / 16 bytes
+    for (uint32_t i = tid; i < tab_vecs; i += 256u) {
+        const v4i v = T.bh[i];
+        s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    }
+    if (tid < 8) s_tab[tab_vecs + tid] = uint4{0, 0, 0, 0};
+    const uint32_t band_zero = 16u * tab_vecs;
+    const int32_t band_lo = T.band_meta[r16];
+    const uint32_t band_nt = (uint32_t)T.band_meta[16 + r16];
+    const uint32_t band_base = r16 * (uint32_t)T.band_stride + 16u * g;
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    uint4 *my = s_pxw[wave];
+    __syncthreads();  // the table is in place
+
+    auto issue_dma = [&](uint32_t F, uint32_t b) __attribute__((always_inline)) {
+        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
+        const uint32_t start = 16u * b * W, bytes = min(16u, H - 16u * b) * W;
+        for (uint32_t off = 0; off < bytes; off += 1024u) {
+            auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
+        }
+    };
+    uint32_t parity = 0;
+    uint32_t F = blockIdx.x;
+    if (F < n_frames && wave < n_blk) issue_dma(F, wave);
+    for (; F < n_frames; F += gridDim.x) {
+        v4i acc_vh = zero4, acc_vl = zero4;
+        const uint32_t Fn = F + gridDim.x;
+        for (uint32_t b = wave; b < n_blk; b += 4) {
+            // vertical fragments of this block's 64-row group (global loads: issued before the wait, consumed after the products)
+            const uint32_t rg = min(b >> 2, (uint32_t)T.n_rg - 1u);
+            const v4i avh = T.av[(rg * 2 + 0) * 64 + lane], avl = T.av[(rg * 2 + 1) * 64 + lane];
+            // This wave's own block has landed once the two fragments have: they were requested AFTER its DMA and VMEM returns in
+            // order.  An empty asm that reads them makes the COMPILER place the vmcnt wait here and know the fragments are in -
+            // with a hand-written s_waitcnt it kept its own wait in front of the vertical products below, i.e. behind the NEXT
+            // block's DMA, and the next fragments' load latency was exposed every block.
+            asm volatile("" ::"v"(avh), "v"(avl) : "memory");
+            v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * W + 16u * g;
+            auto tile = [&](int kt) __attribute__((always_inline)) {
+                const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
+                const v4i a = (v4i){(int)p.x, (int)p.y, (int)p.z, (int)p.w} ^ x80;
+                const uint32_t j = (uint32_t)(kt - band_lo);
+                const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
+                const uint4 th = *reinterpret_cast<const uint4 *>(q), tl = *reinterpret_cast<const uint4 *>(q + 64);
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
+            };
+            int kt = 0;
+            for (; kt + 3 < T.n_kt; kt += 4) { tile(kt); tile(kt + 1); tile(kt + 2); tile(kt + 3); }
+            for (; kt < T.n_kt; kt++) tile(kt);
+            // rows past the frame's end hold the previous block's bytes: their vertical coefficients are zero (as in every kernel)
+            const int val = (int)finalize4(ah, al, T.prec_h);
+            // the buffer is free: the products above consumed every LDS read of it.  Next block of this frame, or this wave's
+            // first block of the next frame - before the frame-end barrier, so the stream never drains
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (b + 4 < n_blk) issue_dma(F, b + 4);
+            else if (Fn < n_frames && wave < n_blk) issue_dma(Fn, wave);
+            const uint32_t mb = b & 3u;
+            v4i bb;
+#pragma unroll
+            for (int m = 0; m < 4; m++) bb[m] = mb == (uint32_t)m ? val : 0;
+            acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, bb, acc_vh, 0, 0, 0);
+            acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, bb, acc_vl, 0, 0, 0);
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_part[parity][wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: the DMA of the next frame's first blocks stays in flight
+        if (wave == 0) {
+            v4i vl = acc_vl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                vl[r] += bias_v[r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) vl[r] += s_part[parity][w][lane][r];
+            }
+            const uint32_t px = finalize4(acc_vh, vl, T.prec_v) ^ 0x80808080u;
+            uint8_t *dst = small + (size_t)F * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        }
+        parity ^= 1u;  // wave 0 reads parity p while the others may already write p ^ 1; p is written again only after the next barrier
+    }
+}
+
 template <int BUF, int TAB, bool BAND>
 static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
                                size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
@@ -1000,6 +1116,10 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     else if (cls == 2)
         launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                             frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+    else if (stream_pitch(w) == w && nb <= 2 && 16u * w + 128u <= (uint32_t)kWaveStreamBuf && !std::getenv("VDF_NO_WAVESTREAM"))
+        // two blocks per chunk (1328 .. 1920 columns at their own pitch): one block stream per wave keeps 4 x 30 KB in flight
+        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes>), dim3(std::min<uint32_t>(n_frames, (uint32_t)cus)),
+                           dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), small);
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);

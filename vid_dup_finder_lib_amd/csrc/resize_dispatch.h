@@ -16,12 +16,15 @@ namespace vdf {
 constexpr int kStreamBufS = 30 * 1024 + 128, kStreamTabS = 8;
 constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
 constexpr int kKsplitBuf = 75 * 1024 + 128;
+constexpr int kWaveStreamBuf = 16 * 1920 + 128;  // one 16-row block of a frame up to 1920 wide per wave (round 3: resize_mfma_frame_wavestream_kernel)
+constexpr int kWaveStreamTabBytes = 16 * (kMfmaBandMaxTiles * 128 + 32) + 128;  // band table + zero slot
 constexpr int kStreamPartBytes = 3 * 64 * 4 * 4;  // s_part: the vertical partial sums of waves 1..3
 constexpr int kLdsPerCu = 160 * 1024;
 static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
 static_assert(2 * (2 * kStreamBufS + kStreamTabS * 2048 + kStreamPartBytes) <= kLdsPerCu, "two S workgroups per CU");
 static_assert(2 * kStreamBufM + kStreamTabM * 2048 + kStreamPartBytes <= kLdsPerCu, "one M workgroup per CU");
 static_assert(2 * kKsplitBuf + 2 * 3 * 64 * 16 + kStreamPartBytes <= kLdsPerCu, "one K-split workgroup per CU");
+static_assert(4 * kWaveStreamBuf + kWaveStreamTabBytes + 2 * kStreamPartBytes <= kLdsPerCu, "one per-wave-stream workgroup per CU");
 
 // LDS row pitch of the stream kernel: the frame's own for multiples of 16 - unless it is a multiple of 256, where the 16
 // rows of a block would share one bank group (16-way conflict on every operand read: re-pitched, 768 / 1024 / 1280 wide
