@@ -677,7 +677,9 @@ def main():
                                "valu": {"achieved": lane_ops / (sv["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
                                         "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS,
                                         "note": "xor + bcnt lane-ops of rows < n_rows only (64 per full pair, 52 for a wave that "
-                                                "leaves after 832 bits); peak = 16 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz"},
+                                                "leaves after 832 bits; the kernel's other VALU work is not counted); peak = 16 lanes/clk/SIMD "
+                                                "x 1024 SIMDs x the NOMINAL 2.4 GHz (rocminfo's Max Clock): the kernel sits on the VALU issue "
+                                                "rate, so frac reads the box's real VALU clock / 2.4 GHz - 0.998 .. 1.005 over this round's boxes"},
                                "note": "XOR + v_bcnt over 32 dwords per pair, candidates streamed through SGPRs; same exact "
                                        "early exit; identical MatchGroups"}
         assert len(gv) == n_groups, "VALU and MFMA backends disagree"
