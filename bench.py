@@ -766,7 +766,7 @@ def main():
                                             "hashing half), log-uniform durations, +-5 % windows, half of the references planted; the "
                                             "candidate database pinned (vdf_ctx_pin_database), as when one cache is searched repeatedly",
                                 "pairs": sr["pairs"], "pairs_computed": sr["pairs_computed"],
-                                "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "kernel_ms": k_pin,
+                                "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "workgroups": sr["n_tiles"], "kernel_ms": k_pin,
                                 "ms": w_pin * 1e3, "hits": nh, "pairs_per_s": sr["pairs"] / w_pin, "timing": t_pin,
                                 "unpinned": {"ms": w_un * 1e3, "kernel_ms": k_un, "timing": t_un,
                                              "note": "every call expands the candidate database again (0.15 ms per million hashes)"}}

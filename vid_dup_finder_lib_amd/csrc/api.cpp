@@ -76,6 +76,7 @@ bool is_sorted_u32(const uint32_t *d, size_t n)
 // Shared core of both searches: windows + tiles, distance kernel, hit download (sorted by (row, col)).
 constexpr size_t kPinSmallBytes = 4u << 20;
 constexpr uint64_t kDeviceSortHits = 1u << 17;
+constexpr uint32_t kRefsMinWorkgroups = 2048;  // a reference search with fewer (tile, chunk) workgroups than this narrows its chunks
 constexpr uint64_t kSpecSortHits = 1u << 14;    // hit lists expected to be at least this long are sorted on the device speculatively
 constexpr uint64_t kFilterHits = 1u << 16;      // from this many hits on, a replay-only launch drops the rows that cannot become targets  // hit lists from this length on are sorted on the device
 
@@ -211,8 +212,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         }
     }
     // counters[0..2] = 0, overflow_row = UINT32_MAX
-    unsigned long long init[8] = {0, 0, 0, 0, 0xFFFFFFFFull, 0, 0, 0};
-    VDF_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+    const unsigned long long init[8] = {0, 0, 0, 0, 0xFFFFFFFFull, 0, 0, 0};
     // How much of the hit list is fetched together with the counters (one synchronisation instead of two): about what the
     // previous call produced.  From 16 k pairs on that head is also put into (row, col) order on the device BEFORE its
     // length is known: the slots are pre-filled with 0xFF (sorts last), so if the list fits the head the host receives it
@@ -222,18 +222,40 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     if (!pin_ok || spec * sizeof(vdf_hit) > kPinSmallBytes) spec = 0;  // long lists go straight to the caller's buffer, once their length is known
     const bool spec_sort = spec && ctx->hits_guess >= kSpecSortHits;
     if (spec_sort) VDF_HIP(ctx, hipMemsetAsync(ctx->hits.p, 0xFF, (size_t)spec * sizeof(vdf_hit), stream));
-    VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
-                                           row_begin, row_end, shard_index, shard_count, L, stream));
-    // workgroup count, sortedness flag and admitted pairs come back through pinned memory (a pageable destination would make
-    // each of the copies a blocking round trip of its own)
+    // A reference search's workgroups are (256-row tile, chunk of its rows' united +-5 % windows): how many there are is only known
+    // once the windows are.  With the chunk width picked for a full rectangle the BASELINE configs[4] shape ends up with ~600
+    // workgroups of very different lengths for 512 resident slots (kernel 0.88 ms); 8192-column chunks give ~2500 and 0.73 ms
+    // (gpurun_out/r03m).  So: if the first pass yields too few, the chunks are halved until there would be enough and the windows /
+    // tile kernels run once more (60 us); the width is remembered for the next search of the same shape.  search() keeps its long
+    // chunks: its 512-row workgroups pay 208 KB of target loads each, and narrower chunks measured slower at every width.
+    const bool adapt_refs = mode == 1 && mfma && ctx->mfma_chunk_cols == 0;
+    if (adapt_refs && ctx->refs_hint_cols == n_cols && ctx->refs_hint_rows == n_rows && ctx->refs_hint_chunk) L.chunk_cols = ctx->refs_hint_chunk;
     if (!ctx->pin_ctrl.reserve(256)) return fail(ctx, VDF_E_OOM, "pinned staging");
     unsigned long long *pre = ctx->pin_ctrl.as<unsigned long long>() + 8;
-    VDF_HIP(ctx, hipMemcpyAsync(pre, L.counters, 64, hipMemcpyDeviceToHost, stream));
-    VDF_HIP(ctx, hipMemcpyAsync(pre + 8, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
-                                hipMemcpyDeviceToHost, stream));
-    VDF_HIP(ctx, hipStreamSynchronize(stream));
-    const uint32_t total_tiles = *reinterpret_cast<const uint32_t *>(pre + 8);
-    const unsigned long long unsorted = pre[5], admitted = pre[2];
+    uint32_t total_tiles = 0;
+    unsigned long long unsorted = 0, admitted = 0;
+    for (int pass = 0;; pass++) {
+        VDF_HIP(ctx, hipMemcpyAsync(ctx->counters.p, init, sizeof init, hipMemcpyHostToDevice, stream));
+        VDF_HIP(ctx, vdf::launch_windows_tiles(mode, d_col_dur, (uint32_t)n_cols, d_row_dur, d_row_perm, (uint32_t)n_rows,
+                                               row_begin, row_end, shard_index, shard_count, L, stream));
+        // workgroup count, sortedness flag and admitted pairs come back through pinned memory (a pageable destination would
+        // make each of the copies a blocking round trip of its own)
+        VDF_HIP(ctx, hipMemcpyAsync(pre, L.counters, 64, hipMemcpyDeviceToHost, stream));
+        VDF_HIP(ctx, hipMemcpyAsync(pre + 8, mfma ? L.group_offset + L.n_groups : L.tile_offset + L.n_row_tiles, 4,
+                                    hipMemcpyDeviceToHost, stream));
+        // (the grouped grid of the matrix-core backend counts every (tile, chunk) of a group's rectangle; the workgroups that
+        // have work are the sum of the tiles' own chunk counts)
+        VDF_HIP(ctx, hipMemcpyAsync(pre + 9, L.tile_offset + L.n_row_tiles, 4, hipMemcpyDeviceToHost, stream));
+        VDF_HIP(ctx, hipStreamSynchronize(stream));
+        total_tiles = *reinterpret_cast<const uint32_t *>(pre + 8);
+        const uint32_t busy_tiles = *reinterpret_cast<const uint32_t *>(pre + 9);
+        unsorted = pre[5];
+        admitted = pre[2];
+        if (!adapt_refs || pass > 0 || unsorted || busy_tiles == 0 || busy_tiles >= kRefsMinWorkgroups || L.chunk_cols <= 4096) break;
+        uint64_t est = busy_tiles;
+        while (L.chunk_cols > 4096 && est < kRefsMinWorkgroups) { L.chunk_cols /= 2; est *= 2; }
+    }
+    if (adapt_refs) { ctx->refs_hint_cols = n_cols; ctx->refs_hint_rows = n_rows; ctx->refs_hint_chunk = L.chunk_cols; }
     // the windows are binary searches over the candidate durations (search_algorithm.rs:93-117,173-185 rely on Search::sort)
     if (unsorted) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");

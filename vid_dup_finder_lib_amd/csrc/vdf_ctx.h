@@ -110,6 +110,8 @@ struct vdf_ctx {
     const void *pinned_db = nullptr;  // vdf_ctx_pin_database: the caller promises these n x 16 words do not change until unpinned
     size_t pinned_n = 0;
     ExpOwner exp_owner;
+    size_t refs_hint_cols = 0, refs_hint_rows = 0;  // shape of the last reference search and the chunk width it settled on
+    uint32_t refs_hint_chunk = 0;
     bool no_hit_filter = false;  // VDF_NO_HIT_FILTER: host-level search() downloads and replays every thresholded pair
     uint64_t hits_guess = 0;  // hits of the previous launch: how much of the list is fetched together with the counters
     PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)
