@@ -60,7 +60,7 @@ int main()
             else assert(m.operand.size() == (size_t)16 * m.band_stride && m.band_meta.size() == 32 && m.bias.size() == 16);
         }
     }
-    // the search path's radix sorts against the standard library, on both sides of their small-input cut-over
+    // the search path's host radix sort against the standard library, on both sides of its small-input cut-over
     for (size_t n : std::vector<size_t>{0, 1, 2, 100, 4095, 4096, 5000, 70000}) {
         std::vector<vdf_hit> h(n), want;
         const uint32_t rows = 1u + (uint32_t)(rng() % 200000), cols = 1u + (uint32_t)(rng() % 2000000);
@@ -70,13 +70,6 @@ int main()
         std::sort(want.begin(), want.end(), [](const vdf_hit &a, const vdf_hit &b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
         vdf_impl::sort_hits(h.data(), n);
         assert(n == 0 || std::memcmp(h.data(), want.data(), n * sizeof(vdf_hit)) == 0);
-        std::vector<uint32_t> keys(n), perm(n), ref(n);
-        const uint32_t span = (n % 3 == 0) ? 0xFFFFFFFFu : 7200u;  // durations are small; the full range takes all three passes
-        for (auto &k : keys) k = (uint32_t)(rng() % (span ? span : 1u));
-        std::iota(ref.begin(), ref.end(), 0u);
-        std::stable_sort(ref.begin(), ref.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-        vdf_impl::stable_argsort_u32(keys.data(), n, perm.data());
-        assert(perm == ref);
     }
     std::puts("sanitize ok");
     return 0;

@@ -635,10 +635,6 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
 // of one lane: row R0 + 2 G + j = even[2 j] + odd[2 j + 1], no cross-lane traffic.  A lane therefore ends up with
 // rows 8 oct + 2 G + {0, 1} of every octet of a 64-row group - the k order of the vertical product is free, its
 // coefficient operand is simply built in that order (kMfmaLayoutVerticalWide).  Bit-identical to the other kernels.
-#ifdef VDF_DEBUG_WIDE
-__device__ v4i g_dbg_b[64];
-__device__ v4i g_dbg_acc[4][64];
-#endif
 template <bool CAREFUL>
 __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src, uint32_t W, uint32_t H,
                                                  const uint8_t *buf_end, const MfmaResizeTables &T, int q_begin,
@@ -703,9 +699,6 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
         }
         if (w == n_win - 1) {  // quad complete: its 32 tmp rows -> two bytes per octet in this lane's vertical operand
             const int qh = q & 1;
-#ifdef VDF_DEBUG_WIDE
-            if (blockIdx.x == 0) { g_dbg_acc[0][lane] = eh[1]; g_dbg_acc[1][lane] = el[1]; g_dbg_acc[2][lane] = oh[1]; g_dbg_acc[3][lane] = ol[1]; }
-#endif
 #pragma unroll
             for (int oct = 0; oct < 4; oct++) {
                 // rows 2G and 2G + 1 of the octet: even-tile part in registers 0 / 2, odd-tile part in registers 1 / 3
@@ -720,9 +713,6 @@ __device__ __forceinline__ void resize_row_quads(const uint8_t *__restrict__ src
             reset_acc();
             if (qh == 1 || !more) {  // last quad this wave owns in the 64-row group
                 const int rg = q >> 1;
-#ifdef VDF_DEBUG_WIDE
-                if (blockIdx.x == 0) g_dbg_b[lane] = b;
-#endif
                 acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 0) * 64 + lane], b, acc_vh, 0, 0, 0);
                 acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(T.av[(rg * 2 + 1) * 64 + lane], b, acc_vl, 0, 0, 0);
                 b = zero4;

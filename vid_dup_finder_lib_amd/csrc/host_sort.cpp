@@ -2,7 +2,6 @@
 
 #include <algorithm>
 #include <cstring>
-#include <numeric>
 #include <vector>
 
 namespace vdf_impl {
@@ -25,25 +24,6 @@ void sort_hits(vdf_hit *hits, size_t n)
         std::swap(src, dst);
     }
     if (src != hits) std::memcpy(hits, src, n * sizeof(vdf_hit));
-}
-
-void stable_argsort_u32(const uint32_t *keys, size_t n, uint32_t *perm)
-{
-    std::iota(perm, perm + n, 0u);
-    std::vector<uint32_t> tmp_v(n);
-    uint32_t *src = perm, *dst = tmp_v.data();
-    uint32_t all_or = 0, all_and = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; i++) { all_or |= keys[i]; all_and &= keys[i]; }
-    for (int shift = 0; shift < 32; shift += 11) {
-        const uint32_t mask = 0x7FFu;
-        if ((((all_or ^ all_and) >> shift) & mask) == 0) continue;  // every key has the same digit here
-        size_t count[2049] = {0};
-        for (size_t i = 0; i < n; i++) count[((keys[src[i]] >> shift) & mask) + 1]++;
-        for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
-        for (size_t i = 0; i < n; i++) dst[count[(keys[src[i]] >> shift) & mask]++] = src[i];
-        std::swap(src, dst);
-    }
-    if (src != perm) std::memcpy(perm, src, n * 4);
 }
 
 }  // namespace vdf_impl
