@@ -81,10 +81,22 @@ int main()
         const int cls = stream_class(q.w, &nb);
         CHECK(cls == q.cls && nb == q.nb, "w=%u: class %d nb %u, expected %d %u", q.w, cls, nb, q.cls, q.nb);
     }
-    for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u, 240u, 160u, 128u})
+    for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u, 240u, 160u, 128u, 1536u, 1792u})  // 1536 / 1792: per-wave block streams (round 3)
         CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should stream by default", w);
-    for (uint32_t w : {1536u, 2048u, 3840u, 48u, 63u})
+    for (uint32_t w : {2048u, 3840u, 48u, 63u})
         CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should not stream by default", w);
+    // the per-wave block streams: band-class widths with at most two blocks per chunk whose re-pitched block fits a wave's buffer
+    for (uint32_t w = 1; w <= 4200; w++) {
+        uint32_t nb = 0;
+        const int cls = stream_class(w, &nb);
+        if (resize_wavestream_applies(w)) {
+            CHECK(cls == 3 && nb <= 2 && w >= 1280 && w <= 1920, "wave-stream width w=%u cls=%d nb=%u", w, cls, nb);
+            CHECK(16 * stream_pitch(w) + 128 <= (uint32_t)kWaveStreamBuf && 4 * kWaveStreamBuf + kWaveStreamTabBytes + 2 * kStreamPartBytes <= kLdsPerCu,
+                  "wave-stream block fits w=%u", w);
+        }
+    }
+    for (uint32_t w : {1360u, 1366u, 1440u, 1536u, 1600u, 1680u, 1792u, 1904u, 1920u}) CHECK(resize_wavestream_applies(w), "%u wide takes the per-wave streams", w);
+    for (uint32_t w : {1280u, 1024u, 1921u, 1936u, 1984u, 2048u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
     uint32_t kp = 0;
     CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");
     CHECK(ksplit_geometry(2048, &kp) == 2 && kp == 2064, "2048 wide: two blocks per chunk");

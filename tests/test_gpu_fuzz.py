@@ -255,8 +255,8 @@ def test_hash_fuzz_wide_frames(seed):
 
 _SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
     ("K-split 2048", 300, 2048, 24, False), ("K-split 3840", 200, 3840, 12, False), ("stream 1024 (re-pitched)", 300, 1024, 32, False),
-    ("stream 422 (shifted)", 240, 422, 40, False), ("wave-stream 1920", 300, 1920, 24, False), ("wave-stream 1440", 200, 1440, 40, False), ("stream band 1984", 200, 1984, 24, False), ("stream 480", 270, 480, 40, False),
-    ("whole-line 1536", 200, 1536, 24, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
+    ("stream 422 (shifted)", 240, 422, 40, False), ("wave-stream 1920", 300, 1920, 24, False), ("wave-stream 1440", 200, 1440, 40, False), ("wave-stream 1366 (shifted)", 200, 1366, 40, False), ("wave-stream 1536 (re-pitched)", 200, 1536, 24, False), ("stream band 1984", 200, 1984, 24, False), ("stream 480", 270, 480, 40, False),
+    ("whole-line 2000", 200, 2000, 20, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
     ("cropped stream 854", 480, 854, 24, True), ("cropped stream 480", 270, 480, 40, True), ("cropped whole-line 1280", 360, 1280, 16, True),
 ]
 

@@ -126,7 +126,8 @@ def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
                                    (360, 600, 3), (480, 854, 2), (240, 426, 40), (300, 500, 3), (256, 333, 3), (768, 1366, 1),
                                    (360, 640, 3), (432, 768, 2), (720, 1280, 1), (1080, 1920, 1), (300, 1984, 1), (300, 2000, 1),
                                    (426, 240, 40), (144, 176, 40), (200, 160, 3), (256, 192, 3), (256, 128, 3), (300, 200, 3), (333, 64, 3), (200, 80, 3),
-                                   (900, 1600, 1), (576, 1024, 1), (136, 1440, 40), (150, 1920, 36), (1080, 1904, 1)])
+                                   (900, 1600, 1), (576, 1024, 1), (136, 1440, 40), (150, 1920, 36), (1080, 1904, 1), (140, 1366, 40), (200, 1536, 24), (130, 1792, 24), (300, 1916, 2),
+                                   (144, 1300, 36), (768, 1534, 1)])
 def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     """Tightly packed frames whose every frame starts on a 16-byte boundary go through the linear-stream kernel (LDS-DMA of
     whole chunks, operands read back from LDS) when the width is not a multiple of the 128-byte line, or is one and still
@@ -140,7 +141,8 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     240 / 176 / 160 / 192 / 128 / 200 / 64 / 80 wide = narrow tall frames (portrait video), one to four K tiles.
     1360 ... 1920 wide at their own pitch = the per-wave block streams of round 3 (resize_mfma_frame_wavestream_kernel): 40 clips of
     136 x 1440 and 36 of 150 x 1920 = more frames than workgroups (frame boundaries, the parity-doubled partial sums), 9 or 10 blocks
-    per frame (uneven shares of the four waves, a partial last block)."""
+    per frame (uneven shares of the four waves, a partial last block); 1366 / 1534 / 1300 wide = those streams with rows re-pitched by the
+    DMA (1366, 1534: row starts off a dword), 1536 / 1792 = line-aligned pitches that took the whole-line kernel before round 3."""
     import vid_dup_finder_lib_amd as vdf
 
     monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))

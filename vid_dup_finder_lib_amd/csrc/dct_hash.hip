@@ -965,11 +965,13 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 // sums meet (double-buffered by frame parity, so wave 0 adds and writes frame F while the others already stream frame F + G).
 // Same products in the same order per output as the other kernels (exact integers): bit-identical.  W % 16 == 0, rows at the
 // frame's own pitch (MODE 0 addressing), table in band form.
-template <int BUF_BYTES, int TAB_BYTES>
+// MODE as in the kernel above: 0 = rows at the frame's own pitch (W % 16 == 0), 1 / 2 = rows re-pitched by the DMA to Wp (an odd
+// multiple of 16 bytes; 2 = row starts that are not dword-aligned: one more dword per operand read and a per-lane byte shift).
+template <int BUF_BYTES, int TAB_BYTES, int MODE>
 __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                            uint32_t H, size_t frame_stride,
                                                                            size_t clip_stride, uint32_t n_frames,
-                                                                           MfmaResizeTables T, uint8_t *__restrict__ small)
+                                                                           MfmaResizeTables T, uint32_t Wp, uint8_t *__restrict__ small)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
     __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
@@ -996,13 +998,31 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
     uint4 *my = s_pxw[wave];
     __syncthreads();  // the table is in place
 
+    // MODE 1, 2: where this lane's first DMA instruction of a block lands (LDS position 16 lane = row * Wp + x) and how far an
+    // instruction (1024 bytes of LDS further) moves it
+    uint32_t lane_x0 = 0, lane_ro0 = 0;
+    const uint32_t step_rows = MODE ? 1024u / Wp : 0u, step_x = MODE ? 1024u - step_rows * Wp : 0u;
+    if constexpr (MODE != 0) {
+        const uint32_t P0 = 16u * lane, row0 = P0 / Wp;
+        lane_x0 = P0 - row0 * Wp;
+        lane_ro0 = row0 * W;
+    }
+    const uint32_t shift = MODE == 2 ? (r16 * W) & 3u : 0u;  // blocks start on multiples of 16 rows: (row * W) & 3 is the frame row's
     auto issue_dma = [&](uint32_t F, uint32_t b) __attribute__((always_inline)) {
         const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = 16u * b * W, bytes = min(16u, H - 16u * b) * W;
+        const uint32_t start = 16u * b * W, bytes = min(16u, H - 16u * b) * Wp;
+        uint32_t x = lane_x0, ro = lane_ro0;
         for (uint32_t off = 0; off < bytes; off += 1024u) {
             auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
+            if constexpr (MODE == 0) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, VDF_STREAM_AUX);
+                x += step_x;
+                ro += step_rows * W;
+                if (x >= Wp) { x -= Wp; ro += W; }
+            }
         }
     };
     uint32_t parity = 0;
@@ -1021,10 +1041,18 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
             // block's DMA, and the next fragments' load latency was exposed every block.
             asm volatile("" ::"v"(avh), "v"(avl) : "memory");
             v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
-            const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * W + 16u * g;
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * Wp + 16u * g;
             auto tile = [&](int kt) __attribute__((always_inline)) {
                 const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
-                const v4i a = (v4i){(int)p.x, (int)p.y, (int)p.z, (int)p.w} ^ x80;
+                v4i a = {(int)p.x, (int)p.y, (int)p.z, (int)p.w};
+                if constexpr (MODE == 2) {
+                    const uint32_t nx = *reinterpret_cast<const uint32_t *>(base + 64 * kt + 16);
+                    a[0] = (int)__builtin_amdgcn_alignbyte(p.y, p.x, shift);
+                    a[1] = (int)__builtin_amdgcn_alignbyte(p.z, p.y, shift);
+                    a[2] = (int)__builtin_amdgcn_alignbyte(p.w, p.z, shift);
+                    a[3] = (int)__builtin_amdgcn_alignbyte(nx, p.w, shift);
+                }
+                a = a ^ x80;
                 const uint32_t j = (uint32_t)(kt - band_lo);
                 const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
                 const uint4 th = *reinterpret_cast<const uint4 *>(q), tl = *reinterpret_cast<const uint4 *>(q + 64);
@@ -1106,10 +1134,19 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     else if (cls == 2)
         launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                             frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
-    else if (stream_pitch(w) == w && nb <= 2 && 16u * w + 128u <= (uint32_t)kWaveStreamBuf && !std::getenv("VDF_NO_WAVESTREAM"))
-        // two blocks per chunk (1328 .. 1920 columns at their own pitch): one block stream per wave keeps 4 x 30 KB in flight
-        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes>), dim3(std::min<uint32_t>(n_frames, (uint32_t)cus)),
-                           dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), small);
+    else if (resize_wavestream_applies(w) && !std::getenv("VDF_NO_WAVESTREAM")) {
+        // two blocks per chunk (1328 .. 1920 columns): one block stream per wave keeps 4 x 30 KB in flight
+        const uint32_t wp = stream_pitch(w), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
+        if (wp == w)
+            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 0>), dim3(grid), dim3(256), 0, stream,
+                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
+        else if (w % 4 == 0)
+            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 1>), dim3(grid), dim3(256), 0, stream,
+                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
+        else
+            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 2>), dim3(grid), dim3(256), 0, stream,
+                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
+    }
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);

@@ -37,6 +37,12 @@ bool resize_stream_wants_band(uint32_t w)
     return stream_class(w, &nb) == 3;
 }
 
+bool resize_wavestream_applies(uint32_t w)
+{
+    uint32_t nb = 0;
+    return stream_class(w, &nb) == 3 && nb <= 2 && 16u * stream_pitch(w) + 128u <= (uint32_t)kWaveStreamBuf;
+}
+
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too)
 {
@@ -50,7 +56,8 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     const int cls = stream_class(w, &nb);
     if (cls == 0) return false;
     const bool repitched_whole_table = stream_pitch(w) != w && cls == 2;  // 1024 wide: 48-row chunks of 50 KB, 5.8 against 5.4 TB/s
-    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) || aligned_too;
+    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) ||
+           resize_wavestream_applies(w) || aligned_too;  // (1536 / 1792 wide: the per-wave block streams of round 3)
 }
 
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)

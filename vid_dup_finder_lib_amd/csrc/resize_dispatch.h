@@ -36,7 +36,10 @@ uint32_t stream_pitch(uint32_t w);
 uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes);
 // which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
 int stream_class(uint32_t w, uint32_t *nb);
-bool resize_stream_wants_band(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
+bool resize_stream_wants_band(uint32_t w);
+// band-class widths whose chunk would hold at most two 16-row blocks and whose (re-pitched) block fits a per-wave buffer:
+// resize_mfma_frame_wavestream_kernel takes them (1328 .. 1920 columns)
+bool resize_wavestream_applies(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
 // Frames starting on 16-byte boundaries, rows packed inside a frame (frames and clips may be padded).  Widths that are a
 // multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
 // kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1536 wide - 2 % with 48 KB chunks);
