@@ -40,6 +40,8 @@ bool resize_stream_wants_band(uint32_t w)
 bool resize_wavestream_applies(uint32_t w)
 {
     uint32_t nb = 0;
+    // two blocks per chunk only: with three (1040 .. 1312 columns) the chunk kernel keeps three waves busy and 62 KB in flight, and the
+    // per-wave form measured SLOWER (1280 x 720 6.63 -> 5.78 TB/s, 1056 x 594 6.45 -> 5.94; gpurun_out/r03q)
     return stream_class(w, &nb) == 3 && nb <= 2 && 16u * stream_pitch(w) + 128u <= (uint32_t)kWaveStreamBuf;
 }
 
