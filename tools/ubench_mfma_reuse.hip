@@ -36,20 +36,25 @@ __device__ __forceinline__ void mfma_a(v16f &acc, const v4i &a, const v4i &b)
 
 __device__ __forceinline__ void home_agpr(v4i &x) { asm volatile("" : "+a"(x)); }
 
+// modes 5..8: mode 0's shape with other fp4 codes for a set bit (does the VALUE of the non-zero operand matter to the energy?):
+//   5 = 0x1 (0.5, the subnormal) for A and B, 6 = 0x4 (2.0), 7 = 0x6 (4.0), 8 = A 0x2 (1.0) with B 0x1 (0.5)
 template <int MODE>
-__global__ __launch_bounds__(MODE <= 1 ? 512 : 256, 1) void mfma_loop(const uint4 *__restrict__ data, uint32_t iters, float *out)
+__global__ __launch_bounds__((MODE <= 1 || MODE >= 5) ? 512 : 256, 1) void mfma_loop(const uint4 *__restrict__ data, uint32_t iters, float *out)
 {
-    constexpr int TILES = MODE <= 1 ? 2 : MODE == 3 ? 6 : 4;
+    constexpr int TILES = (MODE <= 1 || MODE >= 5) ? 2 : MODE == 3 ? 6 : 4;
+    constexpr uint32_t kMaskA = MODE == 5 ? 0x11111111u : MODE == 6 ? 0x44444444u : MODE == 7 ? 0x66666666u : 0x22222222u;
+    constexpr uint32_t kMaskB = (MODE == 5 || MODE == 8) ? 0x11111111u : MODE == 6 ? 0x44444444u : MODE == 7 ? 0x66666666u : 0x22222222u;
     constexpr int K = 13;
     constexpr int NA = TILES * K;
     constexpr int N_AGPR = MODE == 2 ? NA : MODE == 3 ? 64 : 0;  // fragments handed over as AGPR operands
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v4i a[NA], b[8];
     const uint4 *p = data + ((size_t)(blockIdx.x * 8 + wave) * 64 + lane) * 96;
+    auto code = [](uint32_t w, uint32_t mask) { uint32_t b = (w >> 1) & 0x11111111u; return (mask == 0x66666666u) ? (b << 1 | b << 2) : (mask == 0x44444444u) ? b << 2 : (mask == 0x22222222u) ? b << 1 : b; };
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const uint4 v = p[i]; a[i] = (v4i){(int)(v.x & 0x22222222u), (int)(v.y & 0x22222222u), (int)(v.z & 0x22222222u), (int)(v.w & 0x22222222u)}; }
+    for (int i = 0; i < NA; i++) { const uint4 v = p[i]; a[i] = (v4i){(int)code(v.x, kMaskA), (int)code(v.y, kMaskA), (int)code(v.z, kMaskA), (int)code(v.w, kMaskA)}; }
 #pragma unroll
-    for (int i = 0; i < 8; i++) { const uint4 v = p[88 + i]; b[i] = (v4i){(int)(v.x & 0x22222222u), (int)(v.y & 0x22222222u), (int)(v.z & 0x22222222u), (int)(v.w & 0x22222222u)}; }
+    for (int i = 0; i < 8; i++) { const uint4 v = p[88 + i]; b[i] = (v4i){(int)code(v.x, kMaskB), (int)code(v.y, kMaskB), (int)code(v.z, kMaskB), (int)code(v.w, kMaskB)}; }
     // Make the AGPR half the fragments' HOME: an empty asm that ties the value to an accumulator-register operand turns it into
     // an AGPR-class value from here on.  Without it the register allocator keeps the loop-invariant fragments in VGPRs and copies
     // each one into a shuttle AGPR (4 v_accvgpr_write) before every use.
@@ -95,20 +100,27 @@ int main(int argc, char **argv)
     hipMalloc(&d, n_vec * 16); hipMalloc(&o, 4096);
     hipMemcpy(d, h.data(), n_vec * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char *names[5] = {"2 tiles, 2 waves/SIMD, k-step-major (B x2)  ", "2 tiles, 2 waves/SIMD, tile-major (B x1)     ",
+    const char *names[9] = {"2 tiles, 2 waves/SIMD, k-step-major (B x2)  ", "2 tiles, 2 waves/SIMD, tile-major (B x1)     ",
                             "4 tiles, 1 wave/SIMD, B x4, A in AGPRs       ", "6 tiles, 1 wave/SIMD, B x6, A 64 AGPR + 14 V ",
-                            "4 tiles, 1 wave/SIMD, B x4, A compiler-placed"};
+                            "4 tiles, 1 wave/SIMD, B x4, A compiler-placed", "mode 0 with set bit = 0x1 (0.5)             ",
+                            "mode 0 with set bit = 0x4 (2.0)             ", "mode 0 with set bit = 0x6 (4.0)             ",
+                            "mode 0 with A 0x2 (1.0), B 0x1 (0.5)        "};
     for (int rep = 0; rep < 2; rep++)
-        for (int mode = 0; mode < 5; mode++) {
-            const int tiles = mode <= 1 ? 2 : mode == 3 ? 6 : 4, waves_per_simd = mode <= 1 ? 2 : 1;
-            const uint32_t n = iters * 2 / tiles * (mode <= 1 ? 1 : 2);  // the same MFMA count per SIMD in every mode
+        for (int mode = 0; mode < 9; mode++) {
+            const bool two = mode <= 1 || mode >= 5;
+            const int tiles = two ? 2 : mode == 3 ? 6 : 4, waves_per_simd = two ? 2 : 1;
+            const uint32_t n = iters * 2 / tiles * (two ? 1 : 2);  // the same MFMA count per SIMD in every mode
             auto launch = [&](uint32_t k) {
                 switch (mode) {
                 case 0: hipLaunchKernelGGL(mfma_loop<0>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
                 case 1: hipLaunchKernelGGL(mfma_loop<1>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
                 case 2: hipLaunchKernelGGL(mfma_loop<2>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
                 case 3: hipLaunchKernelGGL(mfma_loop<3>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
-                default: hipLaunchKernelGGL(mfma_loop<4>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
+                case 4: hipLaunchKernelGGL(mfma_loop<4>, dim3(n_cu), dim3(256), 0, 0, d, k, o); break;
+                case 5: hipLaunchKernelGGL(mfma_loop<5>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
+                case 6: hipLaunchKernelGGL(mfma_loop<6>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
+                case 7: hipLaunchKernelGGL(mfma_loop<7>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
+                default: hipLaunchKernelGGL(mfma_loop<8>, dim3(n_cu), dim3(512), 0, 0, d, k, o); break;
                 }
             };
             launch(n / 10);
