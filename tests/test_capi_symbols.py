@@ -139,3 +139,19 @@ def test_groups_from_ref_hits_and_empty():
     assert ve.groups_from_ref_hits(hits) == [(2, [5, 9]), (7, [1])]
     assert ve.groups_from_ref_hits(np.zeros((0, 2), np.uint32)) == []
     assert ve.finish_self(ve.replay_self(10, np.zeros((0, 2), np.uint32))) == []
+
+
+def test_host_hit_sort_matches_lexsort():
+    """vdf_sort_hits (host radix sort on row || col) on both sides of its small-input cut-over, with duplicates and extreme values."""
+    from vid_dup_finder_lib_amd import engine as ve
+
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 4095, 4096, 100_000):
+        h = np.stack([rng.integers(0, 50_000, size=n), rng.integers(0, 2**32, size=n)], axis=1).astype(np.uint32).reshape(-1, 2)
+        if n > 4:
+            h[0] = (0xFFFFFFFF, 0xFFFFFFFF)
+            h[1] = (0, 0)
+            h[2] = h[3]
+        got = ve.sort_hits(h.copy())
+        want = h[np.lexsort((h[:, 1], h[:, 0]))] if n else h
+        assert np.array_equal(got, want), n

@@ -354,3 +354,39 @@ def test_pinned_database_reuses_its_expansion_and_never_goes_stale(engine):
     torch.cuda.synchronize()
     pick = np.random.default_rng(77).choice(len(d), size=2000, replace=False)
     assert refs(w2[pick], d[pick], 350) == orc.search_refs_sorted(w2, d, w2[pick], d[pick], 350)
+
+
+@pytest.mark.parametrize("n", [1, 2, 1000, 70_000, 300_001])
+def test_device_sort_order_is_search_sort(engine, n):
+    """vdf_sort_order_device = Search::sort (search_algorithm.rs:55-61: stable sort_by_key on (duration, src_path)) for entries that
+    stay in HBM: durations with many ties, path ranks with ties (equal paths keep input order), and without ranks (all paths equal:
+    stable by duration); vdf_apply_order_device gathers hashes and durations into that order.  Checked against the oracle's
+    sort_order on real path strings (Rust's component-wise PathBuf order) and numpy's stable lexsort."""
+    import torch
+
+    rng = np.random.default_rng(n)
+    dur = rng.integers(0, 40 if n < 100_000 else 7200, size=n).astype(np.uint32)
+    if n > 10:
+        dur[rng.choice(n, size=n // 10, replace=False)] = np.uint32(4_000_000_000)  # large keys: every radix digit is live
+    names = [f"dir{int(rng.integers(0, 7))}/sub.{int(rng.integers(0, 3))}/v{int(rng.integers(0, max(2, n // 3)))}.mp4" for _ in range(n)]
+    order_by_path = sorted(set(names), key=orc.rust_path_key)
+    rank_of = {p: i for i, p in enumerate(order_by_path)}
+    rank = np.array([rank_of[p] for p in names], np.uint32)
+    want = np.array(orc.sort_order(dur.tolist(), names), np.int64) if n <= 70_000 else np.lexsort((np.arange(n), rank, dur))
+    assert np.array_equal(want, np.lexsort((np.arange(n), rank, dur)))
+    w = hg.random_hashes(rng, n)
+    t_d = torch.from_numpy(dur.view(np.int32).copy()).cuda()
+    t_r = torch.from_numpy(rank.view(np.int32).copy()).cuda()
+    t_w = torch.from_numpy(w.view(np.int64).copy()).cuda()
+    perm = torch.zeros(n, dtype=torch.int32, device="cuda")
+    w_out, d_out = torch.zeros_like(t_w), torch.zeros_like(t_d)
+    torch.cuda.synchronize()
+    engine.sort_order_device(t_d.data_ptr(), n, perm.data_ptr(), d_path_rank=t_r.data_ptr())
+    engine.apply_order_device(t_w.data_ptr(), t_d.data_ptr(), perm.data_ptr(), n, w_out.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    got = perm.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(got, want)
+    assert np.array_equal(w_out.cpu().numpy().view(np.uint64), w[want]) and np.array_equal(d_out.cpu().numpy().view(np.uint32), dur[want])
+    engine.sort_order_device(t_d.data_ptr(), n, perm.data_ptr())  # no ranks: all paths equal
+    torch.cuda.synchronize()
+    assert np.array_equal(perm.cpu().numpy().view(np.uint32).astype(np.int64), np.argsort(dur, kind="stable"))
