@@ -106,4 +106,7 @@ extern "C" {
         d_durations_out: *mut u32, stream: *mut c_void,
     ) -> c_int;
     pub fn vdf_sort_hits(hits: *mut vdf_hit, n_hits: u64) -> c_int;
+    // A promise that the resident database (d_hashes, n) does not change until the next call: reference searches against it reuse
+    // its operand expansion.  Null withdraws the promise.
+    pub fn vdf_ctx_pin_database(ctx: *mut vdf_ctx, d_hashes: *const u64, n: usize) -> c_int;
 }

@@ -122,10 +122,11 @@ def test_dense_hits_take_the_device_sort_and_the_overflow_protocol(engine):
     assert engine.search_refs_sorted(w, d, w[pick], d[pick], 350) == orc.search_refs_sorted(w, d, w[pick], d[pick], 350)
 
 
-def test_dup_heavy_at_the_bench_size_matches_the_oracle(engine):
+def test_dup_heavy_at_the_bench_size(engine):
     """The bench leg's own database (1 M hashes, 1015 clusters, 6.59 M thresholded pairs) through the whole host-level search()
-    - stream, suspect queue, wave-staged appends, replay filter, device sort, replay - against the oracle's literal search_self
-    (1.28e10 windowed comparisons on one host thread: ~35 s)."""
+    - stream, suspect queue, wave-staged appends, replay filter, device sort, replay: structure at full size (disjoint groups,
+    every member within tolerance of its group's target, sizes), and the oracle's literal search_self on the same generator's
+    400 k database (2e9 windowed comparisons on one host thread: ~5 s; the full size needs 35 s)."""
     if engine.backend != "mfma":
         pytest.skip("one backend is enough at this size (the VALU backend runs the 50 k and 30 k cases above)")
     import bench
@@ -135,7 +136,6 @@ def test_dup_heavy_at_the_bench_size_matches_the_oracle(engine):
     st, tm = engine.last_stats(), engine.last_timing()
     assert st["n_hits"] == cluster_pairs == 6_590_299 and st["n_launches"] == 1
     assert tm["hits_filtered"] > 6_000_000
-    # structure first (cheap, size-independent): disjoint groups, every member within tolerance of its group's target (last member)
     seen = np.zeros(len(d), bool)
     for g in got[::37]:
         t = g[-1]
@@ -144,4 +144,9 @@ def test_dup_heavy_at_the_bench_size_matches_the_oracle(engine):
         assert not seen[g].any()
         seen[g] = True
     assert seen.sum() == 100_000 and len(got) == n_clusters
-    assert got == orc.search_self_sorted(w, d, 350)
+    targets = [g[-1] for g in got]
+    assert targets == sorted(targets, reverse=True)  # ret.reverse(), search_algorithm.rs:167
+    w4, d4, n4, pairs4 = bench.make_dup_heavy(400_000)
+    got4 = engine.search_self_sorted(w4, d4, 350)
+    assert engine.last_stats()["n_hits"] == pairs4 and engine.last_timing()["hits_filtered"] > 0
+    assert got4 == orc.search_self_sorted(w4, d4, 350) and len(got4) == n4
