@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 final-ish: whole GPU suite, the default bench, the round's profiles
+# round 3 GPU call: whole GPU suite, the default bench, smoke, the round's profiles (profiles/r03_*)
 O=gpurun_out/r03r; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.log; tail -3 $O/pytest.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU call b: parity of the reworked hit path + hash-kernel load variants + the dup_heavy leg
+# round 3 GPU call: parity of the reworked hit path, the 64x64 kernel's load variants (profiles/r03_hash_nt_ab.txt, second block), dup_heavy
 O=gpurun_out/r03b; mkdir -p $O
 python -m pytest tests/test_gpu_dup_heavy.py tests/test_gpu_search_parity.py tests/test_gpu_multi_ctx.py tests/test_gpu_fuzz.py -k "not hash and not stream_kernels" -m gpu -x -q 2>&1 | tail -5 > $O/pytest.log
 cat $O/pytest.log

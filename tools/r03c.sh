@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU call c: NT variants of the frame streams, persistent kernel occupancy, dup_heavy after chunk growth
+# round 3 GPU call: non-temporal variants of the frame streams (profiles/r03_hash_nt_ab.txt, first block), persistent-kernel occupancy
 O=gpurun_out/r03c; mkdir -p $O
 python -m pytest tests/test_gpu_dup_heavy.py tests/test_gpu_hash_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -3 | tee $O/pytest.log
 for rep in 1 2; do for v in default streamnt wident; do cp tools/_libvdf_$v.so vid_dup_finder_lib_amd/libvdf_hip.so

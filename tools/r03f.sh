@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3 GPU call: re-pitch A/B (profiles/r03_repitch_ab.txt), the resize-mode sweep (profiles/r03_resize_sweep.txt), dup_heavy
 O=gpurun_out/r03f; mkdir -p $O
 python -m pytest tests/test_gpu_dup_heavy.py -m gpu -x -q 2>&1 | tail -2
 for rep in 1 2; do for v in default repitch; do cp tools/_libvdf_$v.so vid_dup_finder_lib_amd/libvdf_hip.so

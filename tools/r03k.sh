@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3 GPU call: per-wave block streams - parity, soak and A/B against the chunk kernel (profiles/r03_wavestream_ab.txt)
 O=gpurun_out/r03k; mkdir -p $O
 python -m pytest tests/test_gpu_hash_parity.py tests/test_golden.py -m gpu -x -q 2>&1 | tail -3 | tee $O/pytest.log
 python -m pytest tests/test_gpu_fuzz.py -k "soak or wide_frames or large_frames" -m gpu -x -q 2>&1 | tail -3 | tee -a $O/pytest.log

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3 GPU call: forced chunk widths on the windowed / dense / reference legs (profiles/r03_refs_chunk_sweep.txt)
 O=gpurun_out/r03m; mkdir -p $O
 for c in 0 4096 8192 16384 32768; do
   VDF_MFMA_CHUNK_COLS=$c timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --hash-clips 0 --c4-hashes 0 --no-valu --c5-cands 0 > $O/b_$c.json 2>/dev/null

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3 GPU call: per-wave block streams with the re-pitching DMA modes - parity, soak and A/B (profiles/r03_wavestream_ab.txt, second block)
 O=gpurun_out/r03p; mkdir -p $O
 python -m pytest tests/test_gpu_hash_parity.py tests/test_golden.py tests/test_gpu_letterbox.py -m gpu -x -q 2>&1 | grep -E "passed|failed|Error" | tee $O/pytest.log
 python -m pytest tests/test_gpu_fuzz.py -k "soak or wide_frames or large_frames" -m gpu -x -q 2>&1 | grep -E "passed|failed|Error" | tee -a $O/pytest.log
