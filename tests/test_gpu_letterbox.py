@@ -194,3 +194,45 @@ def test_letterbox_strided_misaligned_device_buffers(engine, h, w, base, pad_f, 
     want_h, want_c = engine.hash_frames_letterbox(np.ascontiguousarray(frames))
     assert np.array_equal(crops, want_c)
     assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want_h)
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (900, 1600), (322, 1440), (200, 1680)])
+def test_top_bottom_bars_on_wide_frames(engine, monkeypatch, h, w):
+    """Full-width crop boxes (top / bottom bars only) on the widths of the per-wave stream kernel take its row-cropped form
+    (resize_mfma_rowcrop_wavestream_kernel): per-clip first row, height and vertical table.  Boxes of every block count (less
+    than four 16-row blocks = waves without work in a frame, heights off a multiple of 16, one row), clips without bars among
+    them; equal to the oracle on the cropped copies and to the whole-line cropped kernel."""
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(h * 7 + w)
+    tb = [(0, 0), (h // 8, h // 8), (1, 0), (0, 1), (h // 2 - 20, h // 2 - 21), (h - 17, 0), (0, h - 33), (h // 3, 5), (7, h // 3),
+          (h - 1, 0), (h // 2 - 32, h // 2 - 32), (16, 16)]
+    n = len(tb)
+    frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+    crops = np.array([(0, 0, t, b) for t, b in tb], np.uint32)
+    want = np.stack([orc.hash_clip(np.ascontiguousarray(frames[c][:, tb[c][0]:h - tb[c][1]]))[1] for c in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("VDF_NO_WAVESTREAM", "1")
+    out2 = torch.zeros_like(out)
+    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    # one clip with a side bar sends the whole call down the general cropped path: same hashes for the others
+    monkeypatch.delenv("VDF_NO_WAVESTREAM")
+    crops2 = crops.copy()
+    crops2[3] = (8, 0, 0, 1)
+    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops2, out2.data_ptr())
+    torch.cuda.synchronize()
+    keep = [c for c in range(n) if c != 3]
+    assert torch.equal(out[keep], out2[keep])
+    bad = crops.copy()
+    bad[5] = (0, 0, h - 10, 10)
+    with pytest.raises(vdf.VdfError) as ei:
+        engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, bad, out2.data_ptr())
+    assert ei.value.code == -5

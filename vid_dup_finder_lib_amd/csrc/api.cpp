@@ -622,6 +622,59 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         int rc0 = ensure_cos_table(ctx, stream);
         if (rc0) return rc0;
     }
+    // Top / bottom bars only (the commonest letterbox: a 2.39 : 1 film in a 16 : 9 frame) on the widths of the per-wave stream
+    // kernel: the box is a contiguous range of rows at the frame's own pitch - no gather, per-clip first row / block count /
+    // vertical table (resize_mfma_rowcrop_wavestream_kernel).
+    if (ctx->resize_mode == 0 && vdf::resize_wavestream_applies(w) && vdf::stream_pitch(w) == w && (h + 63) / 64 > 2 &&
+        (((uintptr_t)d_frames | frame_stride | clip_stride) & 15) == 0 && (uint64_t)w * h < (1ull << 31) && ((uint64_t)w * h) % 16 == 0 &&
+        !std::getenv("VDF_NO_WAVESTREAM")) {
+        bool rows_only = true;
+        for (size_t c = 0; c < n_clips && rows_only; c++) rows_only = crops[4 * c] == 0 && crops[4 * c + 1] == 0;
+        int rc = VDF_OK;
+        DeviceMfmaTable *mh = rows_only ? mfma_table(ctx, w, vdf::kMfmaLayoutHorizontalBand, stream, &rc) : nullptr;
+        if (rc) return rc;
+        if (mh && mh->host.ok) {
+            std::vector<vdf::CropStreamClip> sc(n_clips);
+            std::vector<vdf::CropStreamTable> st;
+            std::map<uint32_t, uint32_t> vindex;  // box height -> entry
+            bool ok = true;
+            for (size_t c = 0; c < n_clips && ok; c++) {
+                const uint32_t t = crops[4 * c + 2], b = crops[4 * c + 3];
+                if ((uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
+                vdf::CropStreamClip &q = sc[c];
+                q = vdf::CropStreamClip{};
+                q.y0 = t; q.w = w; q.h = h - t - b; q.wp = w;
+                auto it = vindex.find(q.h);
+                if (it == vindex.end()) {
+                    DeviceMfmaTable *tv = mfma_table(ctx, q.h, vdf::kMfmaLayoutVertical, stream, &rc);
+                    if (rc) return rc;
+                    if (!tv->host.ok) { ok = false; break; }
+                    st.push_back(vdf::CropStreamTable{tv->operand.p, tv->bias.as<int32_t>(), nullptr, tv->host.n_tiles, tv->host.precision, 0, 0});
+                    it = vindex.emplace(q.h, (uint32_t)st.size() - 1).first;
+                }
+                q.v_table = it->second;
+            }
+            if (ok) {
+                rc = upload(ctx, ctx->crop_desc, sc.data(), sc.size() * sizeof(vdf::CropStreamClip), stream);
+                if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
+                if (rc) return rc;
+                VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
+                vdf::MfmaResizeArgs a{};
+                a.bh = mh->operand.p;
+                a.bias_h = mh->bias.as<int32_t>();
+                a.prec_h = mh->host.precision;
+                a.n_kt = mh->host.n_tiles;
+                a.band_meta = mh->meta.as<int32_t>();
+                a.band_stride = mh->host.band_stride;
+                VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+                VDF_HIP(ctx, vdf::launch_resize_mfma_rowcrop_wavestream(d_frames, n_clips, w, h, frame_stride, clip_stride, a,
+                                                                        ctx->crop_desc.as<vdf::CropStreamClip>(),
+                                                                        ctx->crop_tables.as<vdf::CropStreamTable>(), ctx->small.as<uint8_t>(), stream));
+                VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
+                return VDF_OK;
+            }
+        }
+    }
     // Linear-stream form (frames of 256..1984 columns on dword-aligned bases): the crop box goes through LDS like a whole frame.
     // Default for pitches that are not a multiple of the 128-byte line (measured, detect + crop + hash of letterboxed clips,
     // whole-line kernel -> this: 854x480 1.68 -> 1.24 ms per 1000 clips, 720x576 1.42 -> 1.14, 426x240 x4000 1.85 -> 1.33,

@@ -1586,6 +1586,171 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     write_pending();
 }
 
+// ---- per-wave block streams for clips with top / bottom bars only (round 3) -------------------------------------------------
+// The commonest letterbox is a 2.39 : 1 film in a 16 : 9 frame: full-width boxes, a contiguous range of rows per clip.  Those need
+// nothing of the gather machinery above: the box of clip c is rows y0 .. y0 + h of every frame at the frame's own pitch, i.e. the
+// per-wave kernel (resize_mfma_frame_wavestream_kernel) with a PER-CLIP first row, block count and vertical table.  Per frame
+// the geometry (y0, h, vertical operand / bias pointers, precision) comes from the clip's descriptor by scalar loads, fetched a
+// frame ahead; the horizontal band table is the frame width's and stays in LDS for the whole launch.  W % 16 == 0, rows at the
+// frame's own pitch (the widths resize_wavestream_applies() accepts with stream_pitch(w) == w); clips without bars (y0 = 0,
+// h = H) take the same path.  Same exact integer products as every other kernel.
+template <int BUF_BYTES, int TAB_BYTES>
+__global__ __launch_bounds__(256) void resize_mfma_rowcrop_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+                                                                             uint32_t H, size_t frame_stride,
+                                                                             size_t clip_stride, uint32_t n_frames,
+                                                                             MfmaResizeTables T,
+                                                                             const CropStreamClip *__restrict__ clips_g,
+                                                                             const CropStreamTable *__restrict__ tables_g,
+                                                                             uint8_t *__restrict__ small)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
+    __shared__ int32_t s_part[2][3][64][4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t frame_bytes = W * H;
+    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
+    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
+    const int32_t bias_h = T.bias_h[r16];
+    const uint32_t tab_vecs = (uint32_t)T.band_stride;
+    for (uint32_t i = tid; i < tab_vecs; i += 256u) {
+        const v4i v = T.bh[i];
+        s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
+    }
+    if (tid < 8) s_tab[tab_vecs + tid] = uint4{0, 0, 0, 0};
+    const uint32_t band_zero = 16u * tab_vecs;
+    const int32_t band_lo = T.band_meta[r16];
+    const uint32_t band_nt = (uint32_t)T.band_meta[16 + r16];
+    const uint32_t band_base = r16 * (uint32_t)T.band_stride + 16u * g;
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    uint4 *my = s_pxw[wave];
+    __syncthreads();
+
+    typedef const __attribute__((address_space(1))) v4i *global_v4i;
+    typedef const __attribute__((address_space(1))) int32_t *global_i32;
+    struct Geo {
+        uint32_t y0, h, n_blk;
+        int32_t n_rg, prec_v;
+        global_v4i av;
+        global_i32 bias_v;
+    };
+    // workgroup-uniform values pinned to SGPRs; pointers rebuilt in the GLOBAL address space (see resize_mfma_cropped_stream_kernel)
+    auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto sgpr_ptr = [&](const void *p) __attribute__((always_inline)) {
+        const uint64_t a = (uint64_t)(uintptr_t)p;
+        return (const __attribute__((address_space(1))) void *)(uintptr_t)(((uint64_t)sgpr((uint32_t)(a >> 32)) << 32) | sgpr((uint32_t)a));
+    };
+    auto geo_of = [&](uint32_t F) __attribute__((always_inline)) {
+        const uint32_t clip = sgpr(F >> 4);
+        Geo q;
+        q.y0 = sgpr(clips[clip].y0);
+        q.h = sgpr(clips[clip].h);
+        q.n_blk = (q.h + 15u) / 16u;
+        const uint32_t vt = sgpr(clips[clip].v_table);
+        q.av = (global_v4i)sgpr_ptr(tables[vt].operand);
+        q.bias_v = (global_i32)sgpr_ptr(tables[vt].bias);
+        q.n_rg = (int32_t)sgpr((uint32_t)tables[vt].n_tiles);
+        q.prec_v = (int32_t)sgpr((uint32_t)tables[vt].precision);
+        return q;
+    };
+    auto issue_dma = [&](uint32_t F, const Geo &q, uint32_t b) __attribute__((always_inline)) {
+        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
+        const uint32_t start = (q.y0 + 16u * b) * W, bytes = min(16u, q.h - 16u * b) * W;
+        for (uint32_t off = 0; off < bytes; off += 1024u) {
+            auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
+        }
+    };
+    uint32_t parity = 0;
+    uint32_t F = blockIdx.x;
+    Geo cur = {};
+    if (F < n_frames) {
+        cur = geo_of(F);
+        if (wave < cur.n_blk) issue_dma(F, cur, wave);
+    }
+    for (; F < n_frames; F += gridDim.x) {
+        const uint32_t Fn = F + gridDim.x;
+        Geo nxt = cur;
+        if (Fn < n_frames) nxt = geo_of(Fn);
+        v4i bias_v = zero4;  // consumed by wave 0 at the end of the frame
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) bias_v[r] = cur.bias_v[4 * g + r];
+        }
+        v4i acc_vh = zero4, acc_vl = zero4;
+        bool next_issued = false;  // this wave's first block of the next frame goes out behind its LAST block of this one
+        for (uint32_t b = wave; b < cur.n_blk; b += 4) {
+            const uint32_t rg = min(b >> 2, (uint32_t)cur.n_rg - 1u);
+            const v4i avh = cur.av[(rg * 2 + 0) * 64 + lane], avl = cur.av[(rg * 2 + 1) * 64 + lane];
+            asm volatile("" ::"v"(avh), "v"(avl) : "memory");  // requested after this block's DMA: in, once they are (VMEM returns in order)
+            v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
+            const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * W + 16u * g;
+            auto tile = [&](int kt) __attribute__((always_inline)) {
+                const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
+                const v4i a = (v4i){(int)p.x, (int)p.y, (int)p.z, (int)p.w} ^ x80;
+                const uint32_t j = (uint32_t)(kt - band_lo);
+                const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
+                const uint4 th = *reinterpret_cast<const uint4 *>(q), tl = *reinterpret_cast<const uint4 *>(q + 64);
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
+            };
+            int kt = 0;
+            for (; kt + 3 < T.n_kt; kt += 4) { tile(kt); tile(kt + 1); tile(kt + 2); tile(kt + 3); }
+            for (; kt < T.n_kt; kt++) tile(kt);
+            const int val = (int)finalize4(ah, al, T.prec_h);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the buffer is consumed: it may be overwritten
+            if (b + 4 < cur.n_blk) issue_dma(F, cur, b + 4);
+            else if (Fn < n_frames && wave < nxt.n_blk) { issue_dma(Fn, nxt, wave); next_issued = true; }
+            const uint32_t mb = b & 3u;
+            v4i bb;
+#pragma unroll
+            for (int m = 0; m < 4; m++) bb[m] = mb == (uint32_t)m ? val : 0;
+            acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, bb, acc_vh, 0, 0, 0);
+            acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, bb, acc_vl, 0, 0, 0);
+        }
+        // a wave without a block in this (short) box still owes its first block of the next frame
+        if (!next_issued && Fn < n_frames && wave < nxt.n_blk) issue_dma(Fn, nxt, wave);
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) s_part[parity][wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave == 0) {
+            v4i vl = acc_vl;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                vl[r] += bias_v[r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) vl[r] += s_part[parity][w][lane][r];
+            }
+            const uint32_t px = finalize4(acc_vh, vl, cur.prec_v) ^ 0x80808080u;
+            uint8_t *dst = small + (size_t)F * 256;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        }
+        parity ^= 1u;
+        cur = nxt;
+    }
+}
+
+hipError_t launch_resize_mfma_rowcrop_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                                 size_t clip_stride, const MfmaResizeArgs &a, const CropStreamClip *clips,
+                                                 const CropStreamTable *tables, uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || !resize_wavestream_applies(w) || stream_pitch(w) != w)
+        return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16);
+    hipLaunchKernelGGL((resize_mfma_rowcrop_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes>), dim3(std::min<uint32_t>(n_frames, (uint32_t)cus)),
+                       dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), clips, tables, small);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,
                                              size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
                                              const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
