@@ -97,6 +97,9 @@ int main()
     }
     for (uint32_t w : {1360u, 1366u, 1440u, 1536u, 1600u, 1680u, 1792u, 1904u, 1920u}) CHECK(resize_wavestream_applies(w), "%u wide takes the per-wave streams", w);
     for (uint32_t w : {1280u, 1024u, 1921u, 1936u, 1984u, 2048u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
+    // full-width crop boxes: the ROWCROP stream kernels everywhere but the re-pitched multiples of 256 up to 2048 columns (measured)
+    for (uint32_t w : {64u, 426u, 640u, 854u, 1280u, 1366u, 1600u, 1792u, 1920u, 2560u, 3840u, 4096u}) CHECK(resize_rowcrop_streams(w), "%u wide: row-cropped stream kernels", w);
+    for (uint32_t w : {256u, 512u, 768u, 1024u, 1536u, 2048u}) CHECK(!resize_rowcrop_streams(w), "%u wide: general cropped kernels", w);
     uint32_t kp = 0;
     CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");
     CHECK(ksplit_geometry(2048, &kp) == 2 && kp == 2064, "2048 wide: two blocks per chunk");

@@ -258,6 +258,10 @@ _SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
     ("stream 422 (shifted)", 240, 422, 40, False), ("wave-stream 1920", 300, 1920, 24, False), ("wave-stream 1440", 200, 1440, 40, False), ("wave-stream 1366 (shifted)", 200, 1366, 40, False), ("wave-stream 1536 (re-pitched)", 200, 1536, 24, False), ("stream band 1984", 200, 1984, 24, False), ("stream 480", 270, 480, 40, False),
     ("whole-line 2000", 200, 2000, 20, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
     ("cropped stream 854", 480, 854, 24, True), ("cropped stream 480", 270, 480, 40, True), ("cropped whole-line 1280", 360, 1280, 16, True),
+    # top / bottom bars only: the ROWCROP instantiations of the stream kernels (per-clip first row, height, vertical table)
+    ("row-cropped stream 1280", 360, 1280, 24, "rows"), ("row-cropped stream 854 (shifted)", 300, 854, 24, "rows"),
+    ("row-cropped stream 640", 360, 640, 40, "rows"), ("row-cropped wave-stream 1920", 300, 1920, 24, "rows"),
+    ("row-cropped wave-stream 1366 (shifted)", 200, 1366, 32, "rows"), ("row-cropped K-split 3840", 200, 3840, 12, "rows"),
 ]
 
 
@@ -280,7 +284,7 @@ def test_stream_kernels_soak(name, h, w, n, letterbox):
     if letterbox:
         for c in range(n):
             t, b = int(rng.integers(0, h // 5)), int(rng.integers(0, h // 5))
-            l, r = (int(rng.integers(0, w // 6)), int(rng.integers(0, w // 6))) if c % 2 else (0, 0)
+            l, r = (int(rng.integers(0, w // 6)), int(rng.integers(0, w // 6))) if c % 2 and letterbox != "rows" else (0, 0)
             if t:
                 frames[c, :, :t] = 16
             if b:

@@ -196,17 +196,25 @@ def test_letterbox_strided_misaligned_device_buffers(engine, h, w, base, pad_f, 
     assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want_h)
 
 
-@pytest.mark.parametrize("h,w", [(1080, 1920), (900, 1600), (322, 1440), (200, 1680)])
-def test_top_bottom_bars_on_wide_frames(engine, monkeypatch, h, w):
-    """Full-width crop boxes (top / bottom bars only) on the widths of the per-wave stream kernel take its row-cropped form
-    (resize_mfma_rowcrop_wavestream_kernel): per-clip first row, height and vertical table.  Boxes of every block count (less
-    than four 16-row blocks = waves without work in a frame, heights off a multiple of 16, one row), clips without bars among
-    them; equal to the oracle on the cropped copies and to the whole-line cropped kernel."""
+@pytest.mark.parametrize("h,w", [(1080, 1920), (900, 1600), (322, 1440), (200, 1680),  # per-wave form at the frame's own pitch
+                                 (360, 640), (720, 1280), (270, 480), (176, 320), (594, 1056),  # chunk form, rows as they are (W % 16 == 0)
+                                 (576, 1024), (432, 768), (300, 1536), (260, 1792),  # chunk form, re-pitched rows
+                                 (480, 852), (240, 500), (300, 1364),  # W % 4 == 0, not 16
+                                 (480, 854), (768, 1366), (333, 999), (240, 426), (201, 1001),  # rows off a dword boundary
+                                 (400, 2048), (288, 2560), (432, 3840), (256, 4096), (300, 2064)])  # K-split form
+def test_top_bottom_bars_take_the_stream_kernels(engine, monkeypatch, h, w):
+    """Full-width crop boxes (top / bottom bars only) stream like shorter frames: the linear-stream kernels the uncropped call
+    takes at that width, as ROWCROP instantiations with a per-clip first row, height and vertical table.  Boxes of every block
+    count (fewer than four 16-row blocks = waves without work, heights off a multiple of 16, one row, odd first rows = chunks that
+    start off 4- and 16-byte boundaries), clips without bars among them; equal to the oracle on the cropped copies, to the
+    general cropped kernels (VDF_NO_ROWCROP) and - where the per-wave form exists - to the chunk form (VDF_NO_WAVESTREAM)."""
     import vid_dup_finder_lib_amd as vdf
 
     rng = np.random.default_rng(h * 7 + w)
     tb = [(0, 0), (h // 8, h // 8), (1, 0), (0, 1), (h // 2 - 20, h // 2 - 21), (h - 17, 0), (0, h - 33), (h // 3, 5), (7, h // 3),
-          (h - 1, 0), (h // 2 - 32, h // 2 - 32), (16, 16)]
+          (h - 1, 0), (h // 2 - 32, h // 2 - 32), (16, 16), (3, 2), (h // 5 | 1, h // 7)]
+    if (w * h) % 16:
+        pytest.skip("frames that do not end on a 16-byte boundary stay on the general kernels")
     n = len(tb)
     frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
     crops = np.array([(0, 0, t, b) for t, b in tb], np.uint32)
@@ -218,13 +226,16 @@ def test_top_bottom_bars_on_wide_frames(engine, monkeypatch, h, w):
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(np.uint64)
     assert np.array_equal(got, want)
-    monkeypatch.setenv("VDF_NO_WAVESTREAM", "1")
     out2 = torch.zeros_like(out)
-    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out2.data_ptr())
-    torch.cuda.synchronize()
-    assert torch.equal(out, out2)
+    # VDF_ROWCROP_ALL: also at the widths where the dispatch keeps the general kernels because they measured faster (768, 1024, 1536, 2048)
+    for env in ("VDF_ROWCROP_ALL", "VDF_NO_ROWCROP", "VDF_NO_WAVESTREAM"):
+        monkeypatch.setenv(env, "1")
+        out2.zero_()
+        engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out2.data_ptr())
+        torch.cuda.synchronize()
+        monkeypatch.delenv(env)
+        assert torch.equal(out, out2), env
     # one clip with a side bar sends the whole call down the general cropped path: same hashes for the others
-    monkeypatch.delenv("VDF_NO_WAVESTREAM")
     crops2 = crops.copy()
     crops2[3] = (8, 0, 0, 1)
     engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops2, out2.data_ptr())

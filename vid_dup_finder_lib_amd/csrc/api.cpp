@@ -622,16 +622,18 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         int rc0 = ensure_cos_table(ctx, stream);
         if (rc0) return rc0;
     }
-    // Top / bottom bars only (the commonest letterbox: a 2.39 : 1 film in a 16 : 9 frame) on the widths of the per-wave stream
-    // kernel: the box is a contiguous range of rows at the frame's own pitch - no gather, per-clip first row / block count /
-    // vertical table (resize_mfma_rowcrop_wavestream_kernel).
-    if (ctx->resize_mode == 0 && vdf::resize_wavestream_applies(w) && vdf::stream_pitch(w) == w && (h + 63) / 64 > 2 &&
-        (((uintptr_t)d_frames | frame_stride | clip_stride) & 15) == 0 && (uint64_t)w * h < (1ull << 31) && ((uint64_t)w * h) % 16 == 0 &&
-        !std::getenv("VDF_NO_WAVESTREAM")) {
+    // Top / bottom bars only (the commonest letterbox: a 2.39 : 1 film in a 16 : 9 frame): the box is a contiguous range of rows at the
+    // frame's own pitch, so it streams like a shorter frame - the linear-stream kernels the uncropped call would take (per-wave, chunk
+    // or K-split form), as ROWCROP instantiations with a per-clip first row, height and vertical table.
+    if (ctx->resize_mode == 0 && (h + 63) / 64 > 2 && (vdf::resize_rowcrop_streams(w) || std::getenv("VDF_ROWCROP_ALL")) && !std::getenv("VDF_NO_ROWCROP")) {
         bool rows_only = true;
         for (size_t c = 0; c < n_clips && rows_only; c++) rows_only = crops[4 * c] == 0 && crops[4 * c + 1] == 0;
+        bool streamed = rows_only && vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, false);
+        const bool band = streamed && vdf::resize_stream_wants_band(w);
+        const bool ksplit = rows_only && !streamed && w >= 2048 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         int rc = VDF_OK;
-        DeviceMfmaTable *mh = rows_only ? mfma_table(ctx, w, vdf::kMfmaLayoutHorizontalBand, stream, &rc) : nullptr;
+        DeviceMfmaTable *mh = nullptr;
+        if (streamed || ksplit) mh = mfma_table(ctx, w, band ? vdf::kMfmaLayoutHorizontalBand : vdf::kMfmaLayoutHorizontal, stream, &rc);
         if (rc) return rc;
         if (mh && mh->host.ok) {
             std::vector<vdf::CropStreamClip> sc(n_clips);
@@ -664,12 +666,19 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
                 a.bias_h = mh->bias.as<int32_t>();
                 a.prec_h = mh->host.precision;
                 a.n_kt = mh->host.n_tiles;
-                a.band_meta = mh->meta.as<int32_t>();
-                a.band_stride = mh->host.band_stride;
+                if (band) {
+                    a.band_meta = mh->meta.as<int32_t>();
+                    a.band_stride = mh->host.band_stride;
+                }
                 VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-                VDF_HIP(ctx, vdf::launch_resize_mfma_rowcrop_wavestream(d_frames, n_clips, w, h, frame_stride, clip_stride, a,
-                                                                        ctx->crop_desc.as<vdf::CropStreamClip>(),
-                                                                        ctx->crop_tables.as<vdf::CropStreamTable>(), ctx->small.as<uint8_t>(), stream));
+                if (ksplit)
+                    VDF_HIP(ctx, vdf::launch_resize_mfma_frames_ksplit(d_frames, n_clips, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(),
+                                                                       stream, ctx->crop_desc.as<vdf::CropStreamClip>(),
+                                                                       ctx->crop_tables.as<vdf::CropStreamTable>()));
+                else
+                    VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_clips, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(),
+                                                                       stream, ctx->crop_desc.as<vdf::CropStreamClip>(),
+                                                                       ctx->crop_tables.as<vdf::CropStreamTable>()));
                 VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
                 return VDF_OK;
             }

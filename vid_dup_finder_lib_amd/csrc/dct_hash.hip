@@ -762,6 +762,43 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wide_kernel(const uint8
 
 static MfmaResizeTables make_tables(const MfmaResizeArgs &a);
 
+// ---- per-clip row ranges (letterboxed clips with top / bottom bars only) ---------------------------------------------------
+// The linear-stream kernels below take, as ROWCROP instantiations, a per-clip first row and height: the crop box of a clip
+// with full-width bars is a contiguous run of rows at the frame's own pitch, so the box streams exactly like a (shorter) frame
+// and only the vertical table changes from clip to clip.  The geometry comes from the clip's descriptor (y0, h, v_table of
+// CropStreamClip; the vertical CropStreamTable entry) by scalar loads, a frame ahead of its use.
+typedef const __attribute__((address_space(4))) CropStreamClip *const_clip_ptr;
+typedef const __attribute__((address_space(4))) CropStreamTable *const_table_ptr;
+typedef const __attribute__((address_space(1))) v4i *global_v4i;
+typedef const __attribute__((address_space(1))) int32_t *global_i32;
+struct RowGeo {
+    uint32_t y0, h;
+    int32_t n_rg, prec_v;
+    global_v4i av;
+    global_i32 bias_v;
+};
+// workgroup-uniform values pinned to SGPRs; pointers rebuilt in the GLOBAL address space (a pointer made from integers is a generic
+// one: its loads become flat_load, and the compiler puts a vmcnt(0) in front of a flat load while an LDS-DMA is in flight)
+__device__ __forceinline__ uint32_t sgpr_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ const __attribute__((address_space(1))) void *sgpr_global_ptr(const void *p)
+{
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return (const __attribute__((address_space(1))) void *)(uintptr_t)(((uint64_t)sgpr_u32((uint32_t)(a >> 32)) << 32) | sgpr_u32((uint32_t)a));
+}
+__device__ __forceinline__ RowGeo row_geo_of(const_clip_ptr clips, const_table_ptr tables, uint32_t F)
+{
+    const uint32_t clip = sgpr_u32(F >> 4);
+    RowGeo q;
+    q.y0 = sgpr_u32(clips[clip].y0);
+    q.h = sgpr_u32(clips[clip].h);
+    const uint32_t vt = sgpr_u32(clips[clip].v_table);
+    q.av = (global_v4i)sgpr_global_ptr(tables[vt].operand);
+    q.bias_v = (global_i32)sgpr_global_ptr(tables[vt].bias);
+    q.n_rg = (int32_t)sgpr_u32((uint32_t)tables[vt].n_tiles);
+    q.prec_v = (int32_t)sgpr_u32((uint32_t)tables[vt].precision);
+    return q;
+}
+
 // ---- large frames, linear-stream form ------------------------------------------------------------------------
 // With W % 128 != 0 every row-shaped wave load above (16 x 64 B or 8 x 128 B) straddles lines: 480 x 270 read at 4.6 TB/s
 // while the same bytes read linearly stream at 6.2 (tools/ubench_rowload.hip), and even line-aligned rows cap at 5.7.
@@ -784,12 +821,14 @@ static MfmaResizeTables make_tables(const MfmaResizeArgs &a);
 // row * W + x.  The global side is still a linear sweep (a row's tail lanes run into the next row).  LDS-DMA ignores the
 // low two bits of a global address, so MODE 2 (W % 4 != 0) starts each row at the dword below it and the operand read
 // takes one more dword and shifts by the row's 0..3 bytes (v_alignbyte, a per-lane constant).
-template <int BUF_BYTES, int TAB_TILES, int MODE, bool BAND>
+template <int BUF_BYTES, int TAB_TILES, int MODE, bool BAND, bool ROWCROP = false>
 __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                        uint32_t H, size_t frame_stride,
                                                                        size_t clip_stride, uint32_t n_frames,
                                                                        MfmaResizeTables T, uint32_t nb, uint32_t Wp,
-                                                                       uint8_t *__restrict__ small)
+                                                                       uint8_t *__restrict__ small,
+                                                                       const CropStreamClip *__restrict__ clips_g = nullptr,
+                                                                       const CropStreamTable *__restrict__ tables_g = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_TILES * 2 * 64];
     __shared__ __attribute__((aligned(16))) uint4 s_px0[BUF_BYTES / 16];
@@ -797,7 +836,13 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     __shared__ int32_t s_part[3][64][4];  // 256 hi + lo of waves 1..3 (the sums are exact in i32, as in finalize4)
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
+    const uint32_t rpc = 16u * nb, frame_bytes = W * H;
+    // ROWCROP: rows y0 .. y0 + h of each frame of a clip, its own vertical table; geo = the frame whose products run next, geo_n = the
+    // workgroup's frame after it (fetched when geo becomes current), geo_p = the frame whose result is pending
+    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
+    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
+    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
+    int32_t pend_prec = T.prec_v;
     // MODE 1, 2: where this lane's first DMA instruction of a chunk lands (LDS position P0 = 1024 wave + 16 lane = row * Wp + x) and
     // how far an instruction (4096 bytes of LDS further) moves it; the loop below only adds and compares - with a multiply
     // high / two multiplies per instruction (16 cycles each) the ISSUE of a chunk's DMA cost 0.4 us of a 2.5 us step
@@ -809,9 +854,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         lane_ro0 = row0 * W;
     }
     const int32_t bias_h = T.bias_h[r16];
-    v4i bias_v;
+    v4i bias_v = {0, 0, 0, 0};
+    if constexpr (!ROWCROP) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+        for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    }
     // horizontal table -> LDS: all K tiles, or (BAND, wide frames) only the tiles each output's taps reach, output-major
     const uint32_t tab_vecs = BAND ? (uint32_t)T.band_stride : (uint32_t)T.n_kt * 128u;  // 16 outputs x stride / 16 bytes
     for (uint32_t i = tid; i < tab_vecs; i += 256u) {
@@ -830,10 +877,10 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     const v4i zero4 = {0, 0, 0, 0};
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
 
-    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
+    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst, const RowGeo &q) __attribute__((always_inline)) {
         const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
+        const uint32_t start = (q.y0 + c * rpc) * W, rows = min(rpc, q.h - c * rpc), bytes = rows * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;  // MODE 1, 2: this lane's position in the chunk: column, row * W
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
@@ -841,7 +888,9 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
                 // the whole byte offset goes into the VGPR offset: that is the field the frame-sized range check surely covers
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, VDF_STREAM_AUX);
+                // (MODE 2: the dword below the row's first byte; an uncropped chunk starts on a multiple of 16 bytes, a box need not)
+                const uint32_t at = MODE != 2 ? start + ro : ROWCROP ? (start + ro) & ~3u : start + (ro & ~3u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(at + x), 0, 0, VDF_STREAM_AUX);
                 x += step_x;
                 ro += step_rows * W;
                 if (x >= Wp) { x -= Wp; ro += W; }
@@ -849,11 +898,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         }
     };
     // vertical fragments of the 64-row group that holds this wave's block of chunk c
-    auto load_av = [&](uint32_t c, v4i &h, v4i &l) __attribute__((always_inline)) {
+    auto load_av = [&](uint32_t c, v4i &h, v4i &l, const RowGeo &q) __attribute__((always_inline)) {
         uint32_t rg = (c * nb + wave) >> 2;
-        rg = rg < (uint32_t)T.n_rg ? rg : (uint32_t)T.n_rg - 1u;
-        h = T.av[(rg * 2 + 0) * 64 + lane];
-        l = T.av[(rg * 2 + 1) * 64 + lane];
+        rg = rg < (uint32_t)q.n_rg ? rg : (uint32_t)q.n_rg - 1u;
+        h = q.av[(rg * 2 + 0) * 64 + lane];
+        l = q.av[(rg * 2 + 1) * 64 + lane];
     };
 
     uint32_t F = blockIdx.x, c = 0;  // the chunk whose products run next
@@ -869,7 +918,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 #pragma unroll
                 for (int w = 0; w < 3; w++) vl[r] += s_part[w][lane][r];
             }
-            const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+            const uint32_t px = finalize4(vh, vl, pend_prec) ^ 0x80808080u;
             uint8_t *dst = small + (size_t)out_F * 256;
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
@@ -877,18 +926,25 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
         out_pending = false;
     };
     auto step = [&](const uint4 *cur, uint4 *nxt, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        // Each wave's own DMA instructions of the chunk must have landed BEFORE it arrives at the barrier (the rows of a block come from all
+        // four waves).  The fence of __syncthreads() used to bring that vmcnt(0) along, but it is the compiler's to drop: in the ROWCROP
+        // instantiation the barrier at the loop header came out without it (seen in the ISA; wrong hashes for a few clips per launch).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // chunk (F, c) has landed in `cur` (vmcnt) and every wave is done with `nxt`
+        const uint32_t n_chunks = (geo.h + rpc - 1) / rpc;
+        const bool last = c + 1 == n_chunks;
         uint32_t Fn = F, cn = c + 1;
-        if (cn == n_chunks) { cn = 0; Fn = F + gridDim.x; }
-        if (Fn < n_frames) issue_dma(Fn, cn, nxt);  // first: with one chunk in flight per workgroup its issue time is on the critical path
+        if (last) { cn = 0; Fn = F + gridDim.x; }
+        const RowGeo &gq = ROWCROP && last ? geo_n : geo;  // of the chunk to fetch
+        if (Fn < n_frames) issue_dma(Fn, cn, nxt, gq);  // first: with one chunk in flight per workgroup its issue time is on the critical path
         write_pending();
-        if (Fn < n_frames) load_av(cn, avh_n, avl_n);  // consumed in the next step, behind the barrier's vmcnt wait
-        const uint32_t rows = min(rpc, H - c * rpc);
+        if (Fn < n_frames) load_av(cn, avh_n, avl_n, gq);  // consumed in the next step, behind the barrier's vmcnt wait
+        const uint32_t rows = min(rpc, geo.h - c * rpc);
         if (16u * wave < rows) {
             v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
             const uint32_t row = 16u * wave + r16;  // in the chunk; chunks start on multiples of 16 rows, so (row * W) & 3 is the frame row's
             const uint8_t *base = reinterpret_cast<const uint8_t *>(cur) + row * Wp + 16u * g;
-            const uint32_t shift = MODE == 2 ? (row * W) & 3u : 0u;
+            const uint32_t shift = MODE == 2 ? ((ROWCROP ? geo.y0 * W : 0u) + row * W) & 3u : 0u;
             auto tile = [&](int kt) __attribute__((always_inline)) {
                 const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
                 v4i a = {(int)p.x, (int)p.y, (int)p.z, (int)p.w};
@@ -924,7 +980,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, acc_vh, 0, 0, 0);
             acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
         }
-        if (c + 1 == n_chunks) {  // frame complete: partial sums to LDS, the result is written after the next barrier
+        if (last) {  // frame complete: partial sums to LDS, the result is written after the next barrier
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
@@ -937,13 +993,27 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             acc_vh = zero4; acc_vl = zero4;
             out_pending = true;
             out_F = F;
+            if constexpr (ROWCROP) {  // the finished clip's bias and precision; the next barrier's vmcnt wait covers the loads
+                pend_prec = geo.prec_v;
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bias_v[r] = geo.bias_v[4 * g + r];
+                }
+                geo = geo_n;
+                if (Fn + gridDim.x < n_frames) geo_n = row_geo_of(clips, tables, Fn + gridDim.x);
+            }
         }
         F = Fn; c = cn;
     };
     v4i av0h = zero4, av0l = zero4, av1h = zero4, av1l = zero4;
+    if constexpr (ROWCROP) {
+        if (F < n_frames) geo = row_geo_of(clips, tables, F);
+        geo_n = geo;
+        if (F + gridDim.x < n_frames) geo_n = row_geo_of(clips, tables, F + gridDim.x);
+    }
     if (F < n_frames) {
-        load_av(0, av0h, av0l);
-        issue_dma(F, 0, s_px0);
+        load_av(0, av0h, av0l, geo);
+        issue_dma(F, 0, s_px0, geo);
     }
     while (F < n_frames) {
         step(s_px0, s_px1, av0h, av0l, av1h, av1l);
@@ -967,22 +1037,31 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 // frame's own pitch (MODE 0 addressing), table in band form.
 // MODE as in the kernel above: 0 = rows at the frame's own pitch (W % 16 == 0), 1 / 2 = rows re-pitched by the DMA to Wp (an odd
 // multiple of 16 bytes; 2 = row starts that are not dword-aligned: one more dword per operand read and a per-lane byte shift).
-template <int BUF_BYTES, int TAB_BYTES, int MODE>
+// ROWCROP: per-clip row ranges (see row_geo_of): the box's first row, block count and vertical table change from clip to clip; a wave
+// without a block in a short box still issues its first block of the next frame.
+template <int BUF_BYTES, int TAB_BYTES, int MODE, bool ROWCROP = false>
 __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                            uint32_t H, size_t frame_stride,
                                                                            size_t clip_stride, uint32_t n_frames,
-                                                                           MfmaResizeTables T, uint32_t Wp, uint8_t *__restrict__ small)
+                                                                           MfmaResizeTables T, uint32_t Wp, uint8_t *__restrict__ small,
+                                                                           const CropStreamClip *__restrict__ clips_g = nullptr,
+                                                                           const CropStreamTable *__restrict__ tables_g = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
     __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
     __shared__ int32_t s_part[2][3][64][4];  // [frame parity][wave 1..3]: 256 hi + lo
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t n_blk = (H + 15u) / 16u, frame_bytes = W * H;
+    const uint32_t frame_bytes = W * H;
+    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
+    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
+    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;  // of frame F, of the workgroup's next frame
     const int32_t bias_h = T.bias_h[r16];
-    v4i bias_v;
+    v4i bias_v = {0, 0, 0, 0};
+    if constexpr (!ROWCROP) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+        for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    }
     const uint32_t tab_vecs = (uint32_t)T.band_stride;  // 16 outputs x stride / 16 bytes
     for (uint32_t i = tid; i < tab_vecs; i += 256u) {
         const v4i v = T.bh[i];
@@ -1007,18 +1086,19 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
         lane_x0 = P0 - row0 * Wp;
         lane_ro0 = row0 * W;
     }
-    const uint32_t shift = MODE == 2 ? (r16 * W) & 3u : 0u;  // blocks start on multiples of 16 rows: (row * W) & 3 is the frame row's
-    auto issue_dma = [&](uint32_t F, uint32_t b) __attribute__((always_inline)) {
+    const uint32_t shift0 = MODE == 2 ? (r16 * W) & 3u : 0u;  // blocks start on multiples of 16 rows: (row * W) & 3 is the frame row's
+    auto issue_dma = [&](uint32_t F, uint32_t b, const RowGeo &q) __attribute__((always_inline)) {
         const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = 16u * b * W, bytes = min(16u, H - 16u * b) * Wp;
+        const uint32_t start = (q.y0 + 16u * b) * W, bytes = min(16u, q.h - 16u * b) * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;
         for (uint32_t off = 0; off < bytes; off += 1024u) {
             auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
             if constexpr (MODE == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + (MODE == 2 ? ro & ~3u : ro) + x), 0, 0, VDF_STREAM_AUX);
+                const uint32_t at = MODE != 2 ? start + ro : ROWCROP ? (start + ro) & ~3u : start + (ro & ~3u);  // (a box need not start on a dword)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(at + x), 0, 0, VDF_STREAM_AUX);
                 x += step_x;
                 ro += step_rows * W;
                 if (x >= Wp) { x -= Wp; ro += W; }
@@ -1027,14 +1107,28 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
     };
     uint32_t parity = 0;
     uint32_t F = blockIdx.x;
-    if (F < n_frames && wave < n_blk) issue_dma(F, wave);
+    if constexpr (ROWCROP) {
+        if (F < n_frames) geo = row_geo_of(clips, tables, F);
+    }
+    if (F < n_frames && 16u * wave < geo.h) issue_dma(F, wave, geo);
     for (; F < n_frames; F += gridDim.x) {
         v4i acc_vh = zero4, acc_vl = zero4;
         const uint32_t Fn = F + gridDim.x;
+        const uint32_t n_blk = (geo.h + 15u) / 16u;
+        uint32_t shift = shift0;
+        bool next_issued = false;
+        if constexpr (ROWCROP) {
+            if (Fn < n_frames) geo_n = row_geo_of(clips, tables, Fn);
+            if (wave == 0) {  // consumed at the end of the frame
+#pragma unroll
+                for (int r = 0; r < 4; r++) bias_v[r] = geo.bias_v[4 * g + r];
+            }
+            if constexpr (MODE == 2) shift = (geo.y0 * W + r16 * W) & 3u;
+        }
         for (uint32_t b = wave; b < n_blk; b += 4) {
             // vertical fragments of this block's 64-row group (global loads: issued before the wait, consumed after the products)
-            const uint32_t rg = min(b >> 2, (uint32_t)T.n_rg - 1u);
-            const v4i avh = T.av[(rg * 2 + 0) * 64 + lane], avl = T.av[(rg * 2 + 1) * 64 + lane];
+            const uint32_t rg = min(b >> 2, (uint32_t)geo.n_rg - 1u);
+            const v4i avh = geo.av[(rg * 2 + 0) * 64 + lane], avl = geo.av[(rg * 2 + 1) * 64 + lane];
             // This wave's own block has landed once the two fragments have: they were requested AFTER its DMA and VMEM returns in
             // order.  An empty asm that reads them makes the COMPILER place the vmcnt wait here and know the fragments are in -
             // with a hand-written s_waitcnt it kept its own wait in front of the vertical products below, i.e. behind the NEXT
@@ -1067,14 +1161,17 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
             // the buffer is free: the products above consumed every LDS read of it.  Next block of this frame, or this wave's
             // first block of the next frame - before the frame-end barrier, so the stream never drains
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (b + 4 < n_blk) issue_dma(F, b + 4);
-            else if (Fn < n_frames && wave < n_blk) issue_dma(Fn, wave);
+            if (b + 4 < n_blk) issue_dma(F, b + 4, geo);
+            else if (Fn < n_frames && 16u * wave < geo_n.h) { issue_dma(Fn, wave, geo_n); next_issued = true; }
             const uint32_t mb = b & 3u;
             v4i bb;
 #pragma unroll
             for (int m = 0; m < 4; m++) bb[m] = mb == (uint32_t)m ? val : 0;
             acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, bb, acc_vh, 0, 0, 0);
             acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, bb, acc_vl, 0, 0, 0);
+        }
+        if constexpr (ROWCROP) {  // a wave without a block in this (short) box still owes its first block of the next frame
+            if (!next_issued && Fn < n_frames && 16u * wave < geo_n.h) issue_dma(Fn, wave, geo_n);
         }
         if (wave > 0) {
 #pragma unroll
@@ -1089,21 +1186,34 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
 #pragma unroll
                 for (int w = 0; w < 3; w++) vl[r] += s_part[parity][w][lane][r];
             }
-            const uint32_t px = finalize4(acc_vh, vl, T.prec_v) ^ 0x80808080u;
+            const uint32_t px = finalize4(acc_vh, vl, geo.prec_v) ^ 0x80808080u;
             uint8_t *dst = small + (size_t)F * 256;
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
         }
         parity ^= 1u;  // wave 0 reads parity p while the others may already write p ^ 1; p is written again only after the next barrier
+        if constexpr (ROWCROP) geo = geo_n;
     }
 }
 
 template <int BUF, int TAB, bool BAND>
 static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
                                size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
-                               uint32_t nb, uint8_t *small)
+                               uint32_t nb, uint8_t *small, const CropStreamClip *clips, const CropStreamTable *tables)
 {
     const uint32_t wp = stream_pitch(w);
+    if (clips) {  // per-clip row ranges
+        if (wp == w)
+            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
+        else if (w % 4 == 0)
+            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
+        else
+            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 2, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
+                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
+        return;
+    }
     if (wp == w)
         hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
                            frame_stride, clip_stride, n_frames, T, nb, wp, small);
@@ -1117,7 +1227,8 @@ static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t 
 
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
-                                            uint8_t *small, hipStream_t stream)
+                                            uint8_t *small, hipStream_t stream, const CropStreamClip *clips,
+                                            const CropStreamTable *tables)
 {
     if (n_clips == 0) return hipSuccess;
     uint32_t nb = 0;
@@ -1130,13 +1241,15 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
     if (cls == 1)
         launch_stream_mode<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
-                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
     else if (cls == 2)
         launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
     else if (resize_wavestream_applies(w) && !std::getenv("VDF_NO_WAVESTREAM")) {
         // two blocks per chunk (1328 .. 1920 columns): one block stream per wave keeps 4 x 30 KB in flight
         const uint32_t wp = stream_pitch(w), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
+        if (clips)  // per-clip row ranges
+            return launch_resize_mfma_rowcrop_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream);
         if (wp == w)
             hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 0>), dim3(grid), dim3(256), 0, stream,
                                frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
@@ -1149,7 +1262,7 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     }
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                           frame_stride, clip_stride, n_frames, make_tables(a), nb, small);
+                                                           frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
     return hipGetLastError();
 }
 
@@ -1164,12 +1277,14 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
 // product, so the vertical partial sums are spread over the waves as before.  LDS holds nothing but the two chunk
 // buffers (75 KB each: 16 rows of 4096 columns, 32 of 2048, 48 of 1536, 64 of 1024), rows re-pitched to an odd multiple of
 // 16 bytes by the DMA (at the frame's own pitch the 16 rows of a block would share one bank group: 3840 = 240 x 16).
-template <int MAXT>
+template <int MAXT, bool ROWCROP = false>
 __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                        uint32_t H, size_t frame_stride,
                                                                        size_t clip_stride, uint32_t n_frames,
                                                                        MfmaResizeTables T, uint32_t nb, uint32_t Wp,
-                                                                       uint8_t *__restrict__ small)
+                                                                       uint8_t *__restrict__ small,
+                                                                       const CropStreamClip *__restrict__ clips_g = nullptr,
+                                                                       const CropStreamTable *__restrict__ tables_g = nullptr)
 {
     constexpr int kBuf = kKsplitBuf;
     __shared__ __attribute__((aligned(16))) uint4 s_px0[kBuf / 16];
@@ -1178,7 +1293,12 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
     __shared__ int32_t s_part[3][64][4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t rpc = 16u * nb, n_chunks = (H + rpc - 1) / rpc, frame_bytes = W * H;
+    const uint32_t rpc = 16u * nb, frame_bytes = W * H;
+    // ROWCROP: as in resize_mfma_frame_stream_kernel
+    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
+    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
+    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
+    int32_t pend_prec = T.prec_v;
     const v4i zero4 = {0, 0, 0, 0};
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
     // this wave's K tiles, for the whole launch
@@ -1190,9 +1310,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         if (kt < T.n_kt) { bt[i][0] = T.bh[(kt * 2 + 0) * 64 + lane]; bt[i][1] = T.bh[(kt * 2 + 1) * 64 + lane]; }
     }
     const int32_t bias_h = T.bias_h[r16];
-    v4i bias_v;
+    v4i bias_v = {0, 0, 0, 0};
+    if constexpr (!ROWCROP) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+        for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    }
     // gather DMA: where this lane's first instruction of a chunk lands (LDS position 1024 wave + 16 lane = row * Wp + x)
     const uint32_t step_rows = 4096u / Wp, step_x = 4096u - step_rows * Wp;
     uint32_t lane_x0, lane_ro0;
@@ -1201,10 +1323,10 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         lane_x0 = P0 - row0 * Wp;
         lane_ro0 = row0 * W;
     }
-    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
+    auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst, const RowGeo &q) __attribute__((always_inline)) {
         const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = c * rpc * W, rows = min(rpc, H - c * rpc), bytes = rows * Wp;
+        const uint32_t start = (q.y0 + c * rpc) * W, rows = min(rpc, q.h - c * rpc), bytes = rows * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;
         for (uint32_t off = 1024u * wave; off < bytes; off += 4096u) {
             auto *lds = (__attribute__((address_space(3))) void *)&dst[off >> 4];
@@ -1215,12 +1337,12 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         }
     };
     // the block of chunk c this wave owns (block index & 3 == wave), if the chunk has one: its vertical fragments
-    auto load_av = [&](uint32_t c, v4i &h, v4i &l) __attribute__((always_inline)) {
+    auto load_av = [&](uint32_t c, v4i &h, v4i &l, const RowGeo &q) __attribute__((always_inline)) {
         const uint32_t j = (wave - c * nb) & 3u;  // block j of the chunk has index c * nb + j
         uint32_t rg = (c * nb + j) >> 2;
-        rg = rg < (uint32_t)T.n_rg ? rg : (uint32_t)T.n_rg - 1u;
-        h = T.av[(rg * 2 + 0) * 64 + lane];
-        l = T.av[(rg * 2 + 1) * 64 + lane];
+        rg = rg < (uint32_t)q.n_rg ? rg : (uint32_t)q.n_rg - 1u;
+        h = q.av[(rg * 2 + 0) * 64 + lane];
+        l = q.av[(rg * 2 + 1) * 64 + lane];
     };
 
     uint32_t F = blockIdx.x, c = 0;
@@ -1236,7 +1358,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
 #pragma unroll
                 for (int w = 0; w < 3; w++) vl[r] += s_part[w][lane][r];
             }
-            const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+            const uint32_t px = finalize4(vh, vl, pend_prec) ^ 0x80808080u;
             uint8_t *dst = small + (size_t)out_F * 256;
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
@@ -1244,13 +1366,17 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         out_pending = false;
     };
     auto step = [&](const uint4 *cur, uint4 *nxt, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // see resize_mfma_frame_stream_kernel
         __syncthreads();  // chunk (F, c) has landed in `cur` (vmcnt) and every wave is done with `nxt`
+        const uint32_t n_chunks = (geo.h + rpc - 1) / rpc;
+        const bool last = c + 1 == n_chunks;
         uint32_t Fn = F, cn = c + 1;
-        if (cn == n_chunks) { cn = 0; Fn = F + gridDim.x; }
-        if (Fn < n_frames) issue_dma(Fn, cn, nxt);
+        if (last) { cn = 0; Fn = F + gridDim.x; }
+        const RowGeo &gq = ROWCROP && last ? geo_n : geo;  // of the chunk to fetch
+        if (Fn < n_frames) issue_dma(Fn, cn, nxt, gq);
         write_pending();
-        if (Fn < n_frames) load_av(cn, avh_n, avl_n);
-        const uint32_t rows = min(rpc, H - c * rpc), n_blocks = (rows + 15u) >> 4;
+        if (Fn < n_frames) load_av(cn, avh_n, avl_n, gq);
+        const uint32_t rows = min(rpc, geo.h - c * rpc), n_blocks = (rows + 15u) >> 4;
         for (uint32_t j = 0; j < n_blocks; j++) {
             const uint32_t owner = (c * nb + j) & 3u;
             v4i ah = zero4, al = zero4;
@@ -1288,7 +1414,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
                 acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
             }
         }
-        if (c + 1 == n_chunks) {
+        if (last) {
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
@@ -1298,13 +1424,27 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
             acc_vh = zero4; acc_vl = zero4;
             out_pending = true;
             out_F = F;
+            if constexpr (ROWCROP) {
+                pend_prec = geo.prec_v;
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bias_v[r] = geo.bias_v[4 * g + r];
+                }
+                geo = geo_n;
+                if (Fn + gridDim.x < n_frames) geo_n = row_geo_of(clips, tables, Fn + gridDim.x);
+            }
         }
         F = Fn; c = cn;
     };
     v4i av0h = zero4, av0l = zero4, av1h = zero4, av1l = zero4;
+    if constexpr (ROWCROP) {
+        if (F < n_frames) geo = row_geo_of(clips, tables, F);
+        geo_n = geo;
+        if (F + gridDim.x < n_frames) geo_n = row_geo_of(clips, tables, F + gridDim.x);
+    }
     if (F < n_frames) {
-        load_av(0, av0h, av0l);
-        issue_dma(F, 0, s_px0);
+        load_av(0, av0h, av0l, geo);
+        issue_dma(F, 0, s_px0, geo);
     }
     while (F < n_frames) {
         step(s_px0, s_px1, av0h, av0l, av1h, av1l);
@@ -1317,7 +1457,8 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
 
 hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
-                                            uint8_t *small, hipStream_t stream)
+                                            uint8_t *small, hipStream_t stream, const CropStreamClip *clips,
+                                            const CropStreamTable *tables)
 {
     if (n_clips == 0) return hipSuccess;
     uint32_t wp = 0;
@@ -1328,6 +1469,18 @@ hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clip
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
     const dim3 grid(std::min<uint32_t>(n_frames, (uint32_t)cus));
+    if (clips) {  // per-clip row ranges
+        if (a.n_kt <= 16)
+            hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<4, true>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                               n_frames, make_tables(a), nb, wp, small, clips, tables);
+        else if (a.n_kt <= 32)
+            hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<8, true>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                               n_frames, make_tables(a), nb, wp, small, clips, tables);
+        else
+            hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<16, true>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                               n_frames, make_tables(a), nb, wp, small, clips, tables);
+        return hipGetLastError();
+    }
     if (a.n_kt <= 16)
         hipLaunchKernelGGL((resize_mfma_frame_ksplit_kernel<4>), grid, dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
                            n_frames, make_tables(a), nb, wp, small);
@@ -1348,8 +1501,6 @@ hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clip
 // descriptor by scalar loads.  A workgroup reloads its LDS table only when the next frame's clip uses another one
 // (clips of one source share their box); the biases and the vertical fragments are requested before the DMA of the
 // chunk that needs them, like the vertical fragments above.
-typedef const __attribute__((address_space(4))) CropStreamClip *const_clip_ptr;
-typedef const __attribute__((address_space(4))) CropStreamTable *const_table_ptr;
 
 template <int BUF_BYTES, int TAB_TILES, bool SHIFT>
 __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
@@ -1482,6 +1633,10 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
         out_pending = false;
     };
     auto step = [&](const uint4 *cur_px, uint4 *nxt_px, const v4i &avh, const v4i &avl, v4i &avh_n, v4i &avl_n) __attribute__((always_inline)) {
+        // Each wave's own DMA instructions of the chunk must have landed BEFORE it arrives at the barrier (the rows of a block come from all
+        // four waves).  The fence of __syncthreads() used to bring that vmcnt(0) along, but it is the compiler's to drop: in the ROWCROP
+        // instantiation the barrier at the loop header came out without it (seen in the ISA; wrong hashes for a few clips per launch).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // chunk (F, c) has landed and every wave is done with the other buffer (and, at c == 0, with the old table)
         uint32_t Fn = F, cn = c + 1;
         const bool wraps = cn == cur.n_chunks;
@@ -1586,168 +1741,25 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     write_pending();
 }
 
-// ---- per-wave block streams for clips with top / bottom bars only (round 3) -------------------------------------------------
-// The commonest letterbox is a 2.39 : 1 film in a 16 : 9 frame: full-width boxes, a contiguous range of rows per clip.  Those need
-// nothing of the gather machinery above: the box of clip c is rows y0 .. y0 + h of every frame at the frame's own pitch, i.e. the
-// per-wave kernel (resize_mfma_frame_wavestream_kernel) with a PER-CLIP first row, block count and vertical table.  Per frame
-// the geometry (y0, h, vertical operand / bias pointers, precision) comes from the clip's descriptor by scalar loads, fetched a
-// frame ahead; the horizontal band table is the frame width's and stays in LDS for the whole launch.  W % 16 == 0, rows at the
-// frame's own pitch (the widths resize_wavestream_applies() accepts with stream_pitch(w) == w); clips without bars (y0 = 0,
-// h = H) take the same path.  Same exact integer products as every other kernel.
-template <int BUF_BYTES, int TAB_BYTES>
-__global__ __launch_bounds__(256) void resize_mfma_rowcrop_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
-                                                                             uint32_t H, size_t frame_stride,
-                                                                             size_t clip_stride, uint32_t n_frames,
-                                                                             MfmaResizeTables T,
-                                                                             const CropStreamClip *__restrict__ clips_g,
-                                                                             const CropStreamTable *__restrict__ tables_g,
-                                                                             uint8_t *__restrict__ small)
-{
-    __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
-    __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
-    __shared__ int32_t s_part[2][3][64][4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint32_t frame_bytes = W * H;
-    const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
-    const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
-    const int32_t bias_h = T.bias_h[r16];
-    const uint32_t tab_vecs = (uint32_t)T.band_stride;
-    for (uint32_t i = tid; i < tab_vecs; i += 256u) {
-        const v4i v = T.bh[i];
-        s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
-    }
-    if (tid < 8) s_tab[tab_vecs + tid] = uint4{0, 0, 0, 0};
-    const uint32_t band_zero = 16u * tab_vecs;
-    const int32_t band_lo = T.band_meta[r16];
-    const uint32_t band_nt = (uint32_t)T.band_meta[16 + r16];
-    const uint32_t band_base = r16 * (uint32_t)T.band_stride + 16u * g;
-    const v4i zero4 = {0, 0, 0, 0};
-    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-    uint4 *my = s_pxw[wave];
-    __syncthreads();
-
-    typedef const __attribute__((address_space(1))) v4i *global_v4i;
-    typedef const __attribute__((address_space(1))) int32_t *global_i32;
-    struct Geo {
-        uint32_t y0, h, n_blk;
-        int32_t n_rg, prec_v;
-        global_v4i av;
-        global_i32 bias_v;
-    };
-    // workgroup-uniform values pinned to SGPRs; pointers rebuilt in the GLOBAL address space (see resize_mfma_cropped_stream_kernel)
-    auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    auto sgpr_ptr = [&](const void *p) __attribute__((always_inline)) {
-        const uint64_t a = (uint64_t)(uintptr_t)p;
-        return (const __attribute__((address_space(1))) void *)(uintptr_t)(((uint64_t)sgpr((uint32_t)(a >> 32)) << 32) | sgpr((uint32_t)a));
-    };
-    auto geo_of = [&](uint32_t F) __attribute__((always_inline)) {
-        const uint32_t clip = sgpr(F >> 4);
-        Geo q;
-        q.y0 = sgpr(clips[clip].y0);
-        q.h = sgpr(clips[clip].h);
-        q.n_blk = (q.h + 15u) / 16u;
-        const uint32_t vt = sgpr(clips[clip].v_table);
-        q.av = (global_v4i)sgpr_ptr(tables[vt].operand);
-        q.bias_v = (global_i32)sgpr_ptr(tables[vt].bias);
-        q.n_rg = (int32_t)sgpr((uint32_t)tables[vt].n_tiles);
-        q.prec_v = (int32_t)sgpr((uint32_t)tables[vt].precision);
-        return q;
-    };
-    auto issue_dma = [&](uint32_t F, const Geo &q, uint32_t b) __attribute__((always_inline)) {
-        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = (q.y0 + 16u * b) * W, bytes = min(16u, q.h - 16u * b) * W;
-        for (uint32_t off = 0; off < bytes; off += 1024u) {
-            auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, (int)(start + off + 16u * lane), 0, 0, VDF_STREAM_AUX);
-        }
-    };
-    uint32_t parity = 0;
-    uint32_t F = blockIdx.x;
-    Geo cur = {};
-    if (F < n_frames) {
-        cur = geo_of(F);
-        if (wave < cur.n_blk) issue_dma(F, cur, wave);
-    }
-    for (; F < n_frames; F += gridDim.x) {
-        const uint32_t Fn = F + gridDim.x;
-        Geo nxt = cur;
-        if (Fn < n_frames) nxt = geo_of(Fn);
-        v4i bias_v = zero4;  // consumed by wave 0 at the end of the frame
-        if (wave == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) bias_v[r] = cur.bias_v[4 * g + r];
-        }
-        v4i acc_vh = zero4, acc_vl = zero4;
-        bool next_issued = false;  // this wave's first block of the next frame goes out behind its LAST block of this one
-        for (uint32_t b = wave; b < cur.n_blk; b += 4) {
-            const uint32_t rg = min(b >> 2, (uint32_t)cur.n_rg - 1u);
-            const v4i avh = cur.av[(rg * 2 + 0) * 64 + lane], avl = cur.av[(rg * 2 + 1) * 64 + lane];
-            asm volatile("" ::"v"(avh), "v"(avl) : "memory");  // requested after this block's DMA: in, once they are (VMEM returns in order)
-            v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
-            const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * W + 16u * g;
-            auto tile = [&](int kt) __attribute__((always_inline)) {
-                const uint4 p = *reinterpret_cast<const uint4 *>(base + 64 * kt);
-                const v4i a = (v4i){(int)p.x, (int)p.y, (int)p.z, (int)p.w} ^ x80;
-                const uint32_t j = (uint32_t)(kt - band_lo);
-                const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
-                const uint4 th = *reinterpret_cast<const uint4 *>(q), tl = *reinterpret_cast<const uint4 *>(q + 64);
-                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
-                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
-            };
-            int kt = 0;
-            for (; kt + 3 < T.n_kt; kt += 4) { tile(kt); tile(kt + 1); tile(kt + 2); tile(kt + 3); }
-            for (; kt < T.n_kt; kt++) tile(kt);
-            const int val = (int)finalize4(ah, al, T.prec_h);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the buffer is consumed: it may be overwritten
-            if (b + 4 < cur.n_blk) issue_dma(F, cur, b + 4);
-            else if (Fn < n_frames && wave < nxt.n_blk) { issue_dma(Fn, nxt, wave); next_issued = true; }
-            const uint32_t mb = b & 3u;
-            v4i bb;
-#pragma unroll
-            for (int m = 0; m < 4; m++) bb[m] = mb == (uint32_t)m ? val : 0;
-            acc_vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, bb, acc_vh, 0, 0, 0);
-            acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, bb, acc_vl, 0, 0, 0);
-        }
-        // a wave without a block in this (short) box still owes its first block of the next frame
-        if (!next_issued && Fn < n_frames && wave < nxt.n_blk) issue_dma(Fn, nxt, wave);
-        if (wave > 0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) s_part[parity][wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (wave == 0) {
-            v4i vl = acc_vl;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                vl[r] += bias_v[r];
-#pragma unroll
-                for (int w = 0; w < 3; w++) vl[r] += s_part[parity][w][lane][r];
-            }
-            const uint32_t px = finalize4(acc_vh, vl, cur.prec_v) ^ 0x80808080u;
-            uint8_t *dst = small + (size_t)F * 256;
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
-        }
-        parity ^= 1u;
-        cur = nxt;
-    }
-}
-
 hipError_t launch_resize_mfma_rowcrop_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                                  size_t clip_stride, const MfmaResizeArgs &a, const CropStreamClip *clips,
                                                  const CropStreamTable *tables, uint8_t *small, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || !resize_wavestream_applies(w) || stream_pitch(w) != w)
-        return hipErrorInvalidValue;
+    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || !resize_wavestream_applies(w)) return hipErrorInvalidValue;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t n_frames = (uint32_t)(n_clips * 16);
-    hipLaunchKernelGGL((resize_mfma_rowcrop_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes>), dim3(std::min<uint32_t>(n_frames, (uint32_t)cus)),
-                       dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), clips, tables, small);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16), wp = stream_pitch(w), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
+    if (wp == w)
+        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 0, true>), dim3(grid), dim3(256), 0, stream,
+                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
+    else if (w % 4 == 0)
+        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 1, true>), dim3(grid), dim3(256), 0, stream,
+                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
+    else
+        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 2, true>), dim3(grid), dim3(256), 0, stream,
+                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
     return hipGetLastError();
 }
 

@@ -45,6 +45,15 @@ bool resize_wavestream_applies(uint32_t w)
     return stream_class(w, &nb) == 3 && nb <= 2 && 16u * stream_pitch(w) + 128u <= (uint32_t)kWaveStreamBuf;
 }
 
+bool resize_rowcrop_streams(uint32_t w)
+{
+    // Full-width crop boxes (top / bottom bars) through the ROWCROP stream kernels against the general cropped kernels, detect + crop +
+    // hash of clips with 12 % bars (gpurun_out/r03v, r03w): 1600 wide 3.83 -> 3.07 ms, 1366 1.73 -> 1.51, 3840 5.29 -> 4.65, 1920 4.76 ->
+    // 4.33, 1280 4.43 -> 4.16, 640 / 854 -3 %, 896 / 1152 / 2560 level - but the widths whose rows the DMA re-pitches (multiples of 256
+    // bytes) lose 2-4 % to the whole-line cropped kernel up to 2048 columns (768, 1024, 1536, 2048), 1280 and 1792 excepted.
+    return !(w % 256 == 0 && w <= 2048) || w == 1280 || w == 1792;
+}
+
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                             bool aligned_too)
 {

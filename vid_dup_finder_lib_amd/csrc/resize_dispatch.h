@@ -40,6 +40,9 @@ bool resize_stream_wants_band(uint32_t w);
 // band-class widths whose chunk would hold at most two 16-row blocks and whose (re-pitched) block fits a per-wave buffer:
 // resize_mfma_frame_wavestream_kernel takes them (1328 .. 1920 columns)
 bool resize_wavestream_applies(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
+// Clips whose crop boxes are full-width (top / bottom bars only): do the ROWCROP instantiations of the stream kernels beat the general
+// cropped kernels at this frame width?  (measured; the frame must also pass resize_stream_eligible / resize_ksplit_eligible)
+bool resize_rowcrop_streams(uint32_t w);
 // Frames starting on 16-byte boundaries, rows packed inside a frame (frames and clips may be padded).  Widths that are a
 // multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
 // kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1536 wide - 2 % with 48 KB chunks);

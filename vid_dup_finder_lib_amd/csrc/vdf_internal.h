@@ -113,14 +113,20 @@ hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint
                                      const MfmaResizeArgs &a, uint8_t *small, bool wide, hipStream_t stream);
 // linear-stream form for tightly packed frames whose width is a multiple of 16 but not of the 128-byte line
 // (a.av in kMfmaLayoutVertical order); resize_stream_eligible says whether a call qualifies
+// clips / tables (both or neither): per-clip row ranges - clip c contributes rows y0 .. y0 + h of its frames (full-width crop
+// boxes: top / bottom letterbox bars), resized with vertical table entry v_table; a.av / a.bias_v / a.prec_v / a.n_rg are then unused
+struct CropStreamClip;
+struct CropStreamTable;
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
-                                            uint8_t *small, hipStream_t stream);
+                                            uint8_t *small, hipStream_t stream, const CropStreamClip *clips = nullptr,
+                                            const CropStreamTable *tables = nullptr);
 // K-split form for wide frames (1024..4096 columns, a multiple of 16): horizontal table in registers, a.bh in plain
 // kMfmaLayoutHorizontal form, a.av in kMfmaLayoutVertical order
 hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
-                                            uint8_t *small, hipStream_t stream);
+                                            uint8_t *small, hipStream_t stream, const CropStreamClip *clips = nullptr,
+                                            const CropStreamTable *tables = nullptr);
 // ---- letterbox crop detection + cropped resize -------------------------------------------
 struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
     uint32_t x0, y0, w, h;
