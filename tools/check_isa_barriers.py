@@ -5,11 +5,12 @@ The kernels that hand a DMA-filled LDS buffer from four issuing waves to four co
 resize_mfma_frame_ksplit_kernel, resize_mfma_cropped_stream_kernel) need each wave's own LDS-DMA instructions to have landed before it
 arrives at the barrier.  The compiler once dropped the wait that the fence of __syncthreads() used to bring along (round 3: wrong hashes
 in one instantiation), so the wait is explicit in the source - and this script checks the generated code of every instantiation:
-compile csrc/dct_hash.hip to gfx950 assembly, walk each of those kernels, and for every `s_barrier` that is not one of the hand-written
+compile csrc/dct_hash.hip and csrc/hamming.hip (whose matrix-core search kernels hand candidate stages over the same way) to gfx950
+assembly, walk each of those kernels, and for every `s_barrier` that is not one of the hand-written
 LDS-only barriers (`s_waitcnt lgkmcnt(0)` + `s_barrier` inside one inline-asm block) require an `s_waitcnt vmcnt(0)` among the
 instructions between the last label and the barrier.
 
-    python tools/check_isa_barriers.py [path/to/dct_hash.s]      exit code 0 = every hand-over barrier waits
+    python tools/check_isa_barriers.py [path/to/kernels.s]      exit code 0 = every hand-over barrier waits
 """
 import os
 import re
@@ -18,19 +19,23 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("resize_mfma_frame_stream_kernel", "resize_mfma_frame_ksplit_kernel", "resize_mfma_cropped_stream_kernel")
+KERNELS = ("resize_mfma_frame_stream_kernel", "resize_mfma_frame_ksplit_kernel", "resize_mfma_cropped_stream_kernel",
+           "hamming_mfma2_kernel", "hamming_mfma_kernel")  # the search kernels hand their candidate stages over the same way
 
 
 def assembly(path=None):
     if path:
         return open(path).read()
     csrc = os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc")
+    text = ""
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "dct_hash.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S",
-                        "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(csrc, "dct_hash.hip"), "-o", out],
-                       check=True, stderr=subprocess.DEVNULL)
-        return open(out).read()
+        for src in ("dct_hash.hip", "hamming.hip"):
+            out = os.path.join(tmp, src + ".s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S",
+                            "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(csrc, src), "-o", out],
+                           check=True, stderr=subprocess.DEVNULL)
+            text += open(out).read() + "\n"
+    return text
 
 
 def check(text):

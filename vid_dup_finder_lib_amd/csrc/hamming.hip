@@ -622,7 +622,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
             }
         }
         }
-        if (ABLATE < 3 || ABLATE == 4 || ABLATE >= 6) __syncthreads();  // waits for the DMA (vmcnt) and for every wave to be done with `cur`
+        if (ABLATE < 3 || ABLATE == 4 || ABLATE >= 6) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
+            __syncthreads();  // the DMA has landed (every wave waited for its own pieces) and every wave is done with `cur`
+        }
     };
 #pragma unroll
     for (int i = 0; i < kDmaPerWave; i++) load_piece(stage_rsrc(cb0), s_b0, i);
@@ -632,6 +635,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
     for (int rt = 0; rt < kRowTiles; rt++)
 #pragma unroll
         for (int s = 0; s < 16; s++) asm volatile("" ::"v"(a[rt][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
     __syncthreads();
     for (uint32_t cb = cb0; cb < c_end; cb += 2 * kMfmaColStep) {
         run_stage(cb, s_b0, s_b1);
@@ -1026,7 +1030,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         flags &= valid;
         n_early += (uint32_t)__builtin_popcount(valid & ~flags);
 #ifndef VDF_M2_ABL_NOBARRIER  // ablation (with NODMA): no barrier between stages
-        __syncthreads();  // waits for the DMA and the threshold load (vmcnt) and for every wave to be done with `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
+        __syncthreads();  // the DMA and the threshold load have landed (every wave waited for its own) and every wave is done with `cur`
 #endif
 #pragma unroll
         for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
@@ -1039,6 +1044,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
         for (int s = 0; s < K; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
     __syncthreads();
 #ifdef VDF_M2_SETPRIO  // experiment: static priority for the second-dispatched half of the workgroup (waves w and w + 4 share a SIMD)
     if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(VDF_M2_SETPRIO);
