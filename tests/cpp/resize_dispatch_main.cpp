@@ -35,7 +35,7 @@ int main()
             // every DMA instruction fills a whole KB of LDS, and the last operand read may run 64 + 16 + 3 bytes past the chunk
             CHECK(((16 * nb * wp + 1023) & ~1023u) + 128 <= (uint32_t)buf, "chunk fits its buffer w=%u cls=%d nb=%u wp=%u", w, cls, nb, wp);
             CHECK(cls == 3 ? n_kt > kStreamTabM : n_kt <= (cls == 1 ? kStreamTabS : kStreamTabM), "table class w=%u cls=%d n_kt=%d", w, cls, n_kt);
-            CHECK(resize_stream_wants_band(w) == (cls == 3), "band flag w=%u", w);
+            CHECK(resize_stream_wants_band(w) == (cls == 3 || resize_wavestream_applies(w)), "band flag w=%u", w);
         }
         for (uint32_t h : {129u, 270u, 1080u, 1088u}) {
             const size_t fs = (size_t)w * h;
@@ -85,21 +85,33 @@ int main()
         CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should stream by default", w);
     for (uint32_t w : {2048u, 3840u, 48u, 63u})
         CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should not stream by default", w);
-    // the per-wave block streams: band-class widths with at most two blocks per chunk whose re-pitched block fits a wave's buffer
+    // the per-wave block streams: every M-class width (from 462 columns) whose pitch is at most 1920, with as many waves as block buffers fit; the (whole-KB) block
+    // fits the wave's buffer, the workgroup fits the CU's LDS, and the width's band table fits the table array of that wave count
     for (uint32_t w = 1; w <= 4200; w++) {
         uint32_t nb = 0;
         const int cls = stream_class(w, &nb);
-        if (resize_wavestream_applies(w)) {
-            CHECK(cls == 3 && nb <= 2 && w >= 1280 && w <= 1920, "wave-stream width w=%u cls=%d nb=%u", w, cls, nb);
-            CHECK(16 * stream_pitch(w) + 128 <= (uint32_t)kWaveStreamBuf && 4 * kWaveStreamBuf + kWaveStreamTabBytes + 2 * kStreamPartBytes <= kLdsPerCu,
-                  "wave-stream block fits w=%u", w);
+        const int nw = resize_wavestream_waves(w);
+        CHECK(resize_wavestream_applies(w) == (nw != 0), "applies <-> waves w=%u", w);
+        if (nw) {
+            CHECK(cls >= 2 && w >= 256 && stream_pitch(w) <= 1920, "wave-stream width w=%u cls=%d nb=%u", w, cls, nb);
+            CHECK(nw == 4 || nw == 5 || nw == 6 || nw == 8, "wave count w=%u nw=%d", w, nw);
+            const int buf = nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : kWaveStreamBuf8;
+            const int tab = nw == 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall;
+            CHECK(((16 * stream_pitch(w) + 1023) & ~1023u) + 128 <= (uint32_t)buf, "wave-stream block fits w=%u nw=%d", w, nw);
+            CHECK(nw * buf + tab + 2 * (nw - 1) * 1024 <= kLdsPerCu, "wave-stream workgroup fits the LDS w=%u nw=%d", w, nw);
+            MfmaAxisTable t;
+            build_mfma_axis_table(w, kMfmaLayoutHorizontalBand, t);
+            CHECK(t.ok && 16 * t.band_stride + 128 <= tab, "band table fits w=%u nw=%d: %d bytes of %d", w, nw, 16 * t.band_stride + 128, tab);
+        } else if (w >= 256 && stream_pitch(w) <= 1920) {
+            CHECK(cls < 2, "every M-class width with a pitch up to 1920 takes the per-wave streams w=%u cls=%d", w, cls);
         }
     }
-    for (uint32_t w : {1360u, 1366u, 1440u, 1536u, 1600u, 1680u, 1792u, 1904u, 1920u}) CHECK(resize_wavestream_applies(w), "%u wide takes the per-wave streams", w);
-    for (uint32_t w : {1280u, 1024u, 1921u, 1936u, 1984u, 2048u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
-    // full-width crop boxes: the ROWCROP stream kernels everywhere but the re-pitched multiples of 256 up to 2048 columns (measured)
-    for (uint32_t w : {64u, 426u, 640u, 854u, 1280u, 1366u, 1600u, 1792u, 1920u, 2560u, 3840u, 4096u}) CHECK(resize_rowcrop_streams(w), "%u wide: row-cropped stream kernels", w);
-    for (uint32_t w : {256u, 512u, 768u, 1024u, 1536u, 2048u}) CHECK(!resize_rowcrop_streams(w), "%u wide: general cropped kernels", w);
+    for (uint32_t w : {528u, 640u, 854u, 1024u, 1280u, 1360u, 1366u, 1440u, 1536u, 1600u, 1680u, 1792u, 1904u, 1920u}) CHECK(resize_wavestream_applies(w), "%u wide takes the per-wave streams", w);
+    for (uint32_t w : {480u, 320u, 1910u, 1921u, 1936u, 1984u, 2048u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
+    CHECK(resize_wavestream_waves(640) == 8 && resize_wavestream_waves(1152) == 6 && resize_wavestream_waves(1366) == 5 && resize_wavestream_waves(1920) == 4, "documented wave counts");
+    // full-width crop boxes: the ROWCROP stream kernels everywhere but 2048 columns (measured)
+    for (uint32_t w : {64u, 426u, 640u, 768u, 854u, 1024u, 1280u, 1366u, 1536u, 1600u, 1792u, 1920u, 2560u, 3840u, 4096u}) CHECK(resize_rowcrop_streams(w), "%u wide: row-cropped stream kernels", w);
+    CHECK(!resize_rowcrop_streams(2048), "2048 wide: general cropped kernels");
     uint32_t kp = 0;
     CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");
     CHECK(ksplit_geometry(2048, &kp) == 2 && kp == 2064, "2048 wide: two blocks per chunk");

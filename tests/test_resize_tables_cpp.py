@@ -24,7 +24,8 @@ def test_stream_kernel_geometry_fits_its_buffers_for_every_width():
     os.makedirs(out_dir, exist_ok=True)
     exe = os.path.join(out_dir, "resize_dispatch")
     src = [os.path.join(ROOT, "tests", "cpp", "resize_dispatch_main.cpp"),
-           os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc", "resize_dispatch.cpp")]
+           os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc", "resize_dispatch.cpp"),
+           os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc", "resize_tables.cpp")]  # band tables against the per-wave kernels' table arrays
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-o", exe] + src)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "resize dispatch ok" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -1039,8 +1039,10 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 // multiple of 16 bytes; 2 = row starts that are not dword-aligned: one more dword per operand read and a per-lane byte shift).
 // ROWCROP: per-clip row ranges (see row_geo_of): the box's first row, block count and vertical table change from clip to clip; a wave
 // without a block in a short box still issues its first block of the next frame.
-template <int BUF_BYTES, int TAB_BYTES, int MODE, bool ROWCROP = false>
-__global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
+// NW waves per workgroup, each with its own block buffer: four for the widest frames (30 KB blocks), more for narrower ones, so that the
+// blocks in flight per CU stay near 120 KB whatever the width.
+template <int NW, int BUF_BYTES, int TAB_BYTES, int MODE, bool ROWCROP = false>
+__global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                            uint32_t H, size_t frame_stride,
                                                                            size_t clip_stride, uint32_t n_frames,
                                                                            MfmaResizeTables T, uint32_t Wp, uint8_t *__restrict__ small,
@@ -1048,8 +1050,8 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
                                                                            const CropStreamTable *__restrict__ tables_g = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
-    __shared__ __attribute__((aligned(16))) uint4 s_pxw[4][BUF_BYTES / 16];
-    __shared__ int32_t s_part[2][3][64][4];  // [frame parity][wave 1..3]: 256 hi + lo
+    __shared__ __attribute__((aligned(16))) uint4 s_pxw[NW][BUF_BYTES / 16];
+    __shared__ int32_t s_part[2][NW - 1][64][4];  // [frame parity][wave 1..]: 256 hi + lo
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t frame_bytes = W * H;
@@ -1063,7 +1065,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
         for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
     }
     const uint32_t tab_vecs = (uint32_t)T.band_stride;  // 16 outputs x stride / 16 bytes
-    for (uint32_t i = tid; i < tab_vecs; i += 256u) {
+    for (uint32_t i = tid; i < tab_vecs; i += 64u * NW) {
         const v4i v = T.bh[i];
         s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
     }
@@ -1125,7 +1127,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
             }
             if constexpr (MODE == 2) shift = (geo.y0 * W + r16 * W) & 3u;
         }
-        for (uint32_t b = wave; b < n_blk; b += 4) {
+        for (uint32_t b = wave; b < n_blk; b += NW) {
             // vertical fragments of this block's 64-row group (global loads: issued before the wait, consumed after the products)
             const uint32_t rg = min(b >> 2, (uint32_t)geo.n_rg - 1u);
             const v4i avh = geo.av[(rg * 2 + 0) * 64 + lane], avl = geo.av[(rg * 2 + 1) * 64 + lane];
@@ -1161,7 +1163,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
             // the buffer is free: the products above consumed every LDS read of it.  Next block of this frame, or this wave's
             // first block of the next frame - before the frame-end barrier, so the stream never drains
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (b + 4 < n_blk) issue_dma(F, b + 4, geo);
+            if (b + NW < n_blk) issue_dma(F, b + NW, geo);
             else if (Fn < n_frames && 16u * wave < geo_n.h) { issue_dma(Fn, wave, geo_n); next_issued = true; }
             const uint32_t mb = b & 3u;
             v4i bb;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_wavestream_kernel(const
             for (int r = 0; r < 4; r++) {
                 vl[r] += bias_v[r];
 #pragma unroll
-                for (int w = 0; w < 3; w++) vl[r] += s_part[parity][w][lane][r];
+                for (int w = 0; w < NW - 1; w++) vl[r] += s_part[parity][w][lane][r];
             }
             const uint32_t px = finalize4(acc_vh, vl, geo.prec_v) ^ 0x80808080u;
             uint8_t *dst = small + (size_t)F * 256;
@@ -1225,6 +1227,49 @@ static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t 
                            frame_stride, clip_stride, n_frames, T, nb, wp, small);
 }
 
+// per-wave block streams: NW by the width (resize_wavestream_waves), MODE by the pitch, ROWCROP when clips carry row ranges
+template <int NW, int BUF, int TAB>
+static void launch_wavestream_nw(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride,
+                                 size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T, uint8_t *small,
+                                 const CropStreamClip *clips, const CropStreamTable *tables)
+{
+    const uint32_t wp = stream_pitch(w);
+    const int mode = wp == w ? 0 : w % 4 == 0 ? 1 : 2;
+#define VDF_WS_LAUNCH(M, RC)                                                                                                              \
+    hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<NW, BUF, TAB, M, RC>), dim3(grid), dim3(64 * NW), 0, stream, frames, w, h, \
+                       frame_stride, clip_stride, n_frames, T, wp, small, clips, tables)
+    if (clips) {
+        if (mode == 0) VDF_WS_LAUNCH(0, true);
+        else if (mode == 1) VDF_WS_LAUNCH(1, true);
+        else VDF_WS_LAUNCH(2, true);
+    } else {
+        if (mode == 0) VDF_WS_LAUNCH(0, false);
+        else if (mode == 1) VDF_WS_LAUNCH(1, false);
+        else VDF_WS_LAUNCH(2, false);
+    }
+#undef VDF_WS_LAUNCH
+}
+
+static hipError_t launch_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                    const MfmaResizeArgs &a, const CropStreamClip *clips, const CropStreamTable *tables, uint8_t *small,
+                                    hipStream_t stream)
+{
+    const int nw = resize_wavestream_waves(w);
+    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || nw == 0) return hipErrorInvalidValue;
+    const int tab_bytes = 16 * a.band_stride + 128;  // + the zero slot
+    if (tab_bytes > (nw == 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall)) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_frames = (uint32_t)(n_clips * 16), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
+    const MfmaResizeTables T = make_tables(a);
+    if (nw == 4) launch_wavestream_nw<4, kWaveStreamBuf, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    else if (nw == 5) launch_wavestream_nw<5, kWaveStreamBuf5, kWaveStreamTabMid>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    else if (nw == 6) launch_wavestream_nw<6, kWaveStreamBuf6, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    else launch_wavestream_nw<8, kWaveStreamBuf8, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
                                             size_t frame_stride, size_t clip_stride, const MfmaResizeArgs &a,
                                             uint8_t *small, hipStream_t stream, const CropStreamClip *clips,
@@ -1238,28 +1283,16 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
-    if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
+    if (resize_stream_wants_band(w) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
+    if (resize_wavestream_applies(w))
+        return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream);
+    if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;
     if (cls == 1)
         launch_stream_mode<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
                                                             frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
     else if (cls == 2)
         launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                             frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
-    else if (resize_wavestream_applies(w) && !std::getenv("VDF_NO_WAVESTREAM")) {
-        // two blocks per chunk (1328 .. 1920 columns): one block stream per wave keeps 4 x 30 KB in flight
-        const uint32_t wp = stream_pitch(w), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
-        if (clips)  // per-clip row ranges
-            return launch_resize_mfma_rowcrop_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream);
-        if (wp == w)
-            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 0>), dim3(grid), dim3(256), 0, stream,
-                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
-        else if (w % 4 == 0)
-            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 1>), dim3(grid), dim3(256), 0, stream,
-                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
-        else
-            hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 2>), dim3(grid), dim3(256), 0, stream,
-                               frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small);
-    }
     else
         launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
@@ -1741,27 +1774,6 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     write_pending();
 }
 
-hipError_t launch_resize_mfma_rowcrop_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
-                                                 size_t clip_stride, const MfmaResizeArgs &a, const CropStreamClip *clips,
-                                                 const CropStreamTable *tables, uint8_t *small, hipStream_t stream)
-{
-    if (n_clips == 0) return hipSuccess;
-    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || !resize_wavestream_applies(w)) return hipErrorInvalidValue;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t n_frames = (uint32_t)(n_clips * 16), wp = stream_pitch(w), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
-    if (wp == w)
-        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 0, true>), dim3(grid), dim3(256), 0, stream,
-                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
-    else if (w % 4 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 1, true>), dim3(grid), dim3(256), 0, stream,
-                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
-    else
-        hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<kWaveStreamBuf, kWaveStreamTabBytes, 2, true>), dim3(grid), dim3(256), 0, stream,
-                           frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a), wp, small, clips, tables);
-    return hipGetLastError();
-}
 
 hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_clips, uint32_t pitch, uint32_t frame_rows,
                                              size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,

@@ -1,5 +1,7 @@
 #include "resize_dispatch.h"
 
+#include <cstdlib>
+
 namespace vdf {
 
 uint32_t stream_pitch(uint32_t w)
@@ -31,27 +33,47 @@ int stream_class(uint32_t w, uint32_t *nb)
     return *nb >= 2 ? 3 : 0;
 }
 
+static bool wavestream_fits(uint32_t w, int nw)
+{
+    const uint32_t need = ((16u * stream_pitch(w) + 1023u) & ~1023u) + 128u;  // a DMA instruction fills whole KBs
+    const int buf = nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : nw == 8 ? kWaveStreamBuf8 : 0;
+    return need <= (uint32_t)buf && w >= 256;
+}
+
+int resize_wavestream_waves(uint32_t w)
+{
+    if (std::getenv("VDF_NO_WAVESTREAM")) return 0;    // measurements / tests: the chunk kernel everywhere
+    const char *e = std::getenv("VDF_WAVESTREAM_NW");  // (read per call: a sweep changes it between calls)
+    const int forced = e ? std::atoi(e) : 0;
+    if (forced) return wavestream_fits(w, forced) ? forced : 0;
+    uint32_t nb = 0;
+    const int cls = stream_class(w, &nb);
+    // Frames up to 512 wide keep the chunk kernel (two workgroups per CU, whole table in LDS: 480 x 270 6.5 TB/s against 6.0 with eight
+    // waves).  From there on one block stream per wave, with as many waves as block buffers fit: measured against the chunk kernel
+    // (gpurun_out/r03_nw_sweep2.txt) 576 wide 5.9 -> 6.8 TB/s, 640 6.4 -> 6.8, 1152 5.3 -> 6.8, 1200 6.1 -> 6.7, 1366 5.4 -> 6.3,
+    // 1440 5.6 -> 6.3, 1520 6.0 -> 6.8; level at 896 / 960.  (With FOUR waves the three-block widths had measured slower: 1280 x 720
+    // 6.6 -> 5.8 - the point is the bytes in flight per CU, not the absence of the barrier.)
+    if (cls < 2) return 0;
+    for (int nw : {8, 6, 5, 4})
+        if (wavestream_fits(w, nw)) return nw;
+    return 0;
+}
+
 bool resize_stream_wants_band(uint32_t w)
 {
     uint32_t nb = 0;
-    return stream_class(w, &nb) == 3;
+    return stream_class(w, &nb) == 3 || resize_wavestream_waves(w) != 0;
 }
 
-bool resize_wavestream_applies(uint32_t w)
-{
-    uint32_t nb = 0;
-    // two blocks per chunk only: with three (1040 .. 1312 columns) the chunk kernel keeps three waves busy and 62 KB in flight, and the
-    // per-wave form measured SLOWER (1280 x 720 6.63 -> 5.78 TB/s, 1056 x 594 6.45 -> 5.94; gpurun_out/r03q)
-    return stream_class(w, &nb) == 3 && nb <= 2 && 16u * stream_pitch(w) + 128u <= (uint32_t)kWaveStreamBuf;
-}
+bool resize_wavestream_applies(uint32_t w) { return resize_wavestream_waves(w) != 0; }
 
 bool resize_rowcrop_streams(uint32_t w)
 {
     // Full-width crop boxes (top / bottom bars) through the ROWCROP stream kernels against the general cropped kernels, detect + crop +
-    // hash of clips with 12 % bars (gpurun_out/r03v, r03w): 1600 wide 3.83 -> 3.07 ms, 1366 1.73 -> 1.51, 3840 5.29 -> 4.65, 1920 4.76 ->
-    // 4.33, 1280 4.43 -> 4.16, 640 / 854 -3 %, 896 / 1152 / 2560 level - but the widths whose rows the DMA re-pitches (multiples of 256
-    // bytes) lose 2-4 % to the whole-line cropped kernel up to 2048 columns (768, 1024, 1536, 2048), 1280 and 1792 excepted.
-    return !(w % 256 == 0 && w <= 2048) || w == 1280 || w == 1792;
+    // hash of clips with 12 % bars (gpurun_out/r03v, r03w, r03y): 1600 wide 3.83 -> 2.87 ms, 1152 3.51 -> 3.12, 1280 4.39 -> 3.91,
+    // 1366 1.73 -> 1.51, 3840 5.29 -> 4.65, 1920 4.76 -> 4.33, 1536 3.13 -> 2.90, 1024 2.80 -> 2.64, 640 / 768 / 854 -3 %, 2560 level;
+    // 2048 wide (the K-split form with two-block chunks) lost 4 % to the whole-line cropped kernel and stays there.
+    return w != 2048;
 }
 
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,

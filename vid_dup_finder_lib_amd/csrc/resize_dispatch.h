@@ -18,6 +18,11 @@ constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
 constexpr int kKsplitBuf = 75 * 1024 + 128;
 constexpr int kWaveStreamBuf = 16 * 1920 + 128;  // one 16-row block of a frame up to 1920 wide per wave (round 3: resize_mfma_frame_wavestream_kernel)
 constexpr int kWaveStreamTabBytes = 16 * (kMfmaBandMaxTiles * 128 + 32) + 128;  // band table + zero slot
+// narrower frames: more waves, each with its own (smaller) block buffer, so that the blocks in flight per CU stay near 120 KB.
+// A block's DMA instructions fill whole KBs: the buffers are the block rounded up to 1 KB (+ the operand reads' overrun).
+constexpr int kWaveStreamBuf5 = 25 * 1024 + 128, kWaveStreamBuf6 = 21 * 1024 + 128, kWaveStreamBuf8 = 15 * 1024 + 128;  // pitches up to 1600, 1344, 960
+constexpr int kWaveStreamTabMid = 16 * (12 * 128 + 32) + 128;    // band tables of at most 12 tiles per output (five waves: frames up to 1600 columns)
+constexpr int kWaveStreamTabSmall = 16 * (10 * 128 + 32) + 128;  // at most 10 (six and eight waves: up to 1344 columns)
 constexpr int kStreamPartBytes = 3 * 64 * 4 * 4;  // s_part: the vertical partial sums of waves 1..3
 constexpr int kLdsPerCu = 160 * 1024;
 static_assert(16 * (kMfmaBandMaxTiles * 128 + 32) + 128 <= kStreamTabM * 2048, "band table + zero slot fit the M class");
@@ -25,6 +30,9 @@ static_assert(2 * (2 * kStreamBufS + kStreamTabS * 2048 + kStreamPartBytes) <= k
 static_assert(2 * kStreamBufM + kStreamTabM * 2048 + kStreamPartBytes <= kLdsPerCu, "one M workgroup per CU");
 static_assert(2 * kKsplitBuf + 2 * 3 * 64 * 16 + kStreamPartBytes <= kLdsPerCu, "one K-split workgroup per CU");
 static_assert(4 * kWaveStreamBuf + kWaveStreamTabBytes + 2 * kStreamPartBytes <= kLdsPerCu, "one per-wave-stream workgroup per CU");
+static_assert(5 * kWaveStreamBuf5 + kWaveStreamTabMid + 2 * 4 * 1024 <= kLdsPerCu, "five waves");
+static_assert(6 * kWaveStreamBuf6 + kWaveStreamTabSmall + 2 * 5 * 1024 <= kLdsPerCu, "six waves");
+static_assert(8 * kWaveStreamBuf8 + kWaveStreamTabSmall + 2 * 7 * 1024 <= kLdsPerCu, "eight waves");
 
 // LDS row pitch of the stream kernel: the frame's own for multiples of 16 - unless it is a multiple of 256, where the 16
 // rows of a block would share one bank group (16-way conflict on every operand read: re-pitched, 768 / 1024 / 1280 wide
@@ -40,6 +48,9 @@ bool resize_stream_wants_band(uint32_t w);
 // band-class widths whose chunk would hold at most two 16-row blocks and whose (re-pitched) block fits a per-wave buffer:
 // resize_mfma_frame_wavestream_kernel takes them (1328 .. 1920 columns)
 bool resize_wavestream_applies(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
+// ... and with how many waves per workgroup (4, 5, 6 or 8; 0 = the width does not take the per-wave form).  VDF_WAVESTREAM_NW=n forces
+// n waves on every width whose block fits the n-wave buffer (measurements).
+int resize_wavestream_waves(uint32_t w);
 // Clips whose crop boxes are full-width (top / bottom bars only): do the ROWCROP instantiations of the stream kernels beat the general
 // cropped kernels at this frame width?  (measured; the frame must also pass resize_stream_eligible / resize_ksplit_eligible)
 bool resize_rowcrop_streams(uint32_t w);

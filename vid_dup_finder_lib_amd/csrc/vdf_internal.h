@@ -154,11 +154,6 @@ hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_cli
                                              size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
                                              const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
                                              hipStream_t stream);  // shift: some row of some box starts off a dword boundary
-// clips whose crop boxes are full-width (top / bottom bars only), frame widths of the per-wave stream kernel at their own pitch:
-// clips[c] gives y0, h and the vertical table entry; a = the frame width's band table
-hipError_t launch_resize_mfma_rowcrop_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
-                                                 size_t clip_stride, const MfmaResizeArgs &a, const CropStreamClip *clips,
-                                                 const CropStreamTable *tables, uint8_t *small, hipStream_t stream);
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
                             size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
