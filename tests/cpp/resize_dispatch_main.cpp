@@ -35,15 +35,16 @@ int main()
             // every DMA instruction fills a whole KB of LDS, and the last operand read may run 64 + 16 + 3 bytes past the chunk
             CHECK(((16 * nb * wp + 1023) & ~1023u) + 128 <= (uint32_t)buf, "chunk fits its buffer w=%u cls=%d nb=%u wp=%u", w, cls, nb, wp);
             CHECK(cls == 3 ? n_kt > kStreamTabM : n_kt <= (cls == 1 ? kStreamTabS : kStreamTabM), "table class w=%u cls=%d n_kt=%d", w, cls, n_kt);
-            CHECK(resize_stream_wants_band(w) == (cls == 3 || resize_wavestream_applies(w)), "band flag w=%u", w);
+            CHECK(resize_stream_wants_band(w) == resize_wavestream_applies(w), "band flag w=%u", w);
         }
         for (uint32_t h : {129u, 270u, 1080u, 1088u}) {
             const size_t fs = (size_t)w * h;
-            const bool e = resize_stream_eligible(aligned, w, h, (fs + 15) & ~size_t(15), 16 * ((fs + 15) & ~size_t(15)), false);
+            const bool e = resize_stream_eligible(aligned, w, h, (fs + 15) & ~size_t(15), 16 * ((fs + 15) & ~size_t(15)));
             if (e) CHECK(cls != 0 && w >= 64, "eligible implies a class w=%u", w);
-            if (cls != 0 && w >= 64 && w % 128 != 0 && ((uint64_t)w * h) % 16 == 0) CHECK(e, "every unaligned width with a class streams w=%u", w);
+            if ((cls == 1 || resize_wavestream_applies(w)) && w >= 64 && ((uint64_t)w * h) % 16 == 0) CHECK(e, "every width of the chunk or per-wave form streams w=%u", w);
+            if (cls >= 2 && !resize_wavestream_applies(w)) CHECK(!e, "M-class widths beyond the per-wave buffers (pitch > 1920) take the whole-line kernel w=%u", w);
             if (((uint64_t)w * h) % 16 != 0) CHECK(!e, "frames that do not end on a 16-byte boundary must not stream w=%u h=%u", w, h);
-            CHECK(!resize_stream_eligible(aligned + 4, w, h, fs, 16 * fs, true), "misaligned base must not stream w=%u", w);
+            CHECK(!resize_stream_eligible(aligned + 4, w, h, fs, 16 * fs), "misaligned base must not stream w=%u", w);
         }
         // ---- K-split kernel
         if (w % 16 == 0 && w >= 1024 && w <= 4096) {
@@ -82,9 +83,9 @@ int main()
         CHECK(cls == q.cls && nb == q.nb, "w=%u: class %d nb %u, expected %d %u", q.w, cls, nb, q.cls, q.nb);
     }
     for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u, 240u, 160u, 128u, 1536u, 1792u})  // 1536 / 1792: per-wave block streams (round 3)
-        CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should stream by default", w);
+        CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "%u wide should stream by default", w);
     for (uint32_t w : {2048u, 3840u, 48u, 63u})
-        CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16, false), "%u wide should not stream by default", w);
+        CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "%u wide should not stream by default", w);
     // the per-wave block streams: every M-class width (from 462 columns) whose pitch is at most 1920, with as many waves as block buffers fit; the (whole-KB) block
     // fits the wave's buffer, the workgroup fits the CU's LDS, and the width's band table fits the table array of that wave count
     for (uint32_t w = 1; w <= 4200; w++) {

@@ -254,8 +254,15 @@ def test_hash_fuzz_wide_frames(seed):
 
 
 _SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
-    ("K-split 2048", 300, 2048, 24, False), ("K-split 3840", 200, 3840, 12, False), ("stream 1024 (re-pitched)", 300, 1024, 32, False),
-    ("stream 422 (shifted)", 240, 422, 40, False), ("wave-stream 1920", 300, 1920, 24, False), ("wave-stream 1440", 200, 1440, 40, False), ("wave-stream 1366 (shifted)", 200, 1366, 40, False), ("wave-stream 1536 (re-pitched)", 200, 1536, 24, False), ("stream band 1984", 200, 1984, 24, False), ("stream 480", 270, 480, 40, False),
+    ("K-split 2048", 300, 2048, 24, False), ("K-split 3840", 200, 3840, 12, False),
+    ("stream 422 (shifted)", 240, 422, 40, False), ("stream 480", 270, 480, 40, False), ("stream 500 (re-pitched)", 288, 500, 40, False),
+    # one block stream per wave: 4, 5, 6 and 8 waves per workgroup, every addressing mode
+    ("wave-stream 1920", 300, 1920, 24, False), ("wave-stream 1792 (re-pitched)", 200, 1792, 24, False), ("wave-stream 1440, 5 waves", 200, 1440, 40, False),
+    ("wave-stream 1366 (shifted), 5 waves", 200, 1366, 40, False), ("wave-stream 1536 (re-pitched), 5 waves", 200, 1536, 24, False),
+    ("wave-stream 1280 (re-pitched), 6 waves", 360, 1280, 24, False), ("wave-stream 1152, 6 waves", 324, 1152, 32, False),
+    ("wave-stream 1001 (shifted), 6 waves", 208, 1001, 32, False), ("wave-stream 640, 8 waves", 360, 640, 40, False),
+    ("wave-stream 854 (shifted), 8 waves", 480, 854, 24, False), ("wave-stream 768 (re-pitched), 8 waves", 432, 768, 32, False),
+    ("whole-line 1984", 200, 1984, 24, False),
     ("whole-line 2000", 200, 2000, 20, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
     ("cropped stream 854", 480, 854, 24, True), ("cropped stream 480", 270, 480, 40, True), ("cropped whole-line 1280", 360, 1280, 16, True),
     # top / bottom bars only: the ROWCROP instantiations of the stream kernels (per-clip first row, height, vertical table)

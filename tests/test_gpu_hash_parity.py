@@ -127,22 +127,19 @@ def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
                                    (360, 640, 3), (432, 768, 2), (720, 1280, 1), (1080, 1920, 1), (300, 1984, 1), (300, 2000, 1),
                                    (426, 240, 40), (144, 176, 40), (200, 160, 3), (256, 192, 3), (256, 128, 3), (300, 200, 3), (333, 64, 3), (200, 80, 3),
                                    (900, 1600, 1), (576, 1024, 1), (136, 1440, 40), (150, 1920, 36), (1080, 1904, 1), (140, 1366, 40), (200, 1536, 24), (130, 1792, 24), (300, 1916, 2),
-                                   (144, 1300, 36), (768, 1534, 1)])
+                                   (144, 1300, 36), (768, 1534, 1), (130, 640, 60), (150, 854, 60), (144, 1152, 40), (129, 768, 45), (140, 1024, 40)])
 def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
-    """Tightly packed frames whose every frame starts on a 16-byte boundary go through the linear-stream kernel (LDS-DMA of
-    whole chunks, operands read back from LDS) when the width is not a multiple of the 128-byte line, or is one and still
-    fits 64-row chunks: 480 / 272 / 320 / 352 / 464 wide = two workgroups per CU with 64-row chunks; 496 / 720 / 960 = the
-    large-LDS form with 64-row chunks, 1360 / 1440 / 1520 with 32-row chunks (two of the four waves multiply); 600 / 500 /
-    854 / 426 / 333 / 1366 wide = rows re-pitched by the DMA to an odd multiple of 16 bytes, the last four with the 0..3-byte
-    operand shift (row starts that are not dword-aligned); 640 / 768 = line-aligned
-    widths the kernel also takes; wider than 1024 = the horizontal table in band form (only the K tiles an output's taps
-    reach), 32- or 48-row chunks; 2000 wide = too wide, falls back to the whole-line kernel; 45 and 40 clips = more frames than resident workgroups,
-    so the persistent loop crosses frame boundaries; 270 / 129 / 333 / 191 rows = partial last chunks and partial blocks;
-    240 / 176 / 160 / 192 / 128 / 200 / 64 / 80 wide = narrow tall frames (portrait video), one to four K tiles.
-    1360 ... 1920 wide at their own pitch = the per-wave block streams of round 3 (resize_mfma_frame_wavestream_kernel): 40 clips of
-    136 x 1440 and 36 of 150 x 1920 = more frames than workgroups (frame boundaries, the parity-doubled partial sums), 9 or 10 blocks
-    per frame (uneven shares of the four waves, a partial last block); 1366 / 1534 / 1300 wide = those streams with rows re-pitched by the
-    DMA (1366, 1534: row starts off a dword), 1536 / 1792 = line-aligned pitches that took the whole-line kernel before round 3."""
+    """Tightly packed frames whose every frame starts and ends on a 16-byte boundary go through the linear-stream kernels (LDS-DMA of
+    whole chunks / blocks, operands read back from LDS).  Up to 512 wide = the chunk form, two workgroups per CU with 64-row chunks
+    (480 / 272 / 320 / 352 / 464; 500 / 426 / 333 = rows re-pitched by the DMA to an odd multiple of 16 bytes, the last two with the
+    0..3-byte operand shift of row starts that are not dword-aligned; 240 / 176 / 160 / 192 / 128 / 200 / 64 / 80 wide = narrow tall
+    frames, one to four K tiles).  From there to 1920 wide = one block stream per wave (resize_mfma_frame_wavestream_kernel), the
+    horizontal table in band form, with 8 waves per workgroup (496 ... 960), 6 (1024 ... 1300), 5 (1360 ... 1600) or 4 (... 1920):
+    600 / 854 / 1366 / 1534 = re-pitched rows (854, 1366, 1534: shifted), 768 / 1024 / 1280 / 1536 / 1792 = multiples of 256 bytes,
+    re-pitched to dodge the 16-way bank conflict; 45 / 40 / 36 clips = more frames than resident workgroups, so the persistent loops
+    cross frame boundaries (the parity-doubled partial sums) with 9 or 10 blocks per frame (uneven shares of the waves, waves
+    without a block, a partial last block); 270 / 129 / 333 / 191 rows = partial last chunks and blocks.  1984 / 2000 / 1916 wide =
+    beyond the per-wave buffers: the whole-line kernel."""
     import vid_dup_finder_lib_amd as vdf
 
     monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))

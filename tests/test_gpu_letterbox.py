@@ -207,7 +207,7 @@ def test_top_bottom_bars_take_the_stream_kernels(engine, monkeypatch, h, w):
     takes at that width, as ROWCROP instantiations with a per-clip first row, height and vertical table.  Boxes of every block
     count (fewer than four 16-row blocks = waves without work, heights off a multiple of 16, one row, odd first rows = chunks that
     start off 4- and 16-byte boundaries), clips without bars among them; equal to the oracle on the cropped copies, to the
-    general cropped kernels (VDF_NO_ROWCROP) and - where the per-wave form exists - to the chunk form (VDF_NO_WAVESTREAM)."""
+    general cropped kernels (VDF_NO_ROWCROP, and VDF_NO_WAVESTREAM where only the per-wave form has a ROWCROP instantiation)."""
     import vid_dup_finder_lib_amd as vdf
 
     rng = np.random.default_rng(h * 7 + w)

@@ -15,7 +15,7 @@ def test_every_hand_over_barrier_waits_for_the_dma():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     seen, bad = mod.check(mod.assembly())
-    assert seen >= 120, seen  # stream 18 + K-split 6 + cropped stream 4 + search 21 instantiations, two or three barriers each
+    assert seen >= 100, seen  # chunk stream 6 + K-split 6 + cropped stream 4 + search 21 instantiations, two or three barriers each
     assert not bad, bad
 
 

@@ -516,7 +516,7 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && (h + 63) / 64 <= 2);
         // tightly packed frames stream linearly through LDS where that is the faster form (resize_stream_eligible)
         bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
-                        vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->resize_mode == 5);
+                        vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
         DeviceMfmaTable *mh = nullptr;
         if (streamed && vdf::resize_stream_wants_band(w)) {  // wide frames: the horizontal table in band form
             mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontalBand, stream, &rc);
@@ -628,7 +628,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     if (ctx->resize_mode == 0 && (h + 63) / 64 > 2 && (vdf::resize_rowcrop_streams(w) || std::getenv("VDF_ROWCROP_ALL")) && !std::getenv("VDF_NO_ROWCROP")) {
         bool rows_only = true;
         for (size_t c = 0; c < n_clips && rows_only; c++) rows_only = crops[4 * c] == 0 && crops[4 * c + 1] == 0;
-        bool streamed = rows_only && vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, false);
+        bool streamed = rows_only && vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
         const bool band = streamed && vdf::resize_stream_wants_band(w);
         const bool ksplit = rows_only && !streamed && w >= 2048 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         int rc = VDF_OK;

@@ -821,7 +821,7 @@ __device__ __forceinline__ RowGeo row_geo_of(const_clip_ptr clips, const_table_p
 // row * W + x.  The global side is still a linear sweep (a row's tail lanes run into the next row).  LDS-DMA ignores the
 // low two bits of a global address, so MODE 2 (W % 4 != 0) starts each row at the dword below it and the operand read
 // takes one more dword and shifts by the row's 0..3 bytes (v_alignbyte, a per-lane constant).
-template <int BUF_BYTES, int TAB_TILES, int MODE, bool BAND, bool ROWCROP = false>
+template <int BUF_BYTES, int TAB_TILES, int MODE, bool ROWCROP = false>
 __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uint8_t *__restrict__ frames, uint32_t W,
                                                                        uint32_t H, size_t frame_stride,
                                                                        size_t clip_stride, uint32_t n_frames,
@@ -859,20 +859,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 #pragma unroll
         for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
     }
-    // horizontal table -> LDS: all K tiles, or (BAND, wide frames) only the tiles each output's taps reach, output-major
-    const uint32_t tab_vecs = BAND ? (uint32_t)T.band_stride : (uint32_t)T.n_kt * 128u;  // 16 outputs x stride / 16 bytes
+    // horizontal table -> LDS, all K tiles
+    const uint32_t tab_vecs = (uint32_t)T.n_kt * 128u;
     for (uint32_t i = tid; i < tab_vecs; i += 256u) {
         const v4i v = T.bh[i];
         s_tab[i] = uint4{(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]};
-    }
-    int32_t band_lo = 0;
-    uint32_t band_nt = 0, band_base = 0;
-    const uint32_t band_zero = 16u * tab_vecs;  // 128 zero bytes behind the band table
-    if constexpr (BAND) {
-        if (tid < 8) s_tab[tab_vecs + tid] = uint4{0, 0, 0, 0};
-        band_lo = T.band_meta[r16];
-        band_nt = (uint32_t)T.band_meta[16 + r16];
-        band_base = r16 * (uint32_t)T.band_stride + 16u * g;
     }
     const v4i zero4 = {0, 0, 0, 0};
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
@@ -956,16 +947,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
                     a[3] = (int)__builtin_amdgcn_alignbyte(nx, p.w, shift);
                 }
                 a = a ^ x80;
-                uint4 th, tl;
-                if constexpr (BAND) {  // no branch: lanes outside their output's band read the zero slot behind the table
-                    const uint32_t j = (uint32_t)(kt - band_lo);
-                    const uint8_t *q = reinterpret_cast<const uint8_t *>(s_tab) + (j < band_nt ? band_base + j * 128u : band_zero);
-                    th = *reinterpret_cast<const uint4 *>(q);
-                    tl = *reinterpret_cast<const uint4 *>(q + 64);
-                } else {
-                    th = s_tab[(kt * 2 + 0) * 64 + lane];
-                    tl = s_tab[(kt * 2 + 1) * 64 + lane];
-                }
+                const uint4 th = s_tab[(kt * 2 + 0) * 64 + lane], tl = s_tab[(kt * 2 + 1) * 64 + lane];
                 ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)th.x, (int)th.y, (int)th.z, (int)th.w}, ah, 0, 0, 0);
                 al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, (v4i){(int)tl.x, (int)tl.y, (int)tl.z, (int)tl.w}, al, 0, 0, 0);
             };
@@ -1198,33 +1180,25 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
     }
 }
 
-template <int BUF, int TAB, bool BAND>
 static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h,
                                size_t frame_stride, size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T,
                                uint32_t nb, uint8_t *small, const CropStreamClip *clips, const CropStreamTable *tables)
 {
     const uint32_t wp = stream_pitch(w);
+    const int mode = wp == w ? 0 : w % 4 == 0 ? 1 : 2;
+#define VDF_CS_LAUNCH(M, RC)                                                                                                               \
+    hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<kStreamBufS, kStreamTabS, M, RC>), dim3(grid), dim3(256), 0, stream, frames, w, h, \
+                       frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables)
     if (clips) {  // per-clip row ranges
-        if (wp == w)
-            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
-        else if (w % 4 == 0)
-            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
-        else
-            hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 2, BAND, true>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                               frame_stride, clip_stride, n_frames, T, nb, wp, small, clips, tables);
-        return;
+        if (mode == 0) VDF_CS_LAUNCH(0, true);
+        else if (mode == 1) VDF_CS_LAUNCH(1, true);
+        else VDF_CS_LAUNCH(2, true);
+    } else {
+        if (mode == 0) VDF_CS_LAUNCH(0, false);
+        else if (mode == 1) VDF_CS_LAUNCH(1, false);
+        else VDF_CS_LAUNCH(2, false);
     }
-    if (wp == w)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 0, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
-    else if (w % 4 == 0)
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 1, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
-    else
-        hipLaunchKernelGGL((resize_mfma_frame_stream_kernel<BUF, TAB, 2, BAND>), dim3(grid), dim3(256), 0, stream, frames, w, h,
-                           frame_stride, clip_stride, n_frames, T, nb, wp, small);
+#undef VDF_CS_LAUNCH
 }
 
 // per-wave block streams: NW by the width (resize_wavestream_waves), MODE by the pitch, ROWCROP when clips carry row ranges
@@ -1286,16 +1260,9 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     if (resize_stream_wants_band(w) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
     if (resize_wavestream_applies(w))
         return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream);
-    if ((cls == 3) != (a.band_meta != nullptr)) return hipErrorInvalidValue;
-    if (cls == 1)
-        launch_stream_mode<kStreamBufS, kStreamTabS, false>(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h,
-                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
-    else if (cls == 2)
-        launch_stream_mode<kStreamBufM, kStreamTabM, false>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                            frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
-    else
-        launch_stream_mode<kStreamBufM, kStreamTabM, true>(std::min<uint32_t>(n_frames, (uint32_t)cus), stream, frames, w, h,
-                                                           frame_stride, clip_stride, n_frames, make_tables(a), nb, small, clips, tables);
+    if (cls != 1 || a.band_meta) return hipErrorInvalidValue;  // the chunk form serves the S class only (frames up to 512 wide, two workgroups per CU)
+    launch_stream_mode(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a),
+                       nb, small, clips, tables);
     return hipGetLastError();
 }
 

@@ -59,11 +59,7 @@ int resize_wavestream_waves(uint32_t w)
     return 0;
 }
 
-bool resize_stream_wants_band(uint32_t w)
-{
-    uint32_t nb = 0;
-    return stream_class(w, &nb) == 3 || resize_wavestream_waves(w) != 0;
-}
+bool resize_stream_wants_band(uint32_t w) { return resize_wavestream_waves(w) != 0; }
 
 bool resize_wavestream_applies(uint32_t w) { return resize_wavestream_waves(w) != 0; }
 
@@ -76,8 +72,7 @@ bool resize_rowcrop_streams(uint32_t w)
     return w != 2048;
 }
 
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
-                            bool aligned_too)
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
 {
     // narrow tall frames (portrait video) gain the most: 240 x 426 4.6 -> 6.1 TB/s, 160 x 200 3.5 -> 4.2 against the whole-line kernels
     if (w < 64 || (uint64_t)w * h >= (1ull << 31)) return false;
@@ -86,11 +81,7 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     if (((uint64_t)w * h) % 16 != 0) return false;
     if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
     uint32_t nb = 0;
-    const int cls = stream_class(w, &nb);
-    if (cls == 0) return false;
-    const bool repitched_whole_table = stream_pitch(w) != w && cls == 2;  // 1024 wide: 48-row chunks of 50 KB, 5.8 against 5.4 TB/s
-    return w % 128 != 0 || nb == 4 || 16u * nb * w >= 56u * 1024u || (repitched_whole_table && 16u * nb * w >= 48u * 1024u) ||
-           resize_wavestream_applies(w) || aligned_too;  // (1536 / 1792 wide: the per-wave block streams of round 3)
+    return stream_class(w, &nb) == 1 || resize_wavestream_applies(w);  // the chunk form (frames up to 512 wide) or one block stream per wave
 }
 
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)

@@ -9,10 +9,11 @@
 
 namespace vdf {
 
-// LDS budget of the stream kernel's instantiations: S = two workgroups per CU (64-row chunks of frames up to 480 wide);
-// M = one workgroup per CU, 32 KB of table and two 62 KB chunk buffers: frames up to 1024 wide keep the whole table there,
-// wider ones (up to 1984: two 16-row blocks per chunk) its band form (16 outputs x at most 15 tiles x 128 B + padding).
-// The K-split kernel keeps its table in registers: two 75 KB buffers.  + 128: the operand reads' overrun past the last row.
+// LDS budgets of the linear-stream kernels.  Chunk form (resize_mfma_frame_stream_kernel, frames up to 512 wide): S = two workgroups
+// per CU, 64-row chunks, whole table.  The M sizes (one workgroup per CU, 32 KB of table, two 62 KB chunk buffers; the band form
+// of the table for crops wider than 1024: 16 outputs x at most 15 tiles x 128 B + padding) serve the general cropped kernel only -
+// uncropped M-class frames take the per-wave form.  The K-split kernel keeps its table in registers: two 75 KB buffers.
+// + 128: the operand reads' overrun past the last row.
 constexpr int kStreamBufS = 30 * 1024 + 128, kStreamTabS = 8;
 constexpr int kStreamBufM = 62 * 1024 + 128, kStreamTabM = 16;
 constexpr int kKsplitBuf = 75 * 1024 + 128;
@@ -42,24 +43,20 @@ static_assert(8 * kWaveStreamBuf8 + kWaveStreamTabSmall + 2 * 7 * 1024 <= kLdsPe
 uint32_t stream_pitch(uint32_t w);
 // 16-row blocks per chunk (at most 4) that fit a buffer at that pitch; 0 = not even one
 uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes);
-// which instantiation serves a width: 0 none, 1 = S, 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
+// buffer class of a width: 0 none, 1 = S (the chunk kernel), 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
 int stream_class(uint32_t w, uint32_t *nb);
-bool resize_stream_wants_band(uint32_t w);
-// band-class widths whose chunk would hold at most two 16-row blocks and whose (re-pitched) block fits a per-wave buffer:
-// resize_mfma_frame_wavestream_kernel takes them (1328 .. 1920 columns)
-bool resize_wavestream_applies(uint32_t w);  // the kernel then takes a.bh in kMfmaLayoutHorizontalBand form
-// ... and with how many waves per workgroup (4, 5, 6 or 8; 0 = the width does not take the per-wave form).  VDF_WAVESTREAM_NW=n forces
-// n waves on every width whose block fits the n-wave buffer (measurements).
+bool resize_stream_wants_band(uint32_t w);  // the width's kernel takes a.bh in kMfmaLayoutHorizontalBand form (= the per-wave form)
+// One block stream per wave (resize_mfma_frame_wavestream_kernel): every M-class width whose (re-pitched, whole-KB) block fits a wave's
+// buffer - 512 .. 1920 columns - with as many waves per workgroup as buffers fit (8 / 6 / 5 / 4; 0 = the width does not take this form).
+// VDF_WAVESTREAM_NW=n forces n waves where the block fits the n-wave buffer, VDF_NO_WAVESTREAM=1 switches the form off (measurements).
 int resize_wavestream_waves(uint32_t w);
+bool resize_wavestream_applies(uint32_t w);
 // Clips whose crop boxes are full-width (top / bottom bars only): do the ROWCROP instantiations of the stream kernels beat the general
 // cropped kernels at this frame width?  (measured; the frame must also pass resize_stream_eligible / resize_ksplit_eligible)
 bool resize_rowcrop_streams(uint32_t w);
-// Frames starting on 16-byte boundaries, rows packed inside a frame (frames and clips may be padded).  Widths that are a
-// multiple of the 128-byte line gain only while a chunk keeps enough bytes in flight (measured against the whole-line
-// kernel: 640 / 768 wide + 12 %, 1280 + 5 %, 1920 + 10 % with 56-60 KB chunks; 1536 wide - 2 % with 48 KB chunks);
-// aligned_too = take them all (VDF_RESIZE_MODE=5, for measurements).
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
-                            bool aligned_too);
+// Does a call take a linear-stream kernel (chunk or per-wave form)?  Frames starting on 16-byte boundaries and ending on one, rows packed
+// inside a frame (frames and clips may be padded), 64 .. 1920 columns.
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride);
 
 // K-split form (1024..4096 columns, a multiple of 16): LDS pitch (an odd multiple of 16) and blocks per chunk (0: does not fit)
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp);
