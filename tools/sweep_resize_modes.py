@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One sweep over the frame-size classes of the VideoHash path: every VDF_RESIZE_MODE on every size, TB/s of frame bytes
 (tools/bench_hash.py's figure).  Feeds the size-class table of DESIGN.md 4.1 and the pruning of resize_dispatch.cpp.
-Usage (on the GPU box): python tools/sweep_resize_modes.py [--modes 0,2,4,5,6] > gpurun_out/.../resize_sweep.txt"""
+Usage (on the GPU box): python tools/sweep_resize_modes.py [--modes 0,4,6] > gpurun_out/.../resize_sweep.txt"""
 import argparse
 import os
 import sys
@@ -13,10 +13,10 @@ import vid_dup_finder_lib_amd as vdf
 
 SIZES = [(16, 16), (32, 32), (48, 32), (64, 64), (60, 44), (96, 96), (128, 128), (100, 300), (160, 200), (176, 144), (240, 426),
          (320, 240), (426, 240), (480, 270), (500, 300), (640, 360), (640, 480), (720, 480), (720, 576), (768, 432), (854, 480),
-         (960, 540), (1024, 576), (1280, 720), (1366, 768), (1440, 1080), (1536, 864), (1920, 1080), (2048, 1152), (2560, 1440),
-         (3840, 2160), (4200, 2200)]
+         (960, 540), (1024, 576), (1152, 648), (1280, 720), (1366, 768), (1440, 1080), (1536, 864), (1600, 900), (1680, 1050), (1792, 1008),
+         (1920, 1080), (2000, 1125), (2048, 1152), (2560, 1440), (3840, 2160), (4200, 2200)]
 ap = argparse.ArgumentParser()
-ap.add_argument("--modes", default="0,2,4,5,6")
+ap.add_argument("--modes", default="0,4,6")
 ap.add_argument("--mb", type=int, default=1500, help="frame bytes per launch")
 ap.add_argument("--steps", type=int, default=5)
 args = ap.parse_args()

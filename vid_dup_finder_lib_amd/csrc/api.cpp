@@ -523,10 +523,9 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             if (rc) return rc;
             if (!mh->host.ok) { streamed = false; mh = nullptr; }
         }
-        // wide frames the stream kernel leaves out (1024 / 1536 wide, wider than 1984): its K-split form, table in registers
-        // (measured against the whole-line kernel: 3840 wide 5.4 -> 6.3 TB/s, 2560 5.3 -> 5.8, 2048 5.9 -> 6.1; 1024 and 1536
-        // wide lose - four or three blocks per chunk, each with its own reduction barrier - and stay where they are)
-        const bool ksplit = !fused && ((ctx->resize_mode == 0 && !streamed && w >= 2048) || ctx->resize_mode == 6) &&
+        // frames wider than the per-wave buffers (1920 columns): the K-split form, table in registers (measured against the
+        // whole-line kernel: 3840 wide 5.6 -> 6.7 TB/s, 2560 5.5 -> 6.2, 2000 3.6 -> 5.8, 2048 level)
+        const bool ksplit = !fused && ((ctx->resize_mode == 0 && !streamed && w > 1920) || ctx->resize_mode == 6) &&
                             vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         if (ksplit) { streamed = false; mh = nullptr; }
         const bool wide = !fused && !streamed && !ksplit;
@@ -630,7 +629,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         for (size_t c = 0; c < n_clips && rows_only; c++) rows_only = crops[4 * c] == 0 && crops[4 * c + 1] == 0;
         bool streamed = rows_only && vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
         const bool band = streamed && vdf::resize_stream_wants_band(w);
-        const bool ksplit = rows_only && !streamed && w >= 2048 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
+        const bool ksplit = rows_only && !streamed && w > 1920 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         int rc = VDF_OK;
         DeviceMfmaTable *mh = nullptr;
         if (streamed || ksplit) mh = mfma_table(ctx, w, band ? vdf::kMfmaLayoutHorizontalBand : vdf::kMfmaLayoutHorizontal, stream, &rc);
