@@ -687,9 +687,15 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     // Default for pitches that are not a multiple of the 128-byte line (measured, detect + crop + hash of letterboxed clips,
     // whole-line kernel -> this: 854x480 1.68 -> 1.24 ms per 1000 clips, 720x576 1.42 -> 1.14, 426x240 x4000 1.85 -> 1.33,
     // 960x540 1.63 -> 1.51, 1366x768 x500 2.19 -> 1.95); line-aligned pitches stay on the whole-line kernel (1920x1080
-    // 5.44 against 5.84 ms, 1280x720 2.54 against 2.74); VDF_RESIZE_MODE=5 takes them too.
+    // 5.44 against 5.84 ms, 1280x720 2.54 against 2.74) - for boxes with top / bottom bars only, which is all that measurement had.
+    // Boxes with SIDE bars (pillarboxed clips) take the stream form at line-aligned pitches too: the whole-line kernel reads every
+    // line the box touches and pays for the bars' columns (1000 clips of 1920x1080 with 240-column bars, crop + hash: 7.7 -> 5.5 ms,
+    // 1280x720 x2000 6.4 -> 3.9, 1536x864 4.5 -> 2.9, 640x360 x4000 3.4 -> 2.5; 1024 wide 3.5 -> 3.8: stays; gpurun_out/r03pb).
+    // VDF_RESIZE_MODE=5 takes every pitch.
+    bool side_bars = false;
+    for (size_t c = 0; c < n_clips && !side_bars; c++) side_bars = crops[4 * c] != 0 || crops[4 * c + 1] != 0;
     int stream_cls = 0;
-    if (((ctx->resize_mode == 0 && w % 128 != 0) || ctx->resize_mode == 5) && (h + 63) / 64 > 2 &&
+    if (((ctx->resize_mode == 0 && (w % 128 != 0 || (side_bars && w != 1024))) || ctx->resize_mode == 5) && (h + 63) / 64 > 2 &&
         (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 && (uint64_t)w * h < (1ull << 31) && ((uint64_t)w * h) % 16 == 0 &&
         vdf::resize_cropped_stream_class(w, &stream_cls)) {
         std::vector<vdf::CropStreamClip> sc(n_clips);

@@ -122,11 +122,104 @@ __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p
     return (double)count / (double)len > 0.9;
 }
 
+// NC (8 or 16) adjacent column strips at once (pillarboxed clips: 4 : 3 content in a 16 : 9 frame walks 240 columns in from each side of
+// a 1080p frame).  One column strip is H single bytes, each in its own cache line: strip by strip the walk fetched every line of the
+// frame's side NC times over and was bound by the address coalescer (18 ms to probe 1000 pillarboxed 1080p clips).  Here a lane reads
+// the NC bytes of its row that hold columns x0 .. x0 + NC - 1 and the wave keeps NC histograms (u16 counters, two columns per LDS word:
+// H < 65536); the strips are then judged in walking order - exactly the reference's take_while, evaluated speculatively.
+// from_right: strip k of the batch is column x0 + NC - 1 - k.  Returns how many leading strips of the batch are letterbox (0 .. NC).
+// histn: NC / 2 x 256 words of this wave.  All 64 lanes must call.
+template <int NC>
+__device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f, uint32_t W, uint32_t H, uint32_t x0, bool from_right,
+                                                  uint32_t tol, uint32_t *histn)
+{
+    constexpr uint32_t HALF = NC / 2, ND = NC / 4;  // columns per counter half, dwords per row
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t k = 0; k < HALF * 4; k++) histn[lane + 64 * k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    struct __attribute__((packed, aligned(1))) UN { uint32_t d[ND]; };
+    auto byte_of = [](const UN &v, uint32_t c) {  // (64-bit shifts, not an indexed load: a lane-dependent index would put v in scratch)
+        const uint64_t lo = (uint64_t)v.d[0] | ((uint64_t)v.d[1] << 32);
+        uint64_t w = lo;
+        if constexpr (NC == 16) {
+            const uint64_t hi = (uint64_t)v.d[2] | ((uint64_t)v.d[3] << 32);
+            w = c < 8 ? lo : hi;
+        }
+        return (uint32_t)(w >> (8 * (c & 7))) & 255u;
+    };
+    auto slot = [&](uint32_t c, uint32_t value) { return &histn[(c % HALF) * 256u + value]; };
+    for (uint32_t i0 = 0; i0 < H; i0 += 256) {  // four rows per lane in flight
+        UN v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t row = i0 + 64u * k + lane;
+            if (row < H) v[k] = *reinterpret_cast<const UN *>(f + (size_t)row * W + x0);
+            else
+#pragma unroll
+                for (uint32_t j = 0; j < ND; j++) v[k].d[j] = 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool active = i0 + 64u * k + lane < H;
+            const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+            if (act == 0) break;  // wave-uniform
+            UN first;
+            bool same = true;
+#pragma unroll
+            for (uint32_t j = 0; j < ND; j++) {
+                first.d[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k].d[j]);
+                same = same && v[k].d[j] == first.d[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(active && same) == act) {
+                // every active row holds the same NC bytes (bars): lane c adds the row count to column c's bin
+                if (lane < (uint32_t)NC) atomicAdd(slot(lane, byte_of(first, lane)), (uint32_t)__builtin_popcountll(act) << (16 * (lane / HALF)));
+            } else if (active) {
+#pragma unroll 4
+                for (uint32_t c = 0; c < (uint32_t)NC; c++) atomicAdd(slot(c, byte_of(v[k], c)), 1u << (16 * (c / HALF)));
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane = NC q + c: share q of column c's histogram (256 / (64 / NC) bins)
+    constexpr uint32_t SHARES = 64 / NC, BINS = 256 / SHARES;
+    const uint32_t c = lane % NC, q = lane / NC, sh = 16 * (c / HALF);
+    const uint32_t *hc = histn + (c % HALF) * 256u + BINS * q;
+    uint32_t key = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < BINS; b++) key = max(key, (((hc[b] >> sh) & 0xFFFFu) << 8) | (BINS * q + b));  // max count, ties -> the larger value
+#pragma unroll
+    for (uint32_t o = NC; o < 64; o <<= 1) key = max(key, (uint32_t)__shfl_xor((int)key, (int)o, 64));
+    const uint32_t mode = key & 255u, lo = mode > tol ? mode - tol : 0u, hi = min(mode + tol, 255u);
+    uint32_t count = 0;
+#pragma unroll 8
+    for (uint32_t b = 0; b < BINS; b++) {
+        const uint32_t val = BINS * q + b;
+        if (val >= lo && val <= hi) count += (hc[b] >> sh) & 0xFFFFu;
+    }
+#pragma unroll
+    for (uint32_t o = NC; o < 64; o <<= 1) count += (uint32_t)__shfl_xor((int)count, (int)o, 64);
+    const bool pass = (double)count / (double)H > 0.9;
+    constexpr uint32_t ALL = (1u << NC) - 1u;
+    uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(pass && lane < (uint32_t)NC) & ALL;  // bit c = column x0 + c is letterbox
+    __builtin_amdgcn_wave_barrier();
+    if (from_right) ok = __builtin_bitreverse32(ok) >> (32 - NC);  // bit k = strip k
+    return ok == ALL ? (uint32_t)NC : (uint32_t)__builtin_ctz(~ok);
+}
+
+#ifndef VDF_LETTERBOX_NC
+#define VDF_LETTERBOX_NC 8
+#endif
+constexpr int kColumnBatch = VDF_LETTERBOX_NC;
+
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
                                                         size_t frame_stride, size_t clip_stride, uint32_t n_probe,
                                                         uint32_t tol, uint32_t *__restrict__ crops)
 {
     __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256];  // the column walkers' batches of strips
     __shared__ uint32_t s_edge[4];
     const size_t clip = blockIdx.x / n_probe;
     const uint32_t probe = blockIdx.x % n_probe;  // frame 8 * probe
@@ -134,10 +227,20 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restric
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t *hist = s_hist[wave];
     uint32_t n = 0;
-    if (wave == 0) {
-        while (n < W && strip_is_letterbox(f + n, W, H, tol, hist)) n++;
-    } else if (wave == 1) {
-        while (n < W && strip_is_letterbox(f + (W - n - 1), W, H, tol, hist)) n++;
+    if (wave < 2) {
+        // the first strip alone (most clips have no side bars and stop here), then a batch at a time while a whole batch is inside the frame
+        const bool right = wave == 1;
+        if (strip_is_letterbox(right ? f + (W - 1) : f, W, H, tol, hist)) {
+            n = 1;
+            bool walking = true;
+            while (walking && n + kColumnBatch <= W && H < 65536u) {
+                const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
+                n += got;
+                walking = got == (uint32_t)kColumnBatch;
+            }
+            if (walking)
+                while (n < W && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) n++;
+        }
     } else if (wave == 2) {
         while (n < H && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) n++;
     } else {
