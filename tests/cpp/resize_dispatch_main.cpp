@@ -40,9 +40,9 @@ int main()
         for (uint32_t h : {129u, 270u, 1080u, 1088u}) {
             const size_t fs = (size_t)w * h;
             const bool e = resize_stream_eligible(aligned, w, h, (fs + 15) & ~size_t(15), 16 * ((fs + 15) & ~size_t(15)));
-            if (e) CHECK(cls != 0 && w >= 64, "eligible implies a class w=%u", w);
+            if (e) CHECK((cls == 1 || resize_wavestream_applies(w)) && w >= 64, "eligible implies a kernel w=%u", w);
             if ((cls == 1 || resize_wavestream_applies(w)) && w >= 64 && ((uint64_t)w * h) % 16 == 0) CHECK(e, "every width of the chunk or per-wave form streams w=%u", w);
-            if (cls >= 2 && !resize_wavestream_applies(w)) CHECK(!e, "M-class widths beyond the per-wave buffers (pitch > 1920) take the whole-line kernel w=%u", w);
+            if (cls != 1 && !resize_wavestream_applies(w)) CHECK(!e, "widths beyond the per-wave buffers (pitch > 2368) do not stream w=%u", w);
             if (((uint64_t)w * h) % 16 != 0) CHECK(!e, "frames that do not end on a 16-byte boundary must not stream w=%u h=%u", w, h);
             CHECK(!resize_stream_eligible(aligned + 4, w, h, fs, 16 * fs), "misaligned base must not stream w=%u", w);
         }
@@ -84,7 +84,7 @@ int main()
     }
     for (uint32_t w : {480u, 854u, 640u, 768u, 1024u, 1280u, 1920u, 720u, 1440u, 240u, 160u, 128u, 1536u, 1792u})  // 1536 / 1792: per-wave block streams (round 3)
         CHECK(resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "%u wide should stream by default", w);
-    for (uint32_t w : {2048u, 3840u, 48u, 63u})
+    for (uint32_t w : {2048u, 2560u, 3840u, 48u, 63u})
         CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "%u wide should not stream by default", w);
     // the per-wave block streams: every M-class width (from 462 columns) whose pitch is at most 1920, with as many waves as block buffers fit; the (whole-KB) block
     // fits the wave's buffer, the workgroup fits the CU's LDS, and the width's band table fits the table array of that wave count
@@ -94,22 +94,24 @@ int main()
         const int nw = resize_wavestream_waves(w);
         CHECK(resize_wavestream_applies(w) == (nw != 0), "applies <-> waves w=%u", w);
         if (nw) {
-            CHECK(cls >= 2 && w >= 256 && stream_pitch(w) <= 1920, "wave-stream width w=%u cls=%d nb=%u", w, cls, nb);
-            CHECK(nw == 4 || nw == 5 || nw == 6 || nw == 8, "wave count w=%u nw=%d", w, nw);
-            const int buf = nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : kWaveStreamBuf8;
-            const int tab = nw == 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall;
+            CHECK(cls != 1 && w >= 256 && stream_pitch(w) <= 2368, "wave-stream width w=%u cls=%d nb=%u", w, cls, nb);
+            CHECK(nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8, "wave count w=%u nw=%d", w, nw);
+            CHECK((nw == 3) == (stream_pitch(w) > 1920) && (nw != 3 || w % 16 != 0), "three waves beyond the four-wave buffers, widths the K-split form cannot take w=%u nw=%d", w, nw);
+            const int buf = nw == 3 ? kWaveStreamBuf3 : nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : kWaveStreamBuf8;
+            const int tab = nw <= 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall;
             CHECK(((16 * stream_pitch(w) + 1023) & ~1023u) + 128 <= (uint32_t)buf, "wave-stream block fits w=%u nw=%d", w, nw);
             CHECK(nw * buf + tab + 2 * (nw - 1) * 1024 <= kLdsPerCu, "wave-stream workgroup fits the LDS w=%u nw=%d", w, nw);
             MfmaAxisTable t;
             build_mfma_axis_table(w, kMfmaLayoutHorizontalBand, t);
             CHECK(t.ok && 16 * t.band_stride + 128 <= tab, "band table fits w=%u nw=%d: %d bytes of %d", w, nw, 16 * t.band_stride + 128, tab);
-        } else if (w >= 256 && stream_pitch(w) <= 1920) {
-            CHECK(cls < 2, "every M-class width with a pitch up to 1920 takes the per-wave streams w=%u cls=%d", w, cls);
+        } else if (w >= 256 && stream_pitch(w) <= 2368) {
+            CHECK(cls == 1 || (w % 16 == 0 && w > 1920), "every width beyond the S class with a pitch up to 2368 takes the per-wave streams or the K-split form w=%u cls=%d", w, cls);
         }
     }
     for (uint32_t w : {528u, 640u, 854u, 1024u, 1280u, 1360u, 1366u, 1440u, 1536u, 1600u, 1680u, 1792u, 1904u, 1920u}) CHECK(resize_wavestream_applies(w), "%u wide takes the per-wave streams", w);
-    for (uint32_t w : {480u, 320u, 1910u, 1921u, 1936u, 1984u, 2048u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
-    CHECK(resize_wavestream_waves(640) == 8 && resize_wavestream_waves(1152) == 6 && resize_wavestream_waves(1366) == 5 && resize_wavestream_waves(1920) == 4, "documented wave counts");
+    for (uint32_t w : {480u, 320u, 1936u, 2048u, 2353u, 2560u, 3840u}) CHECK(!resize_wavestream_applies(w), "%u wide must not take the per-wave streams", w);
+    CHECK(resize_wavestream_waves(640) == 8 && resize_wavestream_waves(1152) == 6 && resize_wavestream_waves(1366) == 5 && resize_wavestream_waves(1920) == 4 &&
+          resize_wavestream_waves(1950) == 3 && resize_wavestream_waves(2340) == 3 && resize_wavestream_waves(2000) == 0 && resize_wavestream_waves(1915) == 3, "documented wave counts");
     // full-width crop boxes: the ROWCROP stream kernels everywhere but 2048 columns (measured)
     for (uint32_t w : {64u, 426u, 640u, 768u, 854u, 1024u, 1280u, 1366u, 1536u, 1600u, 1792u, 1920u, 2560u, 3840u, 4096u}) CHECK(resize_rowcrop_streams(w), "%u wide: row-cropped stream kernels", w);
     CHECK(!resize_rowcrop_streams(2048), "2048 wide: general cropped kernels");

@@ -262,7 +262,7 @@ _SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
     ("wave-stream 1280 (re-pitched), 6 waves", 360, 1280, 24, False), ("wave-stream 1152, 6 waves", 324, 1152, 32, False),
     ("wave-stream 1001 (shifted), 6 waves", 208, 1001, 32, False), ("wave-stream 640, 8 waves", 360, 640, 40, False),
     ("wave-stream 854 (shifted), 8 waves", 480, 854, 24, False), ("wave-stream 768 (re-pitched), 8 waves", 432, 768, 32, False),
-    ("whole-line 1984", 200, 1984, 24, False),
+    ("wave-stream 1950 (shifted), 3 waves", 200, 1950, 24, False), ("whole-line 2400 (odd stride)", 131, 2401, 12, False),
     ("whole-line 2000", 200, 2000, 20, False), ("persistent 64", 64, 64, 600, False), ("fused 128", 128, 128, 200, False),
     ("cropped stream 854", 480, 854, 24, True), ("cropped stream 480", 270, 480, 40, True), ("cropped whole-line 1280", 360, 1280, 16, True),
     # top / bottom bars only: the ROWCROP instantiations of the stream kernels (per-clip first row, height, vertical table)

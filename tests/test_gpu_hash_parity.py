@@ -127,7 +127,8 @@ def test_every_resize_kernel_matches_oracle(mode, h, w, monkeypatch):
                                    (360, 640, 3), (432, 768, 2), (720, 1280, 1), (1080, 1920, 1), (300, 1984, 1), (300, 2000, 1),
                                    (426, 240, 40), (144, 176, 40), (200, 160, 3), (256, 192, 3), (256, 128, 3), (300, 200, 3), (333, 64, 3), (200, 80, 3),
                                    (900, 1600, 1), (576, 1024, 1), (136, 1440, 40), (150, 1920, 36), (1080, 1904, 1), (140, 1366, 40), (200, 1536, 24), (130, 1792, 24), (300, 1916, 2),
-                                   (144, 1300, 36), (768, 1534, 1), (130, 640, 60), (150, 854, 60), (144, 1152, 40), (129, 768, 45), (140, 1024, 40)])
+                                   (144, 1300, 36), (768, 1534, 1), (130, 640, 60), (150, 854, 60), (144, 1152, 40), (129, 768, 45), (140, 1024, 40),
+                                   (144, 1950, 36), (300, 2340, 2), (200, 2001, 24), (1096, 1950, 1)])
 def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     """Tightly packed frames whose every frame starts and ends on a 16-byte boundary go through the linear-stream kernels (LDS-DMA of
     whole chunks / blocks, operands read back from LDS).  Up to 512 wide = the chunk form, two workgroups per CU with 64-row chunks
@@ -138,8 +139,8 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
     600 / 854 / 1366 / 1534 = re-pitched rows (854, 1366, 1534: shifted), 768 / 1024 / 1280 / 1536 / 1792 = multiples of 256 bytes,
     re-pitched to dodge the 16-way bank conflict; 45 / 40 / 36 clips = more frames than resident workgroups, so the persistent loops
     cross frame boundaries (the parity-doubled partial sums) with 9 or 10 blocks per frame (uneven shares of the waves, waves
-    without a block, a partial last block); 270 / 129 / 333 / 191 rows = partial last chunks and blocks.  1984 / 2000 / 1916 wide =
-    beyond the per-wave buffers: the whole-line kernel."""
+    without a block, a partial last block); 270 / 129 / 333 / 191 rows = partial last chunks and blocks.  1916 / 1950 / 2001 / 2340 wide
+    (not multiples of 16, pitches up to 2368) = three waves with 37 KB blocks; 1984 / 2000 = the K-split form."""
     import vid_dup_finder_lib_amd as vdf
 
     monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))

@@ -1231,13 +1231,14 @@ static hipError_t launch_wavestream(const uint8_t *frames, size_t n_clips, uint3
     const int nw = resize_wavestream_waves(w);
     if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || nw == 0) return hipErrorInvalidValue;
     const int tab_bytes = 16 * a.band_stride + 128;  // + the zero slot
-    if (tab_bytes > (nw == 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall)) return hipErrorInvalidValue;
+    if (tab_bytes > (nw <= 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall)) return hipErrorInvalidValue;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
     const MfmaResizeTables T = make_tables(a);
-    if (nw == 4) launch_wavestream_nw<4, kWaveStreamBuf, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    if (nw == 3) launch_wavestream_nw<3, kWaveStreamBuf3, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    else if (nw == 4) launch_wavestream_nw<4, kWaveStreamBuf, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
     else if (nw == 5) launch_wavestream_nw<5, kWaveStreamBuf5, kWaveStreamTabMid>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
     else if (nw == 6) launch_wavestream_nw<6, kWaveStreamBuf6, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
     else launch_wavestream_nw<8, kWaveStreamBuf8, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
@@ -1252,7 +1253,7 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     if (n_clips == 0) return hipSuccess;
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
-    if (n_clips * 16 > 0xFFFFFFFFull || cls == 0) return hipErrorInvalidValue;
+    if (n_clips * 16 > 0xFFFFFFFFull) return hipErrorInvalidValue;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

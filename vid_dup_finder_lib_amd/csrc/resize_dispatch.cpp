@@ -36,7 +36,7 @@ int stream_class(uint32_t w, uint32_t *nb)
 static bool wavestream_fits(uint32_t w, int nw)
 {
     const uint32_t need = ((16u * stream_pitch(w) + 1023u) & ~1023u) + 128u;  // a DMA instruction fills whole KBs
-    const int buf = nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : nw == 8 ? kWaveStreamBuf8 : 0;
+    const int buf = nw == 3 ? kWaveStreamBuf3 : nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : nw == 8 ? kWaveStreamBuf8 : 0;
     return need <= (uint32_t)buf && w >= 256;
 }
 
@@ -53,9 +53,13 @@ int resize_wavestream_waves(uint32_t w)
     // (gpurun_out/r03_nw_sweep2.txt) 576 wide 5.9 -> 6.8 TB/s, 640 6.4 -> 6.8, 1152 5.3 -> 6.8, 1200 6.1 -> 6.7, 1366 5.4 -> 6.3,
     // 1440 5.6 -> 6.3, 1520 6.0 -> 6.8; level at 896 / 960.  (With FOUR waves the three-block widths had measured slower: 1280 x 720
     // 6.6 -> 5.8 - the point is the bytes in flight per CU, not the absence of the barrier.)
-    if (cls < 2) return 0;
+    if (cls == 1) return 0;
     for (int nw : {8, 6, 5, 4})
-        if (wavestream_fits(w, nw)) return nw;
+        if (cls >= 2 && wavestream_fits(w, nw)) return nw;
+    // Wider than the four-wave buffers: three waves with 37 KB blocks (pitches up to 2368) - for the widths the K-split kernel cannot take
+    // (not a multiple of 16: 1950 x 1096 3.2 -> 5.2 TB/s against the whole-line kernel).  Multiples of 16 stay with the K-split form,
+    // which measured 2-4 % ahead of three waves (2048 wide 5.79 against 5.53, 2304 5.88 against 5.63; gpurun_out/r03nw3).
+    if (w % 16 != 0 && wavestream_fits(w, 3)) return 3;
     return 0;
 }
 

@@ -22,6 +22,7 @@ constexpr int kWaveStreamTabBytes = 16 * (kMfmaBandMaxTiles * 128 + 32) + 128;  
 // narrower frames: more waves, each with its own (smaller) block buffer, so that the blocks in flight per CU stay near 120 KB.
 // A block's DMA instructions fill whole KBs: the buffers are the block rounded up to 1 KB (+ the operand reads' overrun).
 constexpr int kWaveStreamBuf5 = 25 * 1024 + 128, kWaveStreamBuf6 = 21 * 1024 + 128, kWaveStreamBuf8 = 15 * 1024 + 128;  // pitches up to 1600, 1344, 960
+constexpr int kWaveStreamBuf3 = 37 * 1024 + 128;  // ... and wider frames (pitches up to 2368: 2048 x 1152, 2160 x 3840 portrait) with three waves
 constexpr int kWaveStreamTabMid = 16 * (12 * 128 + 32) + 128;    // band tables of at most 12 tiles per output (five waves: frames up to 1600 columns)
 constexpr int kWaveStreamTabSmall = 16 * (10 * 128 + 32) + 128;  // at most 10 (six and eight waves: up to 1344 columns)
 constexpr int kStreamPartBytes = 3 * 64 * 4 * 4;  // s_part: the vertical partial sums of waves 1..3
@@ -31,6 +32,7 @@ static_assert(2 * (2 * kStreamBufS + kStreamTabS * 2048 + kStreamPartBytes) <= k
 static_assert(2 * kStreamBufM + kStreamTabM * 2048 + kStreamPartBytes <= kLdsPerCu, "one M workgroup per CU");
 static_assert(2 * kKsplitBuf + 2 * 3 * 64 * 16 + kStreamPartBytes <= kLdsPerCu, "one K-split workgroup per CU");
 static_assert(4 * kWaveStreamBuf + kWaveStreamTabBytes + 2 * kStreamPartBytes <= kLdsPerCu, "one per-wave-stream workgroup per CU");
+static_assert(3 * kWaveStreamBuf3 + kWaveStreamTabBytes + 2 * 2 * 1024 <= kLdsPerCu, "three waves");
 static_assert(5 * kWaveStreamBuf5 + kWaveStreamTabMid + 2 * 4 * 1024 <= kLdsPerCu, "five waves");
 static_assert(6 * kWaveStreamBuf6 + kWaveStreamTabSmall + 2 * 5 * 1024 <= kLdsPerCu, "six waves");
 static_assert(8 * kWaveStreamBuf8 + kWaveStreamTabSmall + 2 * 7 * 1024 <= kLdsPerCu, "eight waves");
@@ -47,7 +49,7 @@ uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes);
 int stream_class(uint32_t w, uint32_t *nb);
 bool resize_stream_wants_band(uint32_t w);  // the width's kernel takes a.bh in kMfmaLayoutHorizontalBand form (= the per-wave form)
 // One block stream per wave (resize_mfma_frame_wavestream_kernel): every M-class width whose (re-pitched, whole-KB) block fits a wave's
-// buffer - 512 .. 1920 columns - with as many waves per workgroup as buffers fit (8 / 6 / 5 / 4; 0 = the width does not take this form).
+// buffer - 512 .. 2368 columns - with as many waves per workgroup as buffers fit (8 / 6 / 5 / 4 / 3; 0 = the width does not take this form).
 // VDF_WAVESTREAM_NW=n forces n waves where the block fits the n-wave buffer, VDF_NO_WAVESTREAM=1 switches the form off (measurements).
 int resize_wavestream_waves(uint32_t w);
 bool resize_wavestream_applies(uint32_t w);
