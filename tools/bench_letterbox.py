@@ -11,6 +11,7 @@ ap.add_argument("--w", type=int, default=64)
 ap.add_argument("--h", type=int, default=64)
 ap.add_argument("--bars", type=float, default=0.12, help="letterbox bar height as a fraction of H (0 = none)")
 ap.add_argument("--side", type=float, default=0.0, help="pillarbox bar width as a fraction of W (0 = none)")
+ap.add_argument("--black", type=float, default=0.0, help="fraction of clips whose frame 0 is uniformly black (a fade-in: every strip of every edge is letterbox)")
 ap.add_argument("--steps", type=int, default=3)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -26,6 +27,8 @@ side = int(a.w * a.side)
 if side:
     frames[:, :, :, :side] = 16
     frames[:, :, :, a.w - side:] = 16
+if a.black > 0:
+    frames[:: max(1, int(round(1 / a.black))), 0] = 16
 out = torch.zeros((a.clips, 16), dtype=torch.int64, device=dev)
 crops_d = torch.zeros((a.clips, 4), dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
@@ -37,5 +40,5 @@ for name, fn in (("detect only", lambda: eng.cropdetect_letterbox_device(frames.
     for _ in range(a.steps): r = fn()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
-    print(f"{name}: {a.clips} clips 16x{a.h}x{a.w} bars={bar} side={side}: {ms:.3f} ms, {a.clips*16/ms*1e3:.4g} frames/s, {a.clips*16*a.w*a.h/ms/1e6:.1f} GB/s of frames")
+    print(f"{name}: {a.clips} clips 16x{a.h}x{a.w} bars={bar} side={side} black={a.black}: {ms:.3f} ms, {a.clips*16/ms*1e3:.4g} frames/s, {a.clips*16*a.w*a.h/ms/1e6:.1f} GB/s of frames")
 print("crop[0] =", r[0] if r is not None else None)

@@ -221,30 +221,48 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restric
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256];  // the column walkers' batches of strips
     __shared__ uint32_t s_edge[4];
+    __shared__ uint32_t s_prog[4];  // strips each walker has confirmed so far
     const size_t clip = blockIdx.x / n_probe;
     const uint32_t probe = blockIdx.x % n_probe;  // frame 8 * probe
     const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * probe) * frame_stride;
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t *hist = s_hist[wave];
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
+    __syncthreads();
+    // A frame whose opposite walkers meet (a fade-in: uniformly black, every strip of every edge is letterbox) means "no crop" whatever the
+    // other edges find (video_frames_gray.rs:119-127), and each walker alone would go through the whole frame first - 1.5 ms for ONE
+    // such 1080p frame in a batch whose other thousand clips take 0.1 ms.  The walkers publish their progress; once left + right
+    // reach W or top + bottom reach H the result is fixed and everybody stops.  (The counts only grow, so a partial sum that
+    // reaches the extent implies the final one does.)
+    auto publish = [&](uint32_t n) {
+        if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
+    };
+    auto converged = [&]() {
+        const uint32_t l = __atomic_load_n(&s_prog[0], __ATOMIC_RELAXED), r = __atomic_load_n(&s_prog[1], __ATOMIC_RELAXED);
+        const uint32_t t = __atomic_load_n(&s_prog[2], __ATOMIC_RELAXED), b = __atomic_load_n(&s_prog[3], __ATOMIC_RELAXED);
+        return __builtin_amdgcn_readfirstlane((int)((uint64_t)l + r >= W || (uint64_t)t + b >= H)) != 0;
+    };
     uint32_t n = 0;
     if (wave < 2) {
         // the first strip alone (most clips have no side bars and stop here), then a batch at a time while a whole batch is inside the frame
         const bool right = wave == 1;
         if (strip_is_letterbox(right ? f + (W - 1) : f, W, H, tol, hist)) {
             n = 1;
+            publish(n);
             bool walking = true;
-            while (walking && n + kColumnBatch <= W && H < 65536u) {
+            while (walking && n + kColumnBatch <= W && H < 65536u && !converged()) {
                 const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
                 n += got;
+                publish(n);
                 walking = got == (uint32_t)kColumnBatch;
             }
             if (walking)
-                while (n < W && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) n++;
+                while (n < W && !converged() && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) publish(++n);
         }
     } else if (wave == 2) {
-        while (n < H && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) n++;
+        while (n < H && !converged() && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) publish(++n);
     } else {
-        while (n < H && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) n++;
+        while (n < H && !converged() && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) publish(++n);
     }
     if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
     __syncthreads();
