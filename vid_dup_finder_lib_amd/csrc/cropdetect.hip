@@ -12,18 +12,37 @@
 
 namespace vdf {
 
+// Wave-wide reductions for all 64 lanes active (the walkers' code is wave-uniform).  DPP rotations inside each row of 16 lanes, then the
+// four row results through readlane: ~10 instructions.  The __shfl_xor butterflies this replaces were twelve LDS round trips per strip
+// (ds_bpermute) - most of a strip's wall time once its loads were batched.
+template <int ROR> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + ROR, 0xF, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return v;
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
+    v = max(v, row_ror<8>(v));
+    v = max(v, row_ror<4>(v));
+    v = max(v, row_ror<2>(v));
+    v = max(v, row_ror<1>(v));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
+
+// The reference's test is  count as f64 / len as f64 > 0.9  (video_frames_gray.rs:65,96-99).  For integers below 2^32 that is exactly
+// 10 count > 9 len: a quotient other than 9/10 itself is at least 1 / (10 len) > 2^-36 away from 0.9, far more than the 2^-54 by which
+// the double 0.9 and the rounding of the division can move it; and 9/10 exactly divides to the double 0.9, which is not greater than
+// itself.  (The f64 division was a third of a strip's dependent chain.)
+__device__ __forceinline__ bool more_than_nine_tenths(uint32_t count, uint32_t len) { return 10ull * count > 9ull * len; }
 
 // hist: this wave's 256-bin LDS histogram.  All 64 lanes must call.
 __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p, size_t step, uint32_t len,
@@ -119,7 +138,7 @@ __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p
     }
     count = wave_sum_u32(count);
     __builtin_amdgcn_wave_barrier();
-    return (double)count / (double)len > 0.9;
+    return more_than_nine_tenths(count, len);
 }
 
 // NC (8 or 16) adjacent column strips at once (pillarboxed clips: 4 : 3 content in a 16 : 9 frame walks 240 columns in from each side of
@@ -201,7 +220,7 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
     }
 #pragma unroll
     for (uint32_t o = NC; o < 64; o <<= 1) count += (uint32_t)__shfl_xor((int)count, (int)o, 64);
-    const bool pass = (double)count / (double)H > 0.9;
+    const bool pass = more_than_nine_tenths(count, H);
     constexpr uint32_t ALL = (1u << NC) - 1u;
     uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(pass && lane < (uint32_t)NC) & ALL;  // bit c = column x0 + c is letterbox
     __builtin_amdgcn_wave_barrier();
