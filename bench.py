@@ -844,6 +844,50 @@ def main():
             # 4K: the K-split form of the stream kernel (horizontal table in registers)
             big_leg("uhd_3840x2160", 250, 3840, 2160, "resize_mfma_frame_ksplit_kernel", "resize_mfma_frame_ksplit_kernel@3840x2160", 250)
 
+            # SURVEY 8f N3, the builder's default (Cropdetect::Letterbox before from_frames) at the decoder's native size: detect + crop +
+            # hash of 1080p clips with bars, one vdf_hash_frames_u8_letterbox_device call per step (it downloads the boxes in between)
+            def letterbox_leg(n, w, h):
+                res = {"workload": f"{n} clips of 16 x {h} x {w} u8 per GPU, detect + crop + hash in one call "
+                                   "(letterbox_kernel, then the ROWCROP stream kernels for full-width boxes / resize_mfma_cropped_stream_kernel)",
+                       "GB_per_s_counts": "bytes of the crop boxes (what the resize has to read); the probe reads of the detect pass are on top"}
+                base = torch.empty((n, 16, h, w), dtype=torch.uint8, device=dev)
+                chunk = max(1, (1 << 31) // (16 * h * w))
+                for c0 in range(0, n, chunk):
+                    base[c0:c0 + chunk] = torch.randint(0, 256, (min(chunk, n - c0), 16, h, w), dtype=torch.uint8, device=dev, generator=g)
+                oh = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+                bar_t, bar_s = int(h * 0.12), int(w * 0.125)
+                for name in ("no_bars", "top_bottom_bars", "side_bars", "one_black_probe_frame_in_1000"):
+                    fr = base
+                    if name != "no_bars":
+                        fr = base.clone()
+                    if name == "top_bottom_bars":  # 2.39 : 1 in 16 : 9
+                        fr[:, :, :bar_t, :] = 16
+                        fr[:, :, h - bar_t:, :] = 16
+                    elif name == "side_bars":  # 4 : 3 in 16 : 9
+                        fr[:, :, :, :bar_s] = 16
+                        fr[:, :, :, w - bar_s:] = 16
+                    elif name == "one_black_probe_frame_in_1000":  # a fade-in: every strip is letterbox, the edges converge, "no crop"
+                        fr[::1000, 0] = 16
+                    crops = eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
+                    barrier()
+                    ev0.record()
+                    for _ in range(leg_steps):
+                        crops = eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    ms_l = ev0.elapsed_time(ev1) / leg_steps
+                    c0 = [int(x) for x in crops[0]]
+                    kept = (w - c0[0] - c0[1]) * (h - c0[2] - c0[3])
+                    res[name] = {"ms_per_step": ms_l, "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3), "crop_of_clip_0": c0,
+                                 "box_GB_per_s": n * 16 * kept / (ms_l * 1e-3) / 1e9}
+                    if fr is not base:
+                        del fr
+                out["hash"]["letterbox_full_hd"] = res
+                del base, oh
+
+            if args.hash_hd_clips > 0:
+                letterbox_leg(args.hash_hd_clips, 1920, 1080)
+
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)
         if args.hash_clips > 0:

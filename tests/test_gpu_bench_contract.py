@@ -34,6 +34,11 @@ def test_bench_emits_the_contract_line(backend):
     assert d["value"] > 0 and abs(d["value"] - d["config"]["pairs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
     h = d["hash"]
     assert h["unit"] == "frames/s" and h["roofline"]["bound"] == "hbm" and h["cpu_baseline"]["kind"] == "port"
+    lb = h["letterbox_full_hd"]  # detect + crop + hash in one call
+    h_, w_ = 1080, 1920
+    assert lb["no_bars"]["crop_of_clip_0"] == [0, 0, 0, 0] and lb["top_bottom_bars"]["crop_of_clip_0"] == [0, 0, int(h_ * 0.12), int(h_ * 0.12)]
+    assert lb["side_bars"]["crop_of_clip_0"] == [int(w_ * 0.125), int(w_ * 0.125), 0, 0]
+    assert lb["one_black_probe_frame_in_1000"]["crop_of_clip_0"] == [0, 0, 0, 0] and all(lb[k]["ms_per_step"] > 0 for k in lb if isinstance(lb[k], dict))
     assert d["match_groups"] > 0 and d["windowed"]["pairs"] > 0 and d["windowed"]["steps"] == 1
     assert d["windowed"]["waste_ratio"] >= 1.0
     rf = d["refs_c5_shape"]
