@@ -12,6 +12,7 @@ ap.add_argument("--h", type=int, default=64)
 ap.add_argument("--bars", type=float, default=0.12, help="letterbox bar height as a fraction of H (0 = none)")
 ap.add_argument("--side", type=float, default=0.0, help="pillarbox bar width as a fraction of W (0 = none)")
 ap.add_argument("--black", type=float, default=0.0, help="fraction of clips whose frame 0 is uniformly black (a fade-in: every strip of every edge is letterbox)")
+ap.add_argument("--mix", action="store_true", help="a mixed batch: 70 %% of the clips without bars, 20 %% with --bars top / bottom, 10 %% with --side bars")
 ap.add_argument("--steps", type=int, default=3)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -20,13 +21,17 @@ st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 g = torch.Generator(device=dev); g.manual_seed(1)
 frames = torch.randint(0, 256, (a.clips, 16, a.h, a.w), dtype=torch.uint8, device=dev, generator=g)
 bar = int(a.h * a.bars)
-if bar:
-    frames[:, :, :bar, :] = 16
-    frames[:, :, a.h - bar:, :] = 16
 side = int(a.w * a.side)
+tb = slice(None) if not a.mix else slice(7, None, 10)   # clips 7, 17, ...  (and 8, 18, ... below): 20 %
+tb2 = slice(0, 0) if not a.mix else slice(8, None, 10)
+sd = slice(None) if not a.mix else slice(9, None, 10)   # 10 %
+if bar:
+    for sl in (tb, tb2):
+        frames[sl, :, :bar, :] = 16
+        frames[sl, :, a.h - bar:, :] = 16
 if side:
-    frames[:, :, :, :side] = 16
-    frames[:, :, :, a.w - side:] = 16
+    frames[sd, :, :, :side] = 16
+    frames[sd, :, :, a.w - side:] = 16
 if a.black > 0:
     frames[:: max(1, int(round(1 / a.black))), 0] = 16
 out = torch.zeros((a.clips, 16), dtype=torch.int64, device=dev)

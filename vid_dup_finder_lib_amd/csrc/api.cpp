@@ -621,173 +621,225 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         int rc0 = ensure_cos_table(ctx, stream);
         if (rc0) return rc0;
     }
-    // Top / bottom bars only (the commonest letterbox: a 2.39 : 1 film in a 16 : 9 frame): the box is a contiguous range of rows at the
-    // frame's own pitch, so it streams like a shorter frame - the linear-stream kernels the uncropped call would take (per-wave, chunk
-    // or K-split form), as ROWCROP instantiations with a per-clip first row, height and vertical table.
-    if (ctx->resize_mode == 0 && (h + 63) / 64 > 2 && (vdf::resize_rowcrop_streams(w) || std::getenv("VDF_ROWCROP_ALL")) && !std::getenv("VDF_NO_ROWCROP")) {
-        bool rows_only = true;
-        for (size_t c = 0; c < n_clips && rows_only; c++) rows_only = crops[4 * c] == 0 && crops[4 * c + 1] == 0;
-        bool streamed = rows_only && vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
-        const bool band = streamed && vdf::resize_stream_wants_band(w);
-        const bool ksplit = rows_only && !streamed && w > 1920 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
-        int rc = VDF_OK;
-        DeviceMfmaTable *mh = nullptr;
-        if (streamed || ksplit) mh = mfma_table(ctx, w, band ? vdf::kMfmaLayoutHorizontalBand : vdf::kMfmaLayoutHorizontal, stream, &rc);
-        if (rc) return rc;
-        if (mh && mh->host.ok) {
-            std::vector<vdf::CropStreamClip> sc(n_clips);
-            std::vector<vdf::CropStreamTable> st;
-            std::map<uint32_t, uint32_t> vindex;  // box height -> entry
-            bool ok = true;
-            for (size_t c = 0; c < n_clips && ok; c++) {
-                const uint32_t t = crops[4 * c + 2], b = crops[4 * c + 3];
-                if ((uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
-                vdf::CropStreamClip &q = sc[c];
-                q = vdf::CropStreamClip{};
-                q.y0 = t; q.w = w; q.h = h - t - b; q.wp = w;
-                auto it = vindex.find(q.h);
-                if (it == vindex.end()) {
-                    DeviceMfmaTable *tv = mfma_table(ctx, q.h, vdf::kMfmaLayoutVertical, stream, &rc);
-                    if (rc) return rc;
-                    if (!tv->host.ok) { ok = false; break; }
-                    st.push_back(vdf::CropStreamTable{tv->operand.p, tv->bias.as<int32_t>(), nullptr, tv->host.n_tiles, tv->host.precision, 0, 0});
-                    it = vindex.emplace(q.h, (uint32_t)st.size() - 1).first;
-                }
-                q.v_table = it->second;
-            }
-            if (ok) {
-                rc = upload(ctx, ctx->crop_desc, sc.data(), sc.size() * sizeof(vdf::CropStreamClip), stream);
-                if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
-                if (rc) return rc;
-                VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
-                vdf::MfmaResizeArgs a{};
-                a.bh = mh->operand.p;
-                a.bias_h = mh->bias.as<int32_t>();
-                a.prec_h = mh->host.precision;
-                a.n_kt = mh->host.n_tiles;
-                if (band) {
-                    a.band_meta = mh->meta.as<int32_t>();
-                    a.band_stride = mh->host.band_stride;
-                }
-                VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-                if (ksplit)
-                    VDF_HIP(ctx, vdf::launch_resize_mfma_frames_ksplit(d_frames, n_clips, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(),
-                                                                       stream, ctx->crop_desc.as<vdf::CropStreamClip>(),
-                                                                       ctx->crop_tables.as<vdf::CropStreamTable>()));
-                else
-                    VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_clips, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(),
-                                                                       stream, ctx->crop_desc.as<vdf::CropStreamClip>(),
-                                                                       ctx->crop_tables.as<vdf::CropStreamTable>()));
-                VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
-                return VDF_OK;
-            }
-        }
-    }
-    // Linear-stream form (frames of 256..1984 columns on dword-aligned bases): the crop box goes through LDS like a whole frame.
-    // Default for pitches that are not a multiple of the 128-byte line (measured, detect + crop + hash of letterboxed clips,
-    // whole-line kernel -> this: 854x480 1.68 -> 1.24 ms per 1000 clips, 720x576 1.42 -> 1.14, 426x240 x4000 1.85 -> 1.33,
-    // 960x540 1.63 -> 1.51, 1366x768 x500 2.19 -> 1.95); line-aligned pitches stay on the whole-line kernel (1920x1080
-    // 5.44 against 5.84 ms, 1280x720 2.54 against 2.74) - for boxes with top / bottom bars only, which is all that measurement had.
-    // Boxes with SIDE bars (pillarboxed clips) take the stream form at line-aligned pitches too: the whole-line kernel reads every
-    // line the box touches and pays for the bars' columns (1000 clips of 1920x1080 with 240-column bars, crop + hash: 7.7 -> 5.5 ms,
-    // 1280x720 x2000 6.4 -> 3.9, 1536x864 4.5 -> 2.9, 640x360 x4000 3.4 -> 2.5; 1024 wide 3.5 -> 3.8: stays; gpurun_out/r03pb).
-    // VDF_RESIZE_MODE=5 takes every pitch.
-    bool side_bars = false;
-    for (size_t c = 0; c < n_clips && !side_bars; c++) side_bars = crops[4 * c] != 0 || crops[4 * c + 1] != 0;
-    int stream_cls = 0;
-    if (((ctx->resize_mode == 0 && (w % 128 != 0 || (side_bars && w != 1024))) || ctx->resize_mode == 5) && (h + 63) / 64 > 2 &&
-        (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 && (uint64_t)w * h < (1ull << 31) && ((uint64_t)w * h) % 16 == 0 &&
-        vdf::resize_cropped_stream_class(w, &stream_cls)) {
-        std::vector<vdf::CropStreamClip> sc(n_clips);
-        std::vector<vdf::CropStreamTable> st;
-        std::map<uint64_t, uint32_t> sindex;  // (size * 2 + vertical) -> entry
-        bool ok = true, need_shift = (w & 3u) != 0;
-        auto stream_entry = [&](uint32_t size, bool vertical, int *rc) -> uint32_t {
-            const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
-            auto it = sindex.find(key);
-            if (it != sindex.end()) return it->second;
-            DeviceMfmaTable *t = mfma_table(ctx, size, vertical ? vdf::kMfmaLayoutVertical : vdf::kMfmaLayoutHorizontalBand, stream, rc);
-            if (*rc) return 0;
-            if (!t->host.ok) { ok = false; return 0; }
-            vdf::CropStreamTable e{t->operand.p, t->bias.as<int32_t>(), vertical ? nullptr : t->meta.as<int32_t>(), t->host.n_tiles,
-                                   t->host.precision, t->host.band_stride, 0};
-            st.push_back(e);
-            sindex[key] = (uint32_t)st.size() - 1;
-            return (uint32_t)st.size() - 1;
-        };
-        for (size_t c = 0; c < n_clips && ok; c++) {
-            const uint32_t l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
-            if ((uint64_t)l + r >= w || (uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
-            vdf::CropStreamClip &q = sc[c];
-            q = vdf::CropStreamClip{};
-            q.x0 = l; q.y0 = t; q.w = w - l - r; q.h = h - t - b;
-            q.nb = vdf::resize_cropped_stream_blocks(q.w, q.x0, w, stream_cls, &q.wp);
-            need_shift = need_shift || (q.x0 & 3u) != 0;
-            if (q.nb < 2 && q.h > 16) { ok = false; break; }  // one block per chunk would leave three of the four waves idle
-            if (q.nb == 0) { ok = false; break; }
-            q.step_rows = 4096u / q.wp;
-            q.step_x = 4096u - q.step_rows * q.wp;
-            q.n_chunks = (q.h + 16 * q.nb - 1) / (16 * q.nb);
-            int rc = VDF_OK;
-            q.h_table = stream_entry(q.w, false, &rc);
-            if (rc) return rc;
-            if (ok) q.v_table = stream_entry(q.h, true, &rc);
-            if (rc) return rc;
-        }
-        if (ok) {
-            int rc = upload(ctx, ctx->crop_desc, sc.data(), sc.size() * sizeof(vdf::CropStreamClip), stream);
-            if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
-            if (rc) return rc;
-            VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
-            VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-            VDF_HIP(ctx, vdf::launch_resize_mfma_cropped_stream(d_frames, n_clips, w, h, frame_stride, clip_stride,
-                                                                ctx->crop_desc.as<vdf::CropStreamClip>(),
-                                                                ctx->crop_tables.as<vdf::CropStreamTable>(), stream_cls,
-                                                                need_shift, ctx->small.as<uint8_t>(), stream));
-            VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out,
-                                              d_dc, stream));
-            return VDF_OK;
-        }
-    }
-    std::vector<vdf::CropClipDesc> desc(n_clips);
-    std::vector<vdf::CropTableEntry> entries;
-    const bool wide = w >= 192;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
-    std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
-    auto entry_for = [&](uint32_t size, bool vertical, int *rc) -> uint32_t {
-        const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
-        auto it = index.find(key);
-        if (it != index.end()) return it->second;
-        DeviceMfmaTable *t = mfma_table(ctx, size, !vertical ? vdf::kMfmaLayoutHorizontal : wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, rc);
-        if (*rc) return 0;
-        if (!t->host.ok) { *rc = fail(ctx, VDF_E_BAD_DIMS, "crop box size whose coefficients do not fit the i8 split"); return 0; }
-        vdf::CropTableEntry e{t->operand.p, t->bias.as<int32_t>(), t->host.n_tiles, t->host.precision};
-        entries.push_back(e);
-        index[key] = (uint32_t)entries.size() - 1;
-        return (uint32_t)entries.size() - 1;
-    };
+    // Three kernels read crop boxes in place; a call is dealt out between the first two by box shape, clip by clip (each entry of a
+    // launch names its clip of the batch: CropStreamClip::src_clip), and one dct_hash launch follows over the whole batch:
+    //  * ROWCROP stream kernels - full-width boxes (top / bottom bars only: a 2.39 : 1 film in a 16 : 9 frame, the commonest letterbox;
+    //    clips without bars among them are boxes of the whole frame).  The box is a contiguous range of rows at the frame's own pitch,
+    //    so it streams like a shorter frame: the kernel the uncropped call would take at that width (per-wave, chunk or K-split form)
+    //    with a per-clip first row, height and vertical table.
+    //  * the cropped stream kernel - boxes with side bars (pillarboxed clips): rows x0 .. x0 + w of the box go through LDS by gather
+    //    DMA.  Also full-width boxes where no ROWCROP kernel applies and the pitch is not a multiple of the 128-byte line.
+    //    Measured, detect + crop + hash against the whole-line kernel below: 854x480 1.68 -> 1.24 ms per 1000 clips, 720x576 1.42 -> 1.14,
+    //    426x240 x4000 1.85 -> 1.33, 1366x768 x500 2.19 -> 1.95; pillarboxed 1920x1080 x1000 crop + hash 7.7 -> 5.5 ms, 1280x720 x2000
+    //    6.4 -> 3.9, 1536x864 4.5 -> 2.9, 640x360 x4000 3.4 -> 2.5; 1024 wide 3.5 -> 3.8: stays (gpurun_out/r03pb).
+    //  * the whole-line cropped kernel (below) - everything else: misaligned buffers, frames that do not end on 16 bytes, short frames,
+    //    boxes whose tables do not fit the i8 split, VDF_RESIZE_MODE=4.
+    const bool tall = (h + 63) / 64 > 2, ends16 = ((uint64_t)w * h) % 16 == 0 && (uint64_t)w * h < (1ull << 31);
+    std::vector<uint32_t> rows_clips, side_clips;  // by box shape
     for (size_t c = 0; c < n_clips; c++) {
         const uint32_t l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
         if ((uint64_t)l + r >= w || (uint64_t)t + b >= h) return fail(ctx, VDF_E_INVAL, "crop box leaves no pixels");  // crop.rs:21-22
-        int rc = VDF_OK;
-        desc[c].x0 = l; desc[c].y0 = t; desc[c].w = w - l - r; desc[c].h = h - t - b;
-        desc[c].h_table = entry_for(desc[c].w, false, &rc);
-        if (rc) return rc;
-        desc[c].v_table = entry_for(desc[c].h, true, &rc);
-        if (rc) return rc;
+        (l == 0 && r == 0 ? rows_clips : side_clips).push_back((uint32_t)c);
     }
-    int rc = upload(ctx, ctx->crop_desc, desc.data(), desc.size() * sizeof(vdf::CropClipDesc), stream);
-    if (rc == VDF_OK) rc = upload(ctx, ctx->crop_tables, entries.data(), entries.size() * sizeof(vdf::CropTableEntry), stream);
-    if (rc) return rc;
-    VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors above go out of scope
+    // -- can the full-width boxes take a ROWCROP kernel, and which?
+    bool row_stream = false, row_ksplit = false, row_band = false;
+    DeviceMfmaTable *row_mh = nullptr;
+    if (ctx->resize_mode == 0 && tall && !rows_clips.empty() && (vdf::resize_rowcrop_streams(w) || std::getenv("VDF_ROWCROP_ALL")) &&
+        !std::getenv("VDF_NO_ROWCROP")) {
+        row_stream = vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
+        row_band = row_stream && vdf::resize_stream_wants_band(w);
+        row_ksplit = !row_stream && w > 1920 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
+        if (row_stream || row_ksplit) {
+            int rc = VDF_OK;
+            row_mh = mfma_table(ctx, w, row_band ? vdf::kMfmaLayoutHorizontalBand : vdf::kMfmaLayoutHorizontal, stream, &rc);
+            if (rc) return rc;
+            if (!row_mh->host.ok) row_mh = nullptr;
+        }
+    }
+    // -- can boxes take the cropped stream kernel?
+    int stream_cls = 0;
+    const bool crop_stream_ok = tall && ends16 && (((uintptr_t)d_frames | frame_stride | clip_stride) & 3) == 0 &&
+                                (ctx->resize_mode == 0 || ctx->resize_mode == 5) && vdf::resize_cropped_stream_class(w, &stream_cls);
+    // descriptors of a ROWCROP launch over `ids`; false: some box's vertical table does not fit the i8 split
+    std::vector<vdf::CropStreamClip> rsc, ssc;
+    std::vector<vdf::CropStreamTable> rst, sst;
+    auto build_rows = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
+        std::map<uint32_t, uint32_t> vindex;  // box height -> entry
+        rsc.assign(ids.size(), vdf::CropStreamClip{});
+        rst.clear();
+        for (size_t i = 0; i < ids.size(); i++) {
+            const uint32_t c = ids[i], t = crops[4 * c + 2], b = crops[4 * c + 3];
+            vdf::CropStreamClip &q = rsc[i];
+            q.y0 = t; q.w = w; q.h = h - t - b; q.wp = w; q.src_clip = c;
+            auto it = vindex.find(q.h);
+            if (it == vindex.end()) {
+                DeviceMfmaTable *tv = mfma_table(ctx, q.h, vdf::kMfmaLayoutVertical, stream, rc);
+                if (*rc || !tv->host.ok) return false;
+                rst.push_back(vdf::CropStreamTable{tv->operand.p, tv->bias.as<int32_t>(), nullptr, tv->host.n_tiles, tv->host.precision, 0, 0});
+                it = vindex.emplace(q.h, (uint32_t)rst.size() - 1).first;
+            }
+            q.v_table = it->second;
+        }
+        return true;
+    };
+    // descriptors of a cropped-stream launch over `ids`; false: a box does not fit the kernel (tables, blocks per chunk)
+    bool need_shift = (w & 3u) != 0;
+    auto build_stream = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
+        std::map<uint64_t, uint32_t> sindex;  // (size * 2 + vertical) -> entry
+        ssc.assign(ids.size(), vdf::CropStreamClip{});
+        sst.clear();
+        auto stream_entry = [&](uint32_t size, bool vertical, uint32_t *at) -> bool {
+            const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
+            auto it = sindex.find(key);
+            if (it != sindex.end()) { *at = it->second; return true; }
+            DeviceMfmaTable *t = mfma_table(ctx, size, vertical ? vdf::kMfmaLayoutVertical : vdf::kMfmaLayoutHorizontalBand, stream, rc);
+            if (*rc || !t->host.ok) return false;
+            sst.push_back(vdf::CropStreamTable{t->operand.p, t->bias.as<int32_t>(), vertical ? nullptr : t->meta.as<int32_t>(), t->host.n_tiles,
+                                               t->host.precision, t->host.band_stride, 0});
+            *at = sindex[key] = (uint32_t)sst.size() - 1;
+            return true;
+        };
+        for (size_t i = 0; i < ids.size(); i++) {
+            const uint32_t c = ids[i], l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
+            vdf::CropStreamClip &q = ssc[i];
+            q.x0 = l; q.y0 = t; q.w = w - l - r; q.h = h - t - b; q.src_clip = c;
+            q.nb = vdf::resize_cropped_stream_blocks(q.w, q.x0, w, stream_cls, &q.wp);
+            need_shift = need_shift || (q.x0 & 3u) != 0;
+            if (q.nb == 0 || (q.nb < 2 && q.h > 16)) return false;  // one block per chunk would leave three of the four waves idle
+            q.step_rows = 4096u / q.wp;
+            q.step_x = 4096u - q.step_rows * q.wp;
+            q.n_chunks = (q.h + 16 * q.nb - 1) / (16 * q.nb);
+            if (!stream_entry(q.w, false, &q.h_table) || !stream_entry(q.h, true, &q.v_table)) return false;
+        }
+        return true;
+    };
+    auto upload_desc = [&](const std::vector<vdf::CropStreamClip> &sc, const std::vector<vdf::CropStreamTable> &st, DevBuf &bd, DevBuf &bt) -> int {
+        int rc = upload(ctx, bd, sc.data(), sc.size() * sizeof(vdf::CropStreamClip), stream);
+        if (rc == VDF_OK) rc = upload(ctx, bt, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
+        return rc;
+    };
+    auto launch_rows = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
+        vdf::MfmaResizeArgs a{};
+        a.bh = row_mh->operand.p;
+        a.bias_h = row_mh->bias.as<int32_t>();
+        a.prec_h = row_mh->host.precision;
+        a.n_kt = row_mh->host.n_tiles;
+        if (row_band) {
+            a.band_meta = row_mh->meta.as<int32_t>();
+            a.band_stride = row_mh->host.band_stride;
+        }
+        if (row_ksplit)
+            VDF_HIP(ctx, vdf::launch_resize_mfma_frames_ksplit(d_frames, n_sub, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(), stream,
+                                                               bd.as<vdf::CropStreamClip>(), bt.as<vdf::CropStreamTable>()));
+        else
+            VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_sub, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(), stream,
+                                                               bd.as<vdf::CropStreamClip>(), bt.as<vdf::CropStreamTable>()));
+        return VDF_OK;
+    };
+    auto launch_stream = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
+        VDF_HIP(ctx, vdf::launch_resize_mfma_cropped_stream(d_frames, n_sub, w, h, frame_stride, clip_stride, bd.as<vdf::CropStreamClip>(),
+                                                            bt.as<vdf::CropStreamTable>(), stream_cls, need_shift, ctx->small.as<uint8_t>(), stream));
+        return VDF_OK;
+    };
+    auto uploads_done = [&]() -> int {
+        VDF_HIP(ctx, hipStreamSynchronize(stream));  // the host vectors go out of scope with this call
+        VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
+        return VDF_OK;
+    };
+    auto finish = [&]() -> int {
+        VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
+        return VDF_OK;
+    };
+    {
+        int rc = VDF_OK;
+        // side-bar boxes want the stream form at every pitch but 1024 (measured above); full-width ones where the pitch is not line-aligned
+        const bool side_stream = crop_stream_ok && (ctx->resize_mode == 5 || w != 1024);
+        const bool rows_stream = crop_stream_ok && (ctx->resize_mode == 5 || w % 128 != 0);
+        if (side_clips.empty() && row_mh) {  // every box is full-width: one ROWCROP launch
+            if (build_rows(rows_clips, &rc)) {
+                if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
+                if ((rc = launch_rows(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
+                return finish();
+            }
+            if (rc) return rc;
+        } else if (!side_clips.empty() && !rows_clips.empty() && row_mh && side_stream) {  // mixed: each shape to its kernel
+            if (build_rows(rows_clips, &rc) && build_stream(side_clips, &rc)) {
+                if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = upload_desc(ssc, sst, ctx->crop_desc2, ctx->crop_tables2)) ||
+                    (rc = uploads_done()))
+                    return rc;
+                if ((rc = launch_rows(rows_clips.size(), ctx->crop_desc, ctx->crop_tables))) return rc;
+                if ((rc = launch_stream(side_clips.size(), ctx->crop_desc2, ctx->crop_tables2))) return rc;
+                return finish();
+            }
+            if (rc) return rc;
+        }
+        if (side_clips.empty() ? rows_stream : side_stream) {  // the whole call through the cropped stream kernel
+            std::vector<uint32_t> all(n_clips);
+            for (size_t c = 0; c < n_clips; c++) all[c] = (uint32_t)c;
+            need_shift = (w & 3u) != 0;
+            if (build_stream(all, &rc)) {
+                if ((rc = upload_desc(ssc, sst, ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
+                if ((rc = launch_stream(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
+                return finish();
+            }
+            if (rc) return rc;
+        }
+    }
+    // -- the whole-line cropped kernel, over `ids` (all clips, or the side-bar boxes of a mixed call whose full-width boxes stream)
+    std::vector<vdf::CropClipDesc> desc;
+    std::vector<vdf::CropTableEntry> entries;
+    const bool wide = w >= 192;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
+    auto build_lines = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
+        std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
+        desc.assign(ids.size(), vdf::CropClipDesc{});
+        entries.clear();
+        auto entry_for = [&](uint32_t size, bool vertical, uint32_t *at) -> bool {
+            const uint64_t key = (uint64_t)size * 2 + (vertical ? 1 : 0);
+            auto it = index.find(key);
+            if (it != index.end()) { *at = it->second; return true; }
+            DeviceMfmaTable *t = mfma_table(ctx, size, !vertical ? vdf::kMfmaLayoutHorizontal : wide ? vdf::kMfmaLayoutVerticalWide : vdf::kMfmaLayoutVertical, stream, rc);
+            if (*rc) return false;
+            if (!t->host.ok) { *rc = fail(ctx, VDF_E_BAD_DIMS, "crop box size whose coefficients do not fit the i8 split"); return false; }
+            entries.push_back(vdf::CropTableEntry{t->operand.p, t->bias.as<int32_t>(), t->host.n_tiles, t->host.precision});
+            *at = index[key] = (uint32_t)entries.size() - 1;
+            return true;
+        };
+        for (size_t i = 0; i < ids.size(); i++) {
+            const uint32_t c = ids[i], l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
+            vdf::CropClipDesc &q = desc[i];
+            q.x0 = l; q.y0 = t; q.w = w - l - r; q.h = h - t - b; q.src_clip = c;
+            if (!entry_for(q.w, false, &q.h_table) || !entry_for(q.h, true, &q.v_table)) return false;
+        }
+        return true;
+    };
     const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
-    VDF_HIP(ctx, ctx->small.reserve(n_clips * 4096));
-    VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_clips, w, frame_stride, clip_stride, buf_end,
-                                                 ctx->crop_desc.as<vdf::CropClipDesc>(),
-                                                 ctx->crop_tables.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), wide,
-                                                 stream));
-    VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out,
-                                      d_dc, stream));
-    return VDF_OK;
+    auto launch_lines = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
+        VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),
+                                                     bt.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), wide, stream));
+        return VDF_OK;
+    };
+    auto upload_lines = [&](DevBuf &bd, DevBuf &bt) -> int {
+        int rc = upload(ctx, bd, desc.data(), desc.size() * sizeof(vdf::CropClipDesc), stream);
+        if (rc == VDF_OK) rc = upload(ctx, bt, entries.data(), entries.size() * sizeof(vdf::CropTableEntry), stream);
+        return rc;
+    };
+    int rc = VDF_OK;
+    if (!side_clips.empty() && !rows_clips.empty() && row_mh && build_rows(rows_clips, &rc)) {
+        // mixed call whose side-bar boxes cannot take the stream form (frames wider than its classes: 4K): full-width boxes still stream
+        if (!build_lines(side_clips, &rc)) return rc ? rc : fail(ctx, VDF_E_BAD_DIMS, "crop box");
+        if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = upload_lines(ctx->crop_desc2, ctx->crop_tables2)) || (rc = uploads_done()))
+            return rc;
+        if ((rc = launch_rows(rows_clips.size(), ctx->crop_desc, ctx->crop_tables))) return rc;
+        if ((rc = launch_lines(side_clips.size(), ctx->crop_desc2, ctx->crop_tables2))) return rc;
+        return finish();
+    }
+    if (rc) return rc;
+    std::vector<uint32_t> all(n_clips);
+    for (size_t c = 0; c < n_clips; c++) all[c] = (uint32_t)c;
+    if (!build_lines(all, &rc)) return rc ? rc : fail(ctx, VDF_E_BAD_DIMS, "crop box");
+    if ((rc = upload_lines(ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
+    if ((rc = launch_lines(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
+    return finish();
 }
 
 int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,

@@ -772,7 +772,7 @@ typedef const __attribute__((address_space(4))) CropStreamTable *const_table_ptr
 typedef const __attribute__((address_space(1))) v4i *global_v4i;
 typedef const __attribute__((address_space(1))) int32_t *global_i32;
 struct RowGeo {
-    uint32_t y0, h;
+    uint32_t y0, h, src;  // src: the clip's index in the caller's batch
     int32_t n_rg, prec_v;
     global_v4i av;
     global_i32 bias_v;
@@ -791,6 +791,7 @@ __device__ __forceinline__ RowGeo row_geo_of(const_clip_ptr clips, const_table_p
     RowGeo q;
     q.y0 = sgpr_u32(clips[clip].y0);
     q.h = sgpr_u32(clips[clip].h);
+    q.src = sgpr_u32(clips[clip].src_clip);
     const uint32_t vt = sgpr_u32(clips[clip].v_table);
     q.av = (global_v4i)sgpr_global_ptr(tables[vt].operand);
     q.bias_v = (global_i32)sgpr_global_ptr(tables[vt].bias);
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     // workgroup's frame after it (fetched when geo becomes current), geo_p = the frame whose result is pending
     const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
     const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
-    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
+    RowGeo geo = {0u, H, 0u, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
     int32_t pend_prec = T.prec_v;
     // MODE 1, 2: where this lane's first DMA instruction of a chunk lands (LDS position P0 = 1024 wave + 16 lane = row * Wp + x) and
     // how far an instruction (4096 bytes of LDS further) moves it; the loop below only adds and compares - with a multiply
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
 
     auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst, const RowGeo &q) __attribute__((always_inline)) {
-        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const uint8_t *src = frames + (size_t)(ROWCROP ? q.src : F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
         const uint32_t start = (q.y0 + c * rpc) * W, rows = min(rpc, q.h - c * rpc), bytes = rows * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;  // MODE 1, 2: this lane's position in the chunk: column, row * W
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             pend_vh = acc_vh; pend_vl = acc_vl;
             acc_vh = zero4; acc_vl = zero4;
             out_pending = true;
-            out_F = F;
+            out_F = ROWCROP ? geo.src * 16u + (F & 15u) : F;
             if constexpr (ROWCROP) {  // the finished clip's bias and precision; the next barrier's vmcnt wait covers the loads
                 pend_prec = geo.prec_v;
                 if (wave == 0) {
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
     const uint32_t frame_bytes = W * H;
     const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
     const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
-    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;  // of frame F, of the workgroup's next frame
+    RowGeo geo = {0u, H, 0u, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;  // of frame F, of the workgroup's next frame
     const int32_t bias_h = T.bias_h[r16];
     v4i bias_v = {0, 0, 0, 0};
     if constexpr (!ROWCROP) {
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
     }
     const uint32_t shift0 = MODE == 2 ? (r16 * W) & 3u : 0u;  // blocks start on multiples of 16 rows: (row * W) & 3 is the frame row's
     auto issue_dma = [&](uint32_t F, uint32_t b, const RowGeo &q) __attribute__((always_inline)) {
-        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const uint8_t *src = frames + (size_t)(ROWCROP ? q.src : F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
         const uint32_t start = (q.y0 + 16u * b) * W, bytes = min(16u, q.h - 16u * b) * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;
@@ -1171,7 +1172,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
                 for (int w = 0; w < NW - 1; w++) vl[r] += s_part[parity][w][lane][r];
             }
             const uint32_t px = finalize4(acc_vh, vl, geo.prec_v) ^ 0x80808080u;
-            uint8_t *dst = small + (size_t)F * 256;
+            uint8_t *dst = small + (size_t)(ROWCROP ? geo.src * 16u + (F & 15u) : F) * 256;
 #pragma unroll
             for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
         }
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
     // ROWCROP: as in resize_mfma_frame_stream_kernel
     const_clip_ptr clips = (const_clip_ptr)(uintptr_t)clips_g;
     const_table_ptr tables = (const_table_ptr)(uintptr_t)tables_g;
-    RowGeo geo = {0u, H, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
+    RowGeo geo = {0u, H, 0u, T.n_rg, T.prec_v, (global_v4i)T.av, (global_i32)T.bias_v}, geo_n = geo;
     int32_t pend_prec = T.prec_v;
     const v4i zero4 = {0, 0, 0, 0};
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
         lane_ro0 = row0 * W;
     }
     auto issue_dma = [&](uint32_t F, uint32_t c, uint4 *dst, const RowGeo &q) __attribute__((always_inline)) {
-        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const uint8_t *src = frames + (size_t)(ROWCROP ? q.src : F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
         const uint32_t start = (q.y0 + c * rpc) * W, rows = min(rpc, q.h - c * rpc), bytes = rows * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;
@@ -1424,7 +1425,7 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_ksplit_kernel(const uin
             pend_vh = acc_vh; pend_vl = acc_vl;
             acc_vh = zero4; acc_vl = zero4;
             out_pending = true;
-            out_F = F;
+            out_F = ROWCROP ? geo.src * 16u + (F & 15u) : F;
             if constexpr (ROWCROP) {
                 pend_prec = geo.prec_v;
                 if (wave == 0) {
@@ -1526,7 +1527,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     // (table and bias pointers) is read from the table entries where it is used, once per frame, off the critical path.
     // Kept small on purpose: with the pointers in here the two copies spilled and the scalar loads turned into VMEM loads.
     struct Geo {
-        uint32_t x0, y0, h, wp, step_rows, step_x, nb, n_chunks, h_table, v_table;  // step_*: 4096 = step_rows * wp + step_x
+        uint32_t x0, y0, h, wp, step_rows, step_x, nb, n_chunks, h_table, v_table, src;  // step_*: 4096 = step_rows * wp + step_x; src: the clip's index in the caller's batch
         const __attribute__((address_space(1))) v4i *av;
         int32_t n_kt, n_rg, prec_h, prec_v;
     };
@@ -1545,7 +1546,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     auto geo_of = [&](uint32_t F) __attribute__((always_inline)) {
         const uint32_t clip = sgpr(F >> 4);
         Geo q;
-        q.x0 = sgpr(clips[clip].x0); q.y0 = sgpr(clips[clip].y0); q.h = sgpr(clips[clip].h);
+        q.x0 = sgpr(clips[clip].x0); q.y0 = sgpr(clips[clip].y0); q.h = sgpr(clips[clip].h); q.src = sgpr(clips[clip].src_clip);
         q.wp = sgpr(clips[clip].wp); q.nb = sgpr(clips[clip].nb);
         q.step_rows = sgpr(clips[clip].step_rows); q.step_x = sgpr(clips[clip].step_x);
         q.n_chunks = sgpr(clips[clip].n_chunks);
@@ -1560,7 +1561,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
     };
     // lx0, lro0: this lane's column and row * pitch at its first DMA instruction of a chunk (LDS position 1024 wave + 16 lane)
     auto issue_dma = [&](uint32_t F, const Geo &q, uint32_t lx0, uint32_t lro0, uint32_t c, uint4 *dst) __attribute__((always_inline)) {
-        const uint8_t *src = frames + (size_t)(F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
+        const uint8_t *src = frames + (size_t)q.src * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
         const uint32_t rpc = 16u * q.nb, rows = min(rpc, q.h - c * rpc), bytes = rows * q.wp;
         const uint32_t first = (q.y0 + c * rpc) * pitch + q.x0;  // frame byte of the chunk's first pixel
@@ -1720,7 +1721,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
             pend_vh = acc_vh; pend_vl = acc_vl; pend_bias_v = bias_v; pend_prec_v = cur.prec_v;
             acc_vh = zero4; acc_vl = zero4;
             out_pending = true;
-            out_F = F;
+            out_F = cur.src * 16u + (F & 15u);
             // the next frame's biases, consumed at its first chunk = the next step, behind the barrier (requested here and not in
             // the c == 0 block above, where the same registers are read: the compiler then loaded into temporaries and waited)
             if (Fn < n_frames) load_biases(nf);
@@ -1821,7 +1822,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
     T.band_meta = nullptr;
     T.band_stride = 0;
     v4i vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-    const uint8_t *src = frames + clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
+    const uint8_t *src = frames + (size_t)d.src_clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
     // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very
     // end of the buffer needs the careful loader
     if (WIDE) {  // whole-line loads as in resize_mfma_frame_wide_kernel (vertical tables in kMfmaLayoutVerticalWide order)
@@ -1846,7 +1847,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
             for (int w = 0; w < 3; w++) { vh[r] += s_part[w][0][lane][r]; vl[r] += s_part[w][1][lane][r]; }
         }
         const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
-        uint8_t *dst = small + (clip * 16 + f) * 256;
+        uint8_t *dst = small + ((size_t)d.src_clip * 16 + f) * 256;
 #pragma unroll
         for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
     }

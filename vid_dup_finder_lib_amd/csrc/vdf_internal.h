@@ -131,6 +131,7 @@ hipError_t launch_resize_mfma_frames_ksplit(const uint8_t *frames, size_t n_clip
 struct CropClipDesc {  // per clip: crop box inside the W x H frame and the table entries for its size
     uint32_t x0, y0, w, h;
     uint32_t h_table, v_table;
+    uint32_t src_clip, pad;  // which clip of the caller's batch (a launch may cover a subset: see CropStreamClip::src_clip)
 };
 struct CropTableEntry {  // one MFMA-layout axis table (device pointers)
     const void *operand;
@@ -141,7 +142,9 @@ struct CropTableEntry {  // one MFMA-layout axis table (device pointers)
 // reciprocal the DMA lanes divide by are fixed per clip on the host; the horizontal table is in band form
 struct CropStreamClip {
     uint32_t x0, y0, w, h;
-    uint32_t wp, nb, n_chunks, pad0;   // LDS pitch (odd multiple of 16 >= w + 3, or the frame pitch for a full-width box), 16-row blocks per chunk, chunks per frame
+    uint32_t wp, nb, n_chunks, src_clip;  // LDS pitch (odd multiple of 16 >= w + 3, or the frame pitch for a full-width box), 16-row blocks per chunk, chunks per frame;
+                                          // src_clip: which clip of the caller's batch this entry is (a launch may cover a subset of the batch: frames are
+                                          // read from, and the 16 x 16 results written to, clip src_clip's place)
     uint32_t h_table, v_table, step_rows, step_x;  // 4096 = step_rows * wp + step_x: what one DMA instruction advances a lane by
 };
 struct CropStreamTable {
