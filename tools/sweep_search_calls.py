@@ -25,7 +25,7 @@ def self_call(words, dur, tol, reps=3):
 print("== self search, all durations equal (full triangle), tolerance 350: whole call")
 for n in (1000, 10_000, 100_000, 300_000, 1_000_000):
     w = make_hashes(n, 1); ms, tm, g = self_call(w, np.zeros(n, np.uint32), 350)
-    print(f"n={n:8d}: {ms:8.3f} ms  (stream {tm['stream_ms']:.3f} resolve {tm['resolve_ms']:.3f} download {tm['download_ms']:.3f} replay {tm['replay_ms']:.3f}) {n*(n-1)/2/ms/1e9:.1f} Gpairs/ms-ish")
+    print(f"n={n:8d}: {ms:8.3f} ms  (stream {tm['stream_ms']:.3f} resolve {tm['resolve_ms']:.3f} download {tm['download_ms']:.3f} replay {tm['replay_ms']:.3f}) {n*(n-1)/2/ms/1e9:.1f} T pairs/s")
 print("== 300 k hashes, tolerance sweep (random hashes: hits only from the planted copies)")
 w = make_hashes(300_000, 2)
 for tol in (0, 100, 350, 400, 450, 480, 500):
