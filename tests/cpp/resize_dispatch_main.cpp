@@ -115,6 +115,25 @@ int main()
     // full-width crop boxes: the ROWCROP stream kernels everywhere but 2048 columns (measured)
     for (uint32_t w : {64u, 426u, 640u, 768u, 854u, 1024u, 1280u, 1366u, 1536u, 1600u, 1792u, 1920u, 2560u, 3840u, 4096u}) CHECK(resize_rowcrop_streams(w), "%u wide: row-cropped stream kernels", w);
     CHECK(!resize_rowcrop_streams(2048), "2048 wide: general cropped kernels");
+    // crop boxes that share their column range, through the per-wave kernel: the LDS pitch holds the box and the up to 3 bytes in front of a
+    // row that starts off a dword, is an odd multiple of 16, and the (whole-KB) block fits the buffer of the chosen wave count
+    for (uint32_t fw : {640u, 854u, 1280u, 1366u, 1920u, 1921u, 2048u, 3840u})
+        for (uint32_t x0 : {0u, 1u, 3u, 4u, 16u, 240u, 241u})
+            for (uint32_t bw = 500; x0 + bw <= fw; bw += 37) {
+                int mode = -1;
+                const uint32_t wp = box_stream_pitch(fw, x0, bw, &mode);
+                const bool whole = x0 == 0 && bw == fw, shifted = fw % 4 != 0 || x0 % 4 != 0;
+                if (!whole) {
+                    CHECK(mode == (shifted ? 2 : 1) && wp % 16 == 0 && (wp / 16) % 2 == 1 && wp >= bw + (shifted ? 3u : 0u) && wp < bw + 48,
+                          "box pitch fw=%u x0=%u bw=%u -> %u mode %d", fw, x0, bw, wp, mode);
+                }
+                const int nw = resize_wavestream_waves_box(fw, x0, bw);
+                if (nw && !whole) {
+                    const int buf = nw == 3 ? kWaveStreamBuf3 : nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : kWaveStreamBuf8;
+                    CHECK(bw >= 513 && ((16 * wp + 1023) & ~1023u) + 128 <= (uint32_t)buf, "box block fits fw=%u x0=%u bw=%u nw=%d", fw, x0, bw, nw);
+                }
+                if (!whole && bw >= 513 && wp <= 2368) CHECK(nw != 0, "boxes up to pitch 2368 take the per-wave kernel fw=%u x0=%u bw=%u", fw, x0, bw);
+            }
     uint32_t kp = 0;
     CHECK(ksplit_geometry(3840, &kp) == 1 && kp == 3856, "4K: one 16-row block per chunk at pitch 3856");
     CHECK(ksplit_geometry(2048, &kp) == 2 && kp == 2064, "2048 wide: two blocks per chunk");

@@ -663,14 +663,14 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     // descriptors of a ROWCROP launch over `ids`; false: some box's vertical table does not fit the i8 split
     std::vector<vdf::CropStreamClip> rsc, ssc;
     std::vector<vdf::CropStreamTable> rst, sst;
-    auto build_rows = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
-        std::map<uint32_t, uint32_t> vindex;  // box height -> entry
-        rsc.assign(ids.size(), vdf::CropStreamClip{});
-        rst.clear();
+    std::map<uint32_t, uint32_t> vindex;  // box height -> entry of rst
+    auto append_rows = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {  // (appends: a call may hold several ROWCROP launches)
+        const size_t first = rsc.size();
+        rsc.resize(first + ids.size(), vdf::CropStreamClip{});
         for (size_t i = 0; i < ids.size(); i++) {
             const uint32_t c = ids[i], t = crops[4 * c + 2], b = crops[4 * c + 3];
-            vdf::CropStreamClip &q = rsc[i];
-            q.y0 = t; q.w = w; q.h = h - t - b; q.wp = w; q.src_clip = c;
+            vdf::CropStreamClip &q = rsc[first + i];
+            q.x0 = crops[4 * c]; q.y0 = t; q.w = w - crops[4 * c] - crops[4 * c + 1]; q.h = h - t - b; q.wp = w; q.src_clip = c;
             auto it = vindex.find(q.h);
             if (it == vindex.end()) {
                 DeviceMfmaTable *tv = mfma_table(ctx, q.h, vdf::kMfmaLayoutVertical, stream, rc);
@@ -718,7 +718,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         if (rc == VDF_OK) rc = upload(ctx, bt, st.data(), st.size() * sizeof(vdf::CropStreamTable), stream);
         return rc;
     };
-    auto launch_rows = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
+    auto launch_rows = [&](size_t first, size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
         vdf::MfmaResizeArgs a{};
         a.bh = row_mh->operand.p;
         a.bias_h = row_mh->bias.as<int32_t>();
@@ -730,10 +730,25 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         }
         if (row_ksplit)
             VDF_HIP(ctx, vdf::launch_resize_mfma_frames_ksplit(d_frames, n_sub, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(), stream,
-                                                               bd.as<vdf::CropStreamClip>(), bt.as<vdf::CropStreamTable>()));
+                                                               bd.as<vdf::CropStreamClip>() + first, bt.as<vdf::CropStreamTable>()));
         else
             VDF_HIP(ctx, vdf::launch_resize_mfma_frames_stream(d_frames, n_sub, w, h, frame_stride, clip_stride, a, ctx->small.as<uint8_t>(), stream,
-                                                               bd.as<vdf::CropStreamClip>(), bt.as<vdf::CropStreamTable>()));
+                                                               bd.as<vdf::CropStreamClip>() + first, bt.as<vdf::CropStreamTable>()));
+        return VDF_OK;
+    };
+    // boxes with side bars that share their column range: the per-wave kernel gathers the box (one launch per distinct range)
+    struct BoxGroup { uint32_t x0, bw; std::vector<uint32_t> ids; DeviceMfmaTable *mh; size_t first; };
+    auto launch_box = [&](const BoxGroup &g, DevBuf &bd, DevBuf &bt) -> int {
+        vdf::MfmaResizeArgs a{};
+        a.bh = g.mh->operand.p;
+        a.bias_h = g.mh->bias.as<int32_t>();
+        a.prec_h = g.mh->host.precision;
+        a.n_kt = g.mh->host.n_tiles;
+        a.band_meta = g.mh->meta.as<int32_t>();
+        a.band_stride = g.mh->host.band_stride;
+        VDF_HIP(ctx, vdf::launch_resize_mfma_box_wavestream(d_frames, g.ids.size(), w, h, frame_stride, clip_stride, a, g.x0, g.bw,
+                                                            bd.as<vdf::CropStreamClip>() + g.first, bt.as<vdf::CropStreamTable>(),
+                                                            ctx->small.as<uint8_t>(), stream));
         return VDF_OK;
     };
     auto launch_stream = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
@@ -750,41 +765,6 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
         return VDF_OK;
     };
-    {
-        int rc = VDF_OK;
-        // side-bar boxes want the stream form at every pitch but 1024 (measured above); full-width ones where the pitch is not line-aligned
-        const bool side_stream = crop_stream_ok && (ctx->resize_mode == 5 || w != 1024);
-        const bool rows_stream = crop_stream_ok && (ctx->resize_mode == 5 || w % 128 != 0);
-        if (side_clips.empty() && row_mh) {  // every box is full-width: one ROWCROP launch
-            if (build_rows(rows_clips, &rc)) {
-                if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
-                if ((rc = launch_rows(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
-                return finish();
-            }
-            if (rc) return rc;
-        } else if (!side_clips.empty() && !rows_clips.empty() && row_mh && side_stream) {  // mixed: each shape to its kernel
-            if (build_rows(rows_clips, &rc) && build_stream(side_clips, &rc)) {
-                if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = upload_desc(ssc, sst, ctx->crop_desc2, ctx->crop_tables2)) ||
-                    (rc = uploads_done()))
-                    return rc;
-                if ((rc = launch_rows(rows_clips.size(), ctx->crop_desc, ctx->crop_tables))) return rc;
-                if ((rc = launch_stream(side_clips.size(), ctx->crop_desc2, ctx->crop_tables2))) return rc;
-                return finish();
-            }
-            if (rc) return rc;
-        }
-        if (side_clips.empty() ? rows_stream : side_stream) {  // the whole call through the cropped stream kernel
-            std::vector<uint32_t> all(n_clips);
-            for (size_t c = 0; c < n_clips; c++) all[c] = (uint32_t)c;
-            need_shift = (w & 3u) != 0;
-            if (build_stream(all, &rc)) {
-                if ((rc = upload_desc(ssc, sst, ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
-                if ((rc = launch_stream(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
-                return finish();
-            }
-            if (rc) return rc;
-        }
-    }
     // -- the whole-line cropped kernel, over `ids` (all clips, or the side-bar boxes of a mixed call whose full-width boxes stream)
     std::vector<vdf::CropClipDesc> desc;
     std::vector<vdf::CropTableEntry> entries;
@@ -823,22 +803,69 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         if (rc == VDF_OK) rc = upload(ctx, bt, entries.data(), entries.size() * sizeof(vdf::CropTableEntry), stream);
         return rc;
     };
+    // ---- the plan: who goes where
     int rc = VDF_OK;
-    if (!side_clips.empty() && !rows_clips.empty() && row_mh && build_rows(rows_clips, &rc)) {
-        // mixed call whose side-bar boxes cannot take the stream form (frames wider than its classes: 4K): full-width boxes still stream
-        if (!build_lines(side_clips, &rc)) return rc ? rc : fail(ctx, VDF_E_BAD_DIMS, "crop box");
-        if ((rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables)) || (rc = upload_lines(ctx->crop_desc2, ctx->crop_tables2)) || (rc = uploads_done()))
-            return rc;
-        if ((rc = launch_rows(rows_clips.size(), ctx->crop_desc, ctx->crop_tables))) return rc;
-        if ((rc = launch_lines(side_clips.size(), ctx->crop_desc2, ctx->crop_tables2))) return rc;
-        return finish();
+    std::vector<uint32_t> rows_part, rest;
+    (row_mh ? rows_part : rest) = rows_clips;
+    std::vector<BoxGroup> boxes;
+    if (ctx->resize_mode == 0 && tall && ends16 && (((uintptr_t)d_frames | frame_stride | clip_stride) & 15) == 0 && !side_clips.empty() &&
+        !std::getenv("VDF_NO_BOXSTREAM") && !std::getenv("VDF_NO_ROWCROP")) {
+        std::map<uint64_t, size_t> by_range;  // (x0, width) -> group
+        std::vector<BoxGroup> cand;
+        for (uint32_t c : side_clips) {
+            const uint32_t l = crops[4 * c], bw = w - l - crops[4 * c + 1];
+            auto it = by_range.find(((uint64_t)l << 32) | bw);
+            if (it == by_range.end()) {
+                it = by_range.emplace(((uint64_t)l << 32) | bw, cand.size()).first;
+                cand.push_back(BoxGroup{l, bw, {}, nullptr, 0});
+            }
+            cand[it->second].ids.push_back(c);
+        }
+        for (BoxGroup &g : cand) {
+            const int nw = vdf::resize_wavestream_waves_box(w, g.x0, g.bw);
+            if (nw && boxes.size() < 16) {  // (a launch per range: a batch with more distinct ranges than that leaves the rest to the gather kernel)
+                g.mh = mfma_table(ctx, g.bw, vdf::kMfmaLayoutHorizontalBand, stream, &rc);
+                if (rc) return rc;
+                if (g.mh->host.ok && vdf::resize_wavestream_table_fits(nw, g.mh->host.band_stride)) { boxes.push_back(std::move(g)); continue; }
+            }
+            rest.insert(rest.end(), g.ids.begin(), g.ids.end());
+        }
+    } else {
+        rest.insert(rest.end(), side_clips.begin(), side_clips.end());
     }
-    if (rc) return rc;
-    std::vector<uint32_t> all(n_clips);
-    for (size_t c = 0; c < n_clips; c++) all[c] = (uint32_t)c;
-    if (!build_lines(all, &rc)) return rc ? rc : fail(ctx, VDF_E_BAD_DIMS, "crop box");
-    if ((rc = upload_lines(ctx->crop_desc, ctx->crop_tables)) || (rc = uploads_done())) return rc;
-    if ((rc = launch_lines(n_clips, ctx->crop_desc, ctx->crop_tables))) return rc;
+    bool planned = !rows_part.empty() || !boxes.empty();
+    if (planned) {
+        planned = append_rows(rows_part, &rc);
+        for (BoxGroup &g : boxes) {
+            g.first = rsc.size();
+            planned = planned && append_rows(g.ids, &rc);
+        }
+        if (rc) return rc;
+    }
+    if (!planned) {  // nothing streams per clip: the whole call through one general kernel
+        rest.resize(n_clips);
+        for (size_t c = 0; c < n_clips; c++) rest[c] = (uint32_t)c;
+        rows_part.clear();
+        boxes.clear();
+    }
+    // the general kernel for the rest: the cropped stream kernel for side-bar boxes at every pitch but 1024 and for full-width boxes where the
+    // pitch is not line-aligned (measured above), else the whole-line kernel
+    bool rest_stream = false;
+    if (!rest.empty()) {
+        bool rest_has_side = false;
+        for (uint32_t c : rest) rest_has_side = rest_has_side || crops[4 * c] != 0 || crops[4 * c + 1] != 0;
+        if (crop_stream_ok && (ctx->resize_mode == 5 || (rest_has_side ? w != 1024 : w % 128 != 0))) rest_stream = build_stream(rest, &rc);
+        if (rc) return rc;
+        if (!rest_stream && !build_lines(rest, &rc)) return rc ? rc : fail(ctx, VDF_E_BAD_DIMS, "crop box");
+    }
+    if (planned && (rc = upload_desc(rsc, rst, ctx->crop_desc, ctx->crop_tables))) return rc;
+    if (!rest.empty() && (rc = rest_stream ? upload_desc(ssc, sst, ctx->crop_desc2, ctx->crop_tables2) : upload_lines(ctx->crop_desc2, ctx->crop_tables2))) return rc;
+    if ((rc = uploads_done())) return rc;
+    if (!rows_part.empty() && (rc = launch_rows(0, rows_part.size(), ctx->crop_desc, ctx->crop_tables))) return rc;
+    for (const BoxGroup &g : boxes)
+        if ((rc = launch_box(g, ctx->crop_desc, ctx->crop_tables))) return rc;
+    if (!rest.empty() && (rc = rest_stream ? launch_stream(rest.size(), ctx->crop_desc2, ctx->crop_tables2) : launch_lines(rest.size(), ctx->crop_desc2, ctx->crop_tables2)))
+        return rc;
     return finish();
 }
 

@@ -1021,7 +1021,9 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
 // MODE as in the kernel above: 0 = rows at the frame's own pitch (W % 16 == 0), 1 / 2 = rows re-pitched by the DMA to Wp (an odd
 // multiple of 16 bytes; 2 = row starts that are not dword-aligned: one more dword per operand read and a per-lane byte shift).
 // ROWCROP: per-clip row ranges (see row_geo_of): the box's first row, block count and vertical table change from clip to clip; a wave
-// without a block in a short box still issues its first block of the next frame.
+// without a block in a short box still issues its first block of the next frame.  A launch may also cover boxes with side bars that
+// share their column range (x0, width): W stays the FRAME's pitch (every global address is in frame coordinates), x0 shifts the rows'
+// first byte, and the box's width is in the band table and in Wp (MODE 1 / 2: the DMA gathers the box's bytes of each row).
 // NW waves per workgroup, each with its own block buffer: four for the widest frames (30 KB blocks), more for narrower ones, so that the
 // blocks in flight per CU stay near 120 KB whatever the width.
 template <int NW, int BUF_BYTES, int TAB_BYTES, int MODE, bool ROWCROP = false>
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
                                                                            size_t clip_stride, uint32_t n_frames,
                                                                            MfmaResizeTables T, uint32_t Wp, uint8_t *__restrict__ small,
                                                                            const CropStreamClip *__restrict__ clips_g = nullptr,
-                                                                           const CropStreamTable *__restrict__ tables_g = nullptr)
+                                                                           const CropStreamTable *__restrict__ tables_g = nullptr, uint32_t x0 = 0)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tab[TAB_BYTES / 16];
     __shared__ __attribute__((aligned(16))) uint4 s_pxw[NW][BUF_BYTES / 16];
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
     auto issue_dma = [&](uint32_t F, uint32_t b, const RowGeo &q) __attribute__((always_inline)) {
         const uint8_t *src = frames + (size_t)(ROWCROP ? q.src : F >> 4) * clip_stride + (size_t)(F & 15u) * frame_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, frame_bytes, 0x00020000);
-        const uint32_t start = (q.y0 + 16u * b) * W, bytes = min(16u, q.h - 16u * b) * Wp;
+        const uint32_t start = (q.y0 + 16u * b) * W + (ROWCROP ? x0 : 0u), bytes = min(16u, q.h - 16u * b) * Wp;
         uint32_t x = lane_x0, ro = lane_ro0;
         for (uint32_t off = 0; off < bytes; off += 1024u) {
             auto *lds = (__attribute__((address_space(3))) void *)&my[off >> 4];
@@ -1108,7 +1110,7 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
 #pragma unroll
                 for (int r = 0; r < 4; r++) bias_v[r] = geo.bias_v[4 * g + r];
             }
-            if constexpr (MODE == 2) shift = (geo.y0 * W + r16 * W) & 3u;
+            if constexpr (MODE == 2) shift = (geo.y0 * W + x0 + r16 * W) & 3u;
         }
         for (uint32_t b = wave; b < n_blk; b += NW) {
             // vertical fragments of this block's 64-row group (global loads: issued before the wait, consumed after the products)
@@ -1202,17 +1204,16 @@ static void launch_stream_mode(uint32_t grid, hipStream_t stream, const uint8_t 
 #undef VDF_CS_LAUNCH
 }
 
-// per-wave block streams: NW by the width (resize_wavestream_waves), MODE by the pitch, ROWCROP when clips carry row ranges
+// per-wave block streams: NW by the (box) width (resize_wavestream_waves), MODE by the pitch and the box's first column, ROWCROP when clips
+// carry row ranges
 template <int NW, int BUF, int TAB>
 static void launch_wavestream_nw(uint32_t grid, hipStream_t stream, const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride,
                                  size_t clip_stride, uint32_t n_frames, const MfmaResizeTables &T, uint8_t *small,
-                                 const CropStreamClip *clips, const CropStreamTable *tables)
+                                 const CropStreamClip *clips, const CropStreamTable *tables, uint32_t wp, int mode, uint32_t x0)
 {
-    const uint32_t wp = stream_pitch(w);
-    const int mode = wp == w ? 0 : w % 4 == 0 ? 1 : 2;
 #define VDF_WS_LAUNCH(M, RC)                                                                                                              \
     hipLaunchKernelGGL((resize_mfma_frame_wavestream_kernel<NW, BUF, TAB, M, RC>), dim3(grid), dim3(64 * NW), 0, stream, frames, w, h, \
-                       frame_stride, clip_stride, n_frames, T, wp, small, clips, tables)
+                       frame_stride, clip_stride, n_frames, T, wp, small, clips, tables, x0)
     if (clips) {
         if (mode == 0) VDF_WS_LAUNCH(0, true);
         else if (mode == 1) VDF_WS_LAUNCH(1, true);
@@ -1225,25 +1226,37 @@ static void launch_wavestream_nw(uint32_t grid, hipStream_t stream, const uint8_
 #undef VDF_WS_LAUNCH
 }
 
+// w = the frames' pitch; box_w / x0 = the column range every clip of the launch keeps (box_w == w, x0 == 0: whole rows)
 static hipError_t launch_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                                     const MfmaResizeArgs &a, const CropStreamClip *clips, const CropStreamTable *tables, uint8_t *small,
-                                    hipStream_t stream)
+                                    hipStream_t stream, uint32_t box_w, uint32_t x0)
 {
-    const int nw = resize_wavestream_waves(w);
-    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || nw == 0) return hipErrorInvalidValue;
-    const int tab_bytes = 16 * a.band_stride + 128;  // + the zero slot
-    if (tab_bytes > (nw <= 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall)) return hipErrorInvalidValue;
+    const int nw = resize_wavestream_waves_box(w, x0, box_w);
+    if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || nw == 0 || (box_w != w && !clips) || (uint64_t)x0 + box_w > w)
+        return hipErrorInvalidValue;
+    if (!resize_wavestream_table_fits(nw, a.band_stride)) return hipErrorInvalidValue;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16), grid = std::min<uint32_t>(n_frames, (uint32_t)cus);
     const MfmaResizeTables T = make_tables(a);
-    if (nw == 3) launch_wavestream_nw<3, kWaveStreamBuf3, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
-    else if (nw == 4) launch_wavestream_nw<4, kWaveStreamBuf, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
-    else if (nw == 5) launch_wavestream_nw<5, kWaveStreamBuf5, kWaveStreamTabMid>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
-    else if (nw == 6) launch_wavestream_nw<6, kWaveStreamBuf6, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
-    else launch_wavestream_nw<8, kWaveStreamBuf8, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables);
+    int mode = 0;
+    const uint32_t wp = box_stream_pitch(w, x0, box_w, &mode);
+    if (nw == 3) launch_wavestream_nw<3, kWaveStreamBuf3, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables, wp, mode, x0);
+    else if (nw == 4) launch_wavestream_nw<4, kWaveStreamBuf, kWaveStreamTabBytes>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables, wp, mode, x0);
+    else if (nw == 5) launch_wavestream_nw<5, kWaveStreamBuf5, kWaveStreamTabMid>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables, wp, mode, x0);
+    else if (nw == 6) launch_wavestream_nw<6, kWaveStreamBuf6, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables, wp, mode, x0);
+    else launch_wavestream_nw<8, kWaveStreamBuf8, kWaveStreamTabSmall>(grid, stream, frames, w, h, frame_stride, clip_stride, n_frames, T, small, clips, tables, wp, mode, x0);
     return hipGetLastError();
+}
+
+hipError_t launch_resize_mfma_box_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                             size_t clip_stride, const MfmaResizeArgs &a, uint32_t x0, uint32_t box_w, const CropStreamClip *clips,
+                                             const CropStreamTable *tables, uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    if (!clips || !tables) return hipErrorInvalidValue;
+    return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream, box_w, x0);
 }
 
 hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,
@@ -1261,7 +1274,7 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
     if (resize_stream_wants_band(w) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
     if (resize_wavestream_applies(w))
-        return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream);
+        return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream, w, 0);
     if (cls != 1 || a.band_meta) return hipErrorInvalidValue;  // the chunk form serves the S class only (frames up to 512 wide, two workgroups per CU)
     launch_stream_mode(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a),
                        nb, small, clips, tables);

@@ -63,6 +63,41 @@ int resize_wavestream_waves(uint32_t w)
     return 0;
 }
 
+uint32_t box_stream_pitch(uint32_t frame_w, uint32_t x0, uint32_t box_w, int *mode)
+{
+    if (x0 == 0 && box_w == frame_w) {  // whole rows
+        const uint32_t wp = stream_pitch(frame_w);
+        *mode = wp == frame_w ? 0 : frame_w % 4 == 0 ? 1 : 2;
+        return wp;
+    }
+    // a box: gathered row by row.  Rows of the box start at (row * frame_w + x0): off a dword unless both are multiples of 4, and then
+    // the LDS row holds the up to 3 bytes in front of the box's first pixel too (MODE 2 shifts them out of the operands)
+    const bool shifted = frame_w % 4 != 0 || x0 % 4 != 0;
+    *mode = shifted ? 2 : 1;
+    uint32_t wp = (box_w + (shifted ? 3u : 0u) + 15u) & ~15u;
+    if ((wp / 16) % 2 == 0) wp += 16;  // an odd multiple of 16 bytes: the 16 rows of a block in 16 different bank groups
+    return wp;
+}
+
+int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w)
+{
+    if (x0 == 0 && box_w == frame_w) return resize_wavestream_waves(frame_w);
+    if (std::getenv("VDF_NO_WAVESTREAM") || box_w < 513) return 0;  // narrower boxes: the gather kernel with two workgroups per CU
+    int mode = 0;
+    const uint32_t need = ((16u * box_stream_pitch(frame_w, x0, box_w, &mode) + 1023u) & ~1023u) + 128u;
+    for (int nw : {8, 6, 5, 4, 3}) {
+        const int buf = nw == 3 ? kWaveStreamBuf3 : nw == 4 ? kWaveStreamBuf : nw == 5 ? kWaveStreamBuf5 : nw == 6 ? kWaveStreamBuf6 : kWaveStreamBuf8;
+        if (need <= (uint32_t)buf) return nw;
+    }
+    return 0;
+}
+
+bool resize_wavestream_table_fits(int nw, int band_stride)
+{
+    const int tab_bytes = 16 * band_stride + 128;  // + the zero slot
+    return tab_bytes <= (nw <= 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall);
+}
+
 bool resize_stream_wants_band(uint32_t w) { return resize_wavestream_waves(w) != 0; }
 
 bool resize_wavestream_applies(uint32_t w) { return resize_wavestream_waves(w) != 0; }

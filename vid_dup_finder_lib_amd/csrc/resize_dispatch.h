@@ -53,6 +53,11 @@ bool resize_stream_wants_band(uint32_t w);  // the width's kernel takes a.bh in 
 // VDF_WAVESTREAM_NW=n forces n waves where the block fits the n-wave buffer, VDF_NO_WAVESTREAM=1 switches the form off (measurements).
 int resize_wavestream_waves(uint32_t w);
 bool resize_wavestream_applies(uint32_t w);
+// a launch over crop boxes that share their column range (x0, box_w) of frames frame_w wide: LDS row pitch and addressing mode (0 linear
+// copy of whole rows, 1 gather, 2 gather + the operand shift for rows that start off a dword), and the wave count (0: not this kernel)
+uint32_t box_stream_pitch(uint32_t frame_w, uint32_t x0, uint32_t box_w, int *mode);
+int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w);
+bool resize_wavestream_table_fits(int nw, int band_stride);  // does a band table of that stride (bytes per output) fit the nw-wave kernel's table array
 // Clips whose crop boxes are full-width (top / bottom bars only): do the ROWCROP instantiations of the stream kernels beat the general
 // cropped kernels at this frame width?  (measured; the frame must also pass resize_stream_eligible / resize_ksplit_eligible)
 bool resize_rowcrop_streams(uint32_t w);

@@ -157,6 +157,11 @@ hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_cli
                                              size_t frame_stride, size_t clip_stride, const CropStreamClip *clips,
                                              const CropStreamTable *tables, int cls, bool shift, uint8_t *small,
                                              hipStream_t stream);  // shift: some row of some box starts off a dword boundary
+// crop boxes that share their column range (x0, box_w; e.g. the 4 : 3 picture of every pillarboxed clip in a 16 : 9 batch): the per-wave
+// stream kernel gathers the box's bytes of each row; a = the band table of box_w; per-clip rows as in the ROWCROP launches
+hipError_t launch_resize_mfma_box_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                             size_t clip_stride, const MfmaResizeArgs &a, uint32_t x0, uint32_t box_w, const CropStreamClip *clips,
+                                             const CropStreamTable *tables, uint8_t *small, hipStream_t stream);
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
                             size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
