@@ -251,7 +251,7 @@ def test_top_bottom_bars_take_the_stream_kernels(engine, monkeypatch, h, w):
 
 @pytest.mark.parametrize("h,w", [(120, 200), (64, 17), (70, 33), (300, 64), (1080, 1920), (131, 250)])
 def test_side_bars_walk_in_batches_of_columns(engine, h, w):
-    """Pillarboxed clips: from the second column strip on the device judges a batch of strips at a time (column_strips: eight).  Bars of 1, 15,
+    """Pillarboxed clips: from the second column strip on the device judges a batch of strips at a time (column_strips: sixteen).  Bars of 1, 15,
     16, 17, 18, 32, 33 ... columns on either side, strips that fail in the middle of a batch (just over 10 % outliers, values just outside
     +-16 of the mode, a tie between two modes), noisy bars, frames narrower than a batch, a uniform frame (every strip passes, the edges
     converge): the same crops as the oracle's strip-by-strip take_while."""

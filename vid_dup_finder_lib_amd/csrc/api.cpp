@@ -891,8 +891,9 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     }
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
+    VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(n_clips, frames_per_clip)));
     VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
-                                       ctx->crops.as<uint32_t>(), stream));
+                                       ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream));
     std::vector<uint32_t> crops(n_clips * 4);
     VDF_HIP(ctx, hipMemcpyAsync(crops.data(), ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
@@ -1326,9 +1327,10 @@ int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_
     if (n_clips == 0) return VDF_OK;
     if (!d_frames || !d_crops) return fail(ctx, VDF_E_INVAL, "null pointer");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(std::min(kMaxClipsPerLaunch, n_clips), frames_per_clip)));
     for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch)
         VDF_HIP(ctx, vdf::launch_letterbox(d_frames + c0 * clip_stride, std::min(kMaxClipsPerLaunch, n_clips - c0),
-                                           frames_per_clip, w, h, frame_stride, clip_stride, d_crops + 4 * c0,
+                                           frames_per_clip, w, h, frame_stride, clip_stride, d_crops + 4 * c0, ctx->crop_work.as<uint32_t>(),
                                            stream ? (hipStream_t)stream : ctx->stream));
     return VDF_OK;
 }

@@ -8,6 +8,8 @@
 // first strip that is not letterbox, exactly like the reference's take_while.  A strip is letterbox when more
 // than 90 % of its pixels are within +-tol of the strip's mode (ties: the LAST maximum, Iterator::max_by_key).
 // Integer histogram per strip in LDS, one f64 compare: bit-exact with the oracle.
+#include <algorithm>
+
 #include "vdf_internal.h"
 
 namespace vdf {
@@ -228,17 +230,19 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
     return ok == ALL ? (uint32_t)NC : (uint32_t)__builtin_ctz(~ok);
 }
 
-#ifndef VDF_LETTERBOX_NC
-#define VDF_LETTERBOX_NC 8
-#endif
-constexpr int kColumnBatch = VDF_LETTERBOX_NC;
 
+// Pass 1: one workgroup per probed frame.  Waves 2 / 3 walk in from the top / bottom; waves 0 / 1 judge only the FIRST column strip of their
+// side.  Most frames have no side bars and are finished here (4 KB of LDS, the launch rate of 40 000 small workgroups matters at 64 x 64).
+// A frame whose left or right first strip IS letterbox goes on the work list of pass 2 with its top / bottom result.
+// work: 64 sub-lists (one shared counter took 40 000 same-address atomics 0.6 ms when every 64 x 64 clip of a batch had side bars): counts[64],
+// then 64 x cap entries {frame index (clip * n_probe + probe), top, bottom, left | right << 1 first-strip flags}; frame i appends to sub-list
+// i % 64, so cap = ceil(frames / 64) entries always suffice.
+constexpr uint32_t kWorkLists = 64;
 __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
                                                         size_t frame_stride, size_t clip_stride, uint32_t n_probe,
-                                                        uint32_t tol, uint32_t *__restrict__ crops)
+                                                        uint32_t tol, uint32_t *__restrict__ crops, uint32_t *__restrict__ work)
 {
     __shared__ uint32_t s_hist[4][256];
-    __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256];  // the column walkers' batches of strips
     __shared__ uint32_t s_edge[4];
     __shared__ uint32_t s_prog[4];  // strips each walker has confirmed so far
     const size_t clip = blockIdx.x / n_probe;
@@ -250,24 +254,76 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restric
     __syncthreads();
     // A frame whose opposite walkers meet (a fade-in: uniformly black, every strip of every edge is letterbox) means "no crop" whatever the
     // other edges find (video_frames_gray.rs:119-127), and each walker alone would go through the whole frame first - 1.5 ms for ONE
-    // such 1080p frame in a batch whose other thousand clips take 0.1 ms.  The walkers publish their progress; once left + right
-    // reach W or top + bottom reach H the result is fixed and everybody stops.  (The counts only grow, so a partial sum that
-    // reaches the extent implies the final one does.)
+    // such 1080p frame in a batch whose other thousand clips take 0.1 ms.  The walkers publish their progress; once top + bottom
+    // reach H the result is fixed and they stop.  (The counts only grow, so a partial sum that reaches the extent implies the final one does.)
     auto publish = [&](uint32_t n) {
         if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
     };
     auto converged = [&]() {
-        const uint32_t l = __atomic_load_n(&s_prog[0], __ATOMIC_RELAXED), r = __atomic_load_n(&s_prog[1], __ATOMIC_RELAXED);
         const uint32_t t = __atomic_load_n(&s_prog[2], __ATOMIC_RELAXED), b = __atomic_load_n(&s_prog[3], __ATOMIC_RELAXED);
-        return __builtin_amdgcn_readfirstlane((int)((uint64_t)l + r >= W || (uint64_t)t + b >= H)) != 0;
+        return __builtin_amdgcn_readfirstlane((int)((uint64_t)t + b >= H)) != 0;
     };
     uint32_t n = 0;
-    if (wave < 2) {
-        // the first strip alone (most clips have no side bars and stop here), then a batch at a time while a whole batch is inside the frame
-        const bool right = wave == 1;
-        if (strip_is_letterbox(right ? f + (W - 1) : f, W, H, tol, hist)) {
-            n = 1;
-            publish(n);
+    if (wave == 0) {
+        n = strip_is_letterbox(f, W, H, tol, hist) ? 1u : 0u;
+    } else if (wave == 1) {
+        n = strip_is_letterbox(f + (W - 1), W, H, tol, hist) ? 1u : 0u;
+    } else if (wave == 2) {
+        while (n < H && !converged() && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) publish(++n);
+    } else {
+        while (n < H && !converged() && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) publish(++n);
+    }
+    if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
+    __syncthreads();
+    const uint32_t l = s_edge[0], r = s_edge[1], t = s_edge[2], b = s_edge[3];
+    // side bars to walk (and the frame is not already decided: top + bottom met, or a frame of one or two columns that the first strips cover)
+    const bool deferred = (l | r) != 0 && (uint64_t)t + b < H && (uint64_t)l + r < W;
+    if (deferred) {
+        if (threadIdx.x == 0) {
+            const uint32_t k = blockIdx.x % kWorkLists, cap = (gridDim.x + kWorkLists - 1) / kWorkLists;
+            const uint32_t at = atomicAdd(&work[k], 1u);
+            uint32_t *e = work + kWorkLists + 4 * ((size_t)k * cap + at);
+            e[0] = blockIdx.x; e[1] = t; e[2] = b; e[3] = l | (r << 1);
+        }
+    } else if (threadIdx.x < 4) {
+        // video_frames_gray.rs:119-127: converging edges (e.g. a uniform frame) mean "no crop"
+        const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
+        atomicMin(&crops[clip * 4 + threadIdx.x], ok ? s_edge[threadIdx.x] : 0u);  // union = per-edge minimum
+    }
+}
+
+// Pass 2: the frames with side bars.  Persistent workgroups of two waves (left / right walker) take entries off the work list and walk
+// kColumnBatch column strips per pass; the walkers of a frame stop when left + right reach W.  Then the frame's four edges are final.
+template <int kColumnBatch>
+__global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
+                                                              size_t frame_stride, size_t clip_stride, uint32_t n_probe,
+                                                              uint32_t tol, uint32_t *__restrict__ crops, const uint32_t *__restrict__ work,
+                                                              uint32_t n_frames)
+{
+    __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256];  // batches of strips, or one strip in the first KB
+    __shared__ uint32_t s_edge[2];
+    __shared__ uint32_t s_prog[2];
+    // workgroup b serves sub-list b % 64 from entry b / 64 in steps of gridDim.x / 64 (the grid is a multiple of 64)
+    const uint32_t wave = threadIdx.x >> 6, list = blockIdx.x % kWorkLists, cap = (n_frames + kWorkLists - 1) / kWorkLists;
+    const uint32_t n_work = work[list];
+    const bool right = wave == 1;
+    uint32_t *hist = s_histn[wave];
+    for (uint32_t at = blockIdx.x / kWorkLists; at < n_work; at += gridDim.x / kWorkLists) {
+        const uint32_t *e = work + kWorkLists + 4 * ((size_t)list * cap + at);
+        const uint32_t frame = e[0], t = e[1], b = e[2], first = (e[3] >> wave) & 1u;
+        const size_t clip = frame / n_probe;
+        const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * (frame % n_probe)) * frame_stride;
+        if (threadIdx.x < 2) s_prog[threadIdx.x] = (e[3] >> threadIdx.x) & 1u;
+        __syncthreads();
+        auto publish = [&](uint32_t n) {
+            if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
+        };
+        auto converged = [&]() {
+            const uint32_t l = __atomic_load_n(&s_prog[0], __ATOMIC_RELAXED), r = __atomic_load_n(&s_prog[1], __ATOMIC_RELAXED);
+            return __builtin_amdgcn_readfirstlane((int)((uint64_t)l + r >= W)) != 0;
+        };
+        uint32_t n = first;
+        if (first) {
             bool walking = true;
             while (walking && n + kColumnBatch <= W && H < 65536u && !converged()) {
                 const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
@@ -278,31 +334,54 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restric
             if (walking)
                 while (n < W && !converged() && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) publish(++n);
         }
-    } else if (wave == 2) {
-        while (n < H && !converged() && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) publish(++n);
-    } else {
-        while (n < H && !converged() && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) publish(++n);
-    }
-    if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const uint32_t l = s_edge[0], r = s_edge[1], t = s_edge[2], b = s_edge[3];
-        // video_frames_gray.rs:119-127: converging edges (e.g. a uniform frame) mean "no crop"
-        const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
-        atomicMin(&crops[clip * 4 + threadIdx.x], ok ? s_edge[threadIdx.x] : 0u);  // union = per-edge minimum
+        if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const uint32_t l = s_edge[0], r = s_edge[1];
+            const uint32_t edge[4] = {l, r, t, b};
+            const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
+            atomicMin(&crops[clip * 4 + threadIdx.x], ok ? edge[threadIdx.x] : 0u);
+        }
+        __syncthreads();  // s_edge / s_prog are rewritten for the next entry
     }
 }
 
+size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip)
+{
+    const uint32_t nf = frames_per_clip < VDF_DCT_SIZE ? frames_per_clip : VDF_DCT_SIZE;
+    const size_t frames = n_clips * ((nf + 7) / 8), cap = (frames + kWorkLists - 1) / kWorkLists;
+    return (kWorkLists + 4 * kWorkLists * cap) * sizeof(uint32_t);
+}
+
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
-                            size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream)
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
     const uint32_t nf = frames_per_clip < VDF_DCT_SIZE ? frames_per_clip : VDF_DCT_SIZE;  // the builder keeps 16 frames
     const uint32_t n_probe = (nf + 7) / 8;                                                // frames 0, 8
     hipError_t e = hipMemsetAsync(crops, 0xFF, n_clips * 4 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(work, 0, kWorkLists * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(letterbox_kernel, dim3((uint32_t)(n_clips * n_probe)), dim3(256), 0, stream, frames, w, h,
-                       frame_stride, clip_stride, n_probe, 16u, crops);
+                       frame_stride, clip_stride, n_probe, 16u, crops, work);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // Sixteen strips per pass (16 KB of LDS per workgroup, nine per CU); small frames, where a strip is a handful of loads and the
+    // fixed work per pass (clearing and scanning the histograms) dominates, take eight (twice the workgroups per CU: 64 x 64 x 20 000 clips
+    // with side bars 0.86 -> 0.45 ms).  An empty work list costs one pass of trivial workgroups.
+    const uint32_t n_frames = (uint32_t)(n_clips * n_probe);
+    auto grid_for = [&](uint32_t per_cu) {  // a multiple of 64 (the sub-lists), no more than the frames can fill
+        const size_t want = std::min<size_t>(n_frames, (size_t)cus * per_cu);
+        return (uint32_t)((want + kWorkLists - 1) / kWorkLists * kWorkLists);
+    };
+    if (h >= 256)
+        hipLaunchKernelGGL(letterbox_sides_kernel<16>, dim3(grid_for(9)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+                           work, n_frames);
+    else
+        hipLaunchKernelGGL(letterbox_sides_kernel<8>, dim3(grid_for(16)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+                           work, n_frames);
     return hipGetLastError();
 }
 

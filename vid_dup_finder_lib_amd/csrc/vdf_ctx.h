@@ -104,7 +104,7 @@ struct vdf_ctx {
     DevBuf hits2, hit_bitmaps;  // replay filter: surviving hits, has-incoming / covered bitmaps
     DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side Search::sort
     // hash scratch
-    DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables, crop_desc2, crop_tables2;
+    DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables, crop_desc2, crop_tables2, crop_work;
     PinBuf pin[2], pin_out[2];
     PinBuf pin_ctrl;   // search: the counters of a launch (pageable destinations make hipMemcpyAsync synchronous)
     const void *pinned_db = nullptr;  // vdf_ctx_pin_database: the caller promises these n x 16 words do not change until unpinned

@@ -162,8 +162,10 @@ hipError_t launch_resize_mfma_cropped_stream(const uint8_t *frames, size_t n_cli
 hipError_t launch_resize_mfma_box_wavestream(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                              size_t clip_stride, const MfmaResizeArgs &a, uint32_t x0, uint32_t box_w, const CropStreamClip *clips,
                                              const CropStreamTable *tables, uint8_t *small, hipStream_t stream);
+// work: scratch of letterbox_work_bytes(n_clips, frames_per_clip) bytes (the list of frames whose side bars a second pass walks)
+size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip);
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
-                            size_t frame_stride, size_t clip_stride, uint32_t *crops, hipStream_t stream);
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);
