@@ -143,6 +143,96 @@ __device__ __forceinline__ bool strip_is_letterbox(const uint8_t *__restrict__ p
     return more_than_nine_tenths(count, len);
 }
 
+// Four row strips per pass (top / bottom walkers).  A row strip's wall time is not its loads any more but the dependent chain behind them
+// (clear, LDS atomics, read back, two wave reductions, ~1.3 us) - and a bar is a hundred rows deep.  Four rows go through that chain
+// together: sixteen lanes own a row's 256 bins (DPP reductions stay inside the 16-lane row), one ballot gives the four verdicts, judged in
+// walking order (the reference's take_while, evaluated speculatively).  hist4: 4 x 256 words.  row(k) = address of strip k of the batch.
+// Returns how many leading strips of the batch are letterbox (0 .. 4).  All 64 lanes must call.
+template <class RowAt>
+__device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_t tol, uint32_t *hist4)
+{
+    const uint32_t lane = threadIdx.x & 63, n16 = len >> 4;
+#pragma unroll
+    for (int k = 0; k < 16; k++) hist4[lane + 64 * k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
+    for (uint32_t i0 = 0; i0 < n16; i0 += 128) {  // two 16-byte loads per lane and row in flight, four rows
+        U4 v[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t i = i0 + 64u * k + lane;
+                v[r][k] = i < n16 ? *reinterpret_cast<const U4 *>(row(r) + 16 * (size_t)i) : U4{0, 0, 0, 0};
+            }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t *hist = hist4 + 256 * r;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool active = i0 + 64u * k + lane < n16;
+                const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+                if (act == 0) break;  // wave-uniform
+                const U4 &q = v[r][k];
+                const uint32_t first = __builtin_amdgcn_readfirstlane(q.x);
+                const bool same16 = q.x == (q.x & 255u) * 0x01010101u && q.y == q.x && q.z == q.x && q.w == q.x;
+                if (__builtin_amdgcn_ballot_w64(active && same16 && q.x == first) == act) {
+                    if (lane == 0) atomicAdd(&hist[first & 255u], 16u * (uint32_t)__builtin_popcountll(act));
+                } else if (active) {
+                    if (same16) {
+                        atomicAdd(&hist[q.x & 255u], 16u);
+                    } else {
+                        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (d[j] == (d[j] & 255u) * 0x01010101u) {
+                                atomicAdd(&hist[d[j] & 255u], 4u);
+                            } else {
+                                atomicAdd(&hist[d[j] & 255u], 1u);
+                                atomicAdd(&hist[(d[j] >> 8) & 255u], 1u);
+                                atomicAdd(&hist[(d[j] >> 16) & 255u], 1u);
+                                atomicAdd(&hist[d[j] >> 24], 1u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (uint32_t i = 16 * n16 + lane; i < len; i += 64) atomicAdd(&hist4[256 * r + row(r)[i]], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane = 16 r + q: bins 16 q .. 16 q + 15 of row r
+    const uint32_t r = lane >> 4, q = lane & 15;
+    const uint32_t *hr = hist4 + 256 * r + 16 * q;
+    uint32_t key = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) key = max(key, (hr[b] << 8) | (16u * q + b));  // max count, ties -> the larger value
+    key = max(key, row_ror<8>(key));
+    key = max(key, row_ror<4>(key));
+    key = max(key, row_ror<2>(key));
+    key = max(key, row_ror<1>(key));
+    const uint32_t mode = key & 255u, lo = mode > tol ? mode - tol : 0u, hi = min(mode + tol, 255u);
+    uint32_t count = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) {
+        const uint32_t val = 16u * q + b;
+        if (val >= lo && val <= hi) count += hr[b];
+    }
+    count += row_ror<8>(count);
+    count += row_ror<4>(count);
+    count += row_ror<2>(count);
+    count += row_ror<1>(count);
+    const uint64_t okm = __builtin_amdgcn_ballot_w64(more_than_nine_tenths(count, len));
+    __builtin_amdgcn_wave_barrier();
+    uint32_t got = 0;
+    while (got < 4 && ((okm >> (16 * got)) & 1ull)) got++;
+    return got;
+}
+
 // NC (8 or 16) adjacent column strips at once (pillarboxed clips: 4 : 3 content in a 16 : 9 frame walks 240 columns in from each side of
 // a 1080p frame).  One column strip is H single bytes, each in its own cache line: strip by strip the walk fetched every line of the
 // frame's side NC times over and was bound by the address coalescer (18 ms to probe 1000 pillarboxed 1080p clips).  Here a lane reads
@@ -238,11 +328,12 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 // then 64 x cap entries {frame index (clip * n_probe + probe), top, bottom, left | right << 1 first-strip flags}; frame i appends to sub-list
 // i % 64, so cap = ceil(frames / 64) entries always suffice.
 constexpr uint32_t kWorkLists = 64;
-__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
+__global__ __launch_bounds__(256, 8) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
                                                         size_t frame_stride, size_t clip_stride, uint32_t n_probe,
                                                         uint32_t tol, uint32_t *__restrict__ crops, uint32_t *__restrict__ work)
 {
     __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_hist4[2][4 * 256];  // the row walkers' four-strip batches
     __shared__ uint32_t s_edge[4];
     __shared__ uint32_t s_prog[4];  // strips each walker has confirmed so far
     const size_t clip = blockIdx.x / n_probe;
@@ -268,10 +359,25 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t *__restric
         n = strip_is_letterbox(f, W, H, tol, hist) ? 1u : 0u;
     } else if (wave == 1) {
         n = strip_is_letterbox(f + (W - 1), W, H, tol, hist) ? 1u : 0u;
-    } else if (wave == 2) {
-        while (n < H && !converged() && strip_is_letterbox(f + (size_t)n * W, 1, W, tol, hist)) publish(++n);
     } else {
-        while (n < H && !converged() && strip_is_letterbox(f + (size_t)(H - n - 1) * W, 1, W, tol, hist)) publish(++n);
+        // top (wave 2) / bottom (wave 3): strip k is row k / H - 1 - k.  The first strip alone (most frames have no bar and stop here), then
+        // four at a time while a whole batch is inside the frame
+        const bool bottom = wave == 3;
+        auto strip = [&](uint32_t k) { return f + (size_t)(bottom ? H - 1 - k : k) * W; };
+        if (strip_is_letterbox(strip(0), 1, W, tol, hist)) {
+            n = 1;
+            publish(n);
+            bool walking = true;
+            while (walking && n + 4 <= H && !converged()) {
+                const uint32_t n0 = n;
+                const uint32_t got = row_strips4([&](uint32_t k) { return strip(n0 + k); }, W, tol, s_hist4[wave - 2]);
+                n += got;
+                publish(n);
+                walking = got == 4;
+            }
+            if (walking)
+                while (n < H && !converged() && strip_is_letterbox(strip(n), 1, W, tol, hist)) publish(++n);
+        }
     }
     if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
     __syncthreads();
