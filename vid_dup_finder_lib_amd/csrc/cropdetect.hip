@@ -9,6 +9,7 @@
 // than 90 % of its pixels are within +-tol of the strip's mode (ties: the LAST maximum, Iterator::max_by_key).
 // Integer histogram per strip in LDS, one f64 compare: bit-exact with the oracle.
 #include <algorithm>
+#include <cstdlib>
 
 #include "vdf_internal.h"
 
@@ -251,20 +252,21 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     struct __attribute__((packed, aligned(1))) UN { uint32_t d[ND]; };
-    auto byte_of = [](const UN &v, uint32_t c) {  // (64-bit shifts, not an indexed load: a lane-dependent index would put v in scratch)
-        const uint64_t lo = (uint64_t)v.d[0] | ((uint64_t)v.d[1] << 32);
-        uint64_t w = lo;
-        if constexpr (NC == 16) {
-            const uint64_t hi = (uint64_t)v.d[2] | ((uint64_t)v.d[3] << 32);
-            w = c < 8 ? lo : hi;
+    auto byte_of = [](const UN &v, uint32_t c) {  // (64-bit shifts and selects, not an indexed load: a lane-dependent index would put v in scratch)
+        uint64_t w = (uint64_t)v.d[0] | ((uint64_t)v.d[1] << 32);
+#pragma unroll
+        for (uint32_t j = 1; j < ND / 2; j++) {
+            const uint64_t wj = (uint64_t)v.d[2 * j] | ((uint64_t)v.d[2 * j + 1] << 32);
+            w = (c >> 3) == j ? wj : w;
         }
         return (uint32_t)(w >> (8 * (c & 7))) & 255u;
     };
     auto slot = [&](uint32_t c, uint32_t value) { return &histn[(c % HALF) * 256u + value]; };
-    for (uint32_t i0 = 0; i0 < H; i0 += 256) {  // four rows per lane in flight
-        UN v[4];
+    constexpr int INFL = NC <= 16 ? 4 : 2;  // rows per lane in flight (16 dwords of loads either way)
+    for (uint32_t i0 = 0; i0 < H; i0 += 64u * INFL) {
+        UN v[INFL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < INFL; k++) {
             const uint32_t row = i0 + 64u * k + lane;
             if (row < H) v[k] = *reinterpret_cast<const UN *>(f + (size_t)row * W + x0);
             else
@@ -272,7 +274,7 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
                 for (uint32_t j = 0; j < ND; j++) v[k].d[j] = 0u;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < INFL; k++) {
             const bool active = i0 + 64u * k + lane < H;
             const uint64_t act = __builtin_amdgcn_ballot_w64(active);
             if (act == 0) break;  // wave-uniform
@@ -313,7 +315,7 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 #pragma unroll
     for (uint32_t o = NC; o < 64; o <<= 1) count += (uint32_t)__shfl_xor((int)count, (int)o, 64);
     const bool pass = more_than_nine_tenths(count, H);
-    constexpr uint32_t ALL = (1u << NC) - 1u;
+    constexpr uint32_t ALL = NC == 32 ? 0xFFFFFFFFu : (1u << (NC & 31)) - 1u;
     uint32_t ok = (uint32_t)__builtin_amdgcn_ballot_w64(pass && lane < (uint32_t)NC) & ALL;  // bit c = column x0 + c is letterbox
     __builtin_amdgcn_wave_barrier();
     if (from_right) ok = __builtin_bitreverse32(ok) >> (32 - NC);  // bit k = strip k
@@ -482,7 +484,10 @@ hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t fram
         const size_t want = std::min<size_t>(n_frames, (size_t)cus * per_cu);
         return (uint32_t)((want + kWorkLists - 1) / kWorkLists * kWorkLists);
     };
-    if (h >= 256)
+    if (h >= 512 && !std::getenv("VDF_LB_NC16"))
+        hipLaunchKernelGGL(letterbox_sides_kernel<32>, dim3(grid_for(4)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+                           work, n_frames);
+    else if (h >= 256)
         hipLaunchKernelGGL(letterbox_sides_kernel<16>, dim3(grid_for(9)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
                            work, n_frames);
     else
