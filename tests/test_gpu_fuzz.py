@@ -268,7 +268,8 @@ _SOAK_FAMILIES = [  # name, rows, columns, clips, letterboxed
     # top / bottom bars only: the ROWCROP instantiations of the stream kernels (per-clip first row, height, vertical table)
     ("row-cropped stream 1280", 360, 1280, 24, "rows"), ("row-cropped stream 854 (shifted)", 300, 854, 24, "rows"),
     ("row-cropped stream 640", 360, 640, 40, "rows"), ("row-cropped wave-stream 1920", 300, 1920, 24, "rows"),
-    ("row-cropped wave-stream 1366 (shifted)", 200, 1366, 32, "rows"), ("row-cropped K-split 3840", 200, 3840, 12, "rows"),
+    ("row-cropped wave-stream 1366 (shifted)", 200, 1366, 32, "rows"), ("row-cropped K-split 3840", 200, 3840, 12, "rows"),    # side bars from a few fixed widths: boxes that share their column range go through the per-wave kernel group by group
+    ("box groups 1280", 360, 1280, 32, "boxes"), ("box groups 1001 (shifted)", 300, 1001, 32, "boxes"),
 ]
 
 
@@ -292,6 +293,8 @@ def test_stream_kernels_soak(name, h, w, n, letterbox):
         for c in range(n):
             t, b = int(rng.integers(0, h // 5)), int(rng.integers(0, h // 5))
             l, r = (int(rng.integers(0, w // 6)), int(rng.integers(0, w // 6))) if c % 2 and letterbox != "rows" else (0, 0)
+            if letterbox == "boxes":
+                l, r = [(w // 8, w // 8), (w // 8 + 1, w // 8 + 2), (0, 0)][c % 3]
             if t:
                 frames[c, :, :t] = 16
             if b:

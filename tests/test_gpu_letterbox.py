@@ -299,3 +299,36 @@ def test_side_bars_walk_in_batches_of_columns(engine, h, w):
     want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
     assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0]
     assert (want[:, :2] > 16).any() or w < 40  # the batches were really walked
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (720, 1280), (480, 854), (300, 1001), (576, 1024), (432, 3840), (144, 2000), (400, 700)])
+def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, monkeypatch, h, w):
+    """Pillarboxed clips whose boxes share a column range (x0, width) form groups, and a group of four or more goes through the per-wave
+    stream kernel with the frame's pitch, a column offset and the box's band table (one launch per range) while the clips with full-width
+    boxes stream next to them and odd ones out take the gather kernel.  Ranges on and off dword boundaries (MODE 1 / 2 of the DMA),
+    widths off a multiple of 4 and of 16, per-clip rows inside a range, boxes narrower than the kernel takes (< 513 columns: gather):
+    equal to the oracle on the cropped copies and to the gather kernel alone (VDF_NO_BOXSTREAM)."""
+    rng = np.random.default_rng(h * 13 + w)
+    ranges = [(w // 8, w // 8), (w // 8 + 1, w // 8 - 1), (16, 0), (3, 5), (w // 2, 8), (0, w // 5)]
+    crops = []
+    for k, (l, r) in enumerate(ranges):
+        for j in range(5):  # five clips per range, each with its own rows
+            crops.append((l, r, (j * 7) % (h // 4), (j * 11 + k) % (h // 4)))
+    crops += [(0, 0, 0, 0), (0, 0, h // 8, h // 8), (0, 0, 0, 3), (w // 3, 1, 2, 0), (5, w // 4, 0, 0)]  # full-width boxes and two odd ones out
+    order = rng.permutation(len(crops))
+    crops = np.array([crops[i] for i in order], np.uint32)
+    n = len(crops)
+    frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+    want = np.stack([orc.hash_clip(np.ascontiguousarray(frames[c][:, crops[c][2]:h - crops[c][3], crops[c][0]:w - crops[c][1]]))[1] for c in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out.data_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0].tolist()
+    monkeypatch.setenv("VDF_NO_BOXSTREAM", "1")
+    out2 = torch.zeros_like(out)
+    engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)

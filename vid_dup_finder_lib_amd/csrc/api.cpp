@@ -823,7 +823,9 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         }
         for (BoxGroup &g : cand) {
             const int nw = vdf::resize_wavestream_waves_box(w, g.x0, g.bw);
-            if (nw && boxes.size() < 16) {  // (a launch per range: a batch with more distinct ranges than that leaves the rest to the gather kernel)
+            // (a launch per range: ranges shared by fewer than four clips - a launch would leave most CUs idle - and the ranges beyond sixteen
+            // are left to the gather kernel)
+            if (nw && g.ids.size() >= 4 && boxes.size() < 16) {
                 g.mh = mfma_table(ctx, g.bw, vdf::kMfmaLayoutHorizontalBand, stream, &rc);
                 if (rc) return rc;
                 if (g.mh->host.ok && vdf::resize_wavestream_table_fits(nw, g.mh->host.band_stride)) { boxes.push_back(std::move(g)); continue; }
