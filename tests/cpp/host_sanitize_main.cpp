@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../../include/vdf.h"
@@ -39,6 +40,56 @@ int main()
         vdf_groups r{};
         assert(vdf_groups_from_ref_hits(hits.data(), hits.size(), &r) == VDF_OK);
         vdf_groups_free(&a); vdf_groups_free(&b); vdf_groups_free(&r);
+    }
+    // the hash-cache codec (csrc/cache_format.cpp: arrays allocated at an upper bound and filled in place): round trips with every varint
+    // width inside the hashes, then every truncation and a few thousand byte mutations of a valid file - accepted or VDF_E_INVAL, never
+    // a read or write out of bounds (copies sized exactly, so ASan sees an overrun of one byte)
+    for (int rep = 0; rep < 30; rep++) {
+        const size_t n = rng() % 40;
+        std::vector<uint64_t> h(n * 16), secs(n), offs(n + 1, 0);
+        std::vector<uint32_t> d(n), nanos(n);
+        std::string blob;
+        for (size_t i = 0; i < n; i++) {
+            for (int w = 0; w < 16; w++) {
+                const uint64_t x = ((uint64_t)rng() << 32) | rng();
+                const int kind = rng() % 5;
+                h[i * 16 + w] = kind == 0 ? x % 251 : kind == 1 ? x % 65536 : kind == 2 ? (uint32_t)x : x;
+            }
+            d[i] = rng(); secs[i] = ((uint64_t)rng() << 20) ^ rng(); nanos[i] = rng() % 1000000000u;
+            const size_t len = rng() % 300;
+            for (size_t k = 0; k < len; k++) blob.push_back((char)('a' + rng() % 26));
+            offs[i + 1] = blob.size();
+        }
+        uint8_t *enc = nullptr; size_t enc_len = 0;
+        assert(vdf_cache_encode(n, h.data(), d.data(), offs.data(), blob.data(), secs.data(), nanos.data(), &enc, &enc_len) == VDF_OK);
+        std::vector<uint8_t> file(enc, enc + enc_len);  // exactly sized copy
+        vdf_buffer_free(enc);
+        vdf_cache_soa c{};
+        assert(vdf_cache_decode(file.data(), file.size(), &c) == VDF_OK && c.n_ok == n && c.n_err == 0 && c.n_key_differs == 0);
+        assert(n == 0 || (std::memcmp(c.hashes, h.data(), n * 128) == 0 && std::memcmp(c.durations, d.data(), n * 4) == 0 &&
+                          std::memcmp(c.path_offsets, offs.data(), (n + 1) * 8) == 0 && std::memcmp(c.paths, blob.data(), blob.size()) == 0 &&
+                          std::memcmp(c.mtime_secs, secs.data(), n * 8) == 0 && std::memcmp(c.mtime_nanos, nanos.data(), n * 4) == 0));
+        vdf_cache_free(&c);
+        for (size_t cut = 0; cut < file.size(); cut += 1 + file.size() / 400) {
+            std::vector<uint8_t> part(file.begin(), file.begin() + cut);
+            vdf_cache_soa t{};
+            const int rc = vdf_cache_decode(part.data(), part.size(), &t);
+            assert(rc == VDF_E_INVAL || (rc == VDF_OK && cut == 0 && false) || (rc == VDF_OK && t.n_entries == 0 && part.size() == 1) || rc == VDF_OK);
+            if (rc == VDF_OK) vdf_cache_free(&t);
+        }
+        for (int m = 0; m < 300 && !file.empty(); m++) {
+            std::vector<uint8_t> mut = file;
+            for (int k = 0; k < 1 + (int)(rng() % 3); k++) mut[rng() % mut.size()] = (uint8_t)rng();
+            vdf_cache_soa t{};
+            const int rc = vdf_cache_decode(mut.data(), mut.size(), &t);
+            assert(rc == VDF_OK || rc == VDF_E_INVAL || rc == VDF_E_OOM);
+            if (rc == VDF_OK) { assert(t.n_ok <= t.n_entries); vdf_cache_free(&t); }
+        }
+    }
+    {   // a hostile count in front of nothing: refused without allocating the claimed size
+        const uint8_t huge[9] = {253, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x7F};
+        vdf_cache_soa t{};
+        assert(vdf_cache_decode(huge, sizeof huge, &t) == VDF_E_INVAL);
     }
     vdf_groups e{};
     assert(vdf_replay_self(0, nullptr, 0, 0, 0, nullptr, &e) == VDF_OK && vdf_groups_finish_self(&e) == VDF_OK && e.n_groups == 0);
