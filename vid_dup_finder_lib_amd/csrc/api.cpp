@@ -33,7 +33,7 @@ vdf_ctx::~vdf_ctx()
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
-                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &sort_scratch, &hits2, &hit_bitmaps};
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &crop_desc2, &crop_tables2, &crop_work, &sort_scratch, &hits2, &hit_bitmaps};
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
