@@ -130,6 +130,9 @@ int vdf_ctx_device(const vdf_ctx *ctx);
 int vdf_ctx_set_hit_capacity(vdf_ctx *ctx, uint64_t capacity);
 int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out);
 int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out); /* multi-GPU context: host figures + the slowest device's */
+/* Diagnostics: bytes of device memory held by the library's growable buffers over all contexts of the process (tables, staging, hit
+ * lists, crop descriptors ...).  Back to its earlier value after vdf_ctx_destroy, or a buffer was forgotten. */
+long long vdf_live_device_bytes(void);
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------------ */
 /* VideoHash::hamming_distance, video_hash.rs:190-192,311-317: all 16 words, padding included. */

@@ -58,6 +58,8 @@ extern "C" {
     pub fn vdf_ctx_destroy(ctx: *mut vdf_ctx);
     pub fn vdf_last_error(ctx: *const vdf_ctx) -> *const c_char;
     pub fn vdf_ctx_last_search_stats(ctx: *const vdf_ctx, out: *mut vdf_search_stats) -> c_int;
+    /// bytes of device memory held by the library's growable buffers over all contexts (diagnostics)
+    pub fn vdf_live_device_bytes() -> std::os::raw::c_longlong;
 
     pub fn vdf_tolerance_int(tolerance: f64) -> u32;
     pub fn vdf_hamming_u1024(a: *const u64, b: *const u64) -> u32;

@@ -332,3 +332,43 @@ def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, mo
     engine.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out2.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+def test_contexts_give_their_device_memory_back():
+    """Every device buffer a context grows (the crop split's descriptor arrays, the detect work list, tables, staging, hit lists) is released
+    with the context: create - hash letterboxed, pillarboxed and mixed batches - search - close, and the library's own count of live
+    device bytes (vdf_live_device_bytes) is back where it was (a context once forgot three buffers in its destructor)."""
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import _capi
+
+    lib = _capi.load()
+    rng = np.random.default_rng(7)
+    h, w, n = 360, 1280, 48
+    frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
+    frames[0::3, :, :40] = 16
+    frames[0::3, :, h - 40:] = 16
+    frames[1::3, :, :, :160] = 16
+    frames[1::3, :, :, w - 160:] = 16
+    d = torch.from_numpy(frames).cuda()
+    out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+    words = rng.integers(0, 2**63, size=(5000, 16), dtype=np.int64).astype(np.uint64)
+    before = lib.vdf_live_device_bytes()
+    for _ in range(3):
+        eng = vdf.Engine(0)
+        try:
+            eng.hash_frames_letterbox_device(d.data_ptr(), n, 16, w, h, out.data_ptr())
+            eng.hash_frames(frames[:2])
+            eng.search_self_sorted(words, np.zeros(len(words), np.uint32), 350)
+            eng.search_refs_sorted(words, np.zeros(len(words), np.uint32), words[:100], np.zeros(100, np.uint32), 350)
+            torch.cuda.synchronize()
+            assert lib.vdf_live_device_bytes() > before
+        finally:
+            eng.close()
+        assert lib.vdf_live_device_bytes() == before
+    eng = vdf.Engine(devices=[0, 0])  # the multi-device form: per-device sub-contexts
+    try:
+        eng.hash_frames_letterbox(frames[:8])
+        eng.search_self_sorted(words, np.zeros(len(words), np.uint32), 350)
+    finally:
+        eng.close()
+    assert lib.vdf_live_device_bytes() == before

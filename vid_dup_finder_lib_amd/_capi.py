@@ -92,6 +92,7 @@ SIGNATURES = {
     "vdf_ctx_set_hit_capacity": (C.c_int, [_ctx, C.c_uint64]),
     "vdf_ctx_last_search_stats": (C.c_int, [_ctx, C.POINTER(VdfSearchStats)]),
     "vdf_ctx_last_search_timing": (C.c_int, [_ctx, C.POINTER(VdfSearchTiming)]),
+    "vdf_live_device_bytes": (C.c_longlong, []),
     "vdf_hamming_u1024": (C.c_uint32, [_u64p, _u64p]),
     "vdf_tolerance_int": (C.c_uint32, [C.c_double]),
     "vdf_count_pairs_self": (C.c_uint64, [_u32p, C.c_size_t]),

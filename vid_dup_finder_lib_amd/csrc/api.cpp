@@ -1240,6 +1240,8 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
     return VDF_OK;
 }
 
+long long vdf_live_device_bytes(void) { return g_live_device_bytes.load(); }
+
 int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out)
 {
     if (!ctx || !out) return VDF_E_INVAL;

@@ -11,7 +11,13 @@
 #include <vector>
 
 #include "resize_tables.h"
+#include <atomic>
+
 #include "vdf_internal.h"
+
+// bytes of device memory the library's growable buffers hold right now, over all contexts of the process (vdf_live_device_bytes: a
+// context that forgets a buffer in its destructor shows up as a difference around create / use / destroy)
+inline std::atomic<long long> g_live_device_bytes{0};
 
 struct DevBuf {
     void *p = nullptr;
@@ -19,14 +25,20 @@ struct DevBuf {
     hipError_t reserve(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        release();
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
+        g_live_device_bytes += (long long)cap;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) { (void)hipFree(p); g_live_device_bytes -= (long long)cap; }
+        p = nullptr;
+        cap = 0;
+    }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
