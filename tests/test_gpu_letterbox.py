@@ -365,6 +365,19 @@ def test_contexts_give_their_device_memory_back():
         finally:
             eng.close()
         assert lib.vdf_live_device_bytes() == before
+    eng = vdf.Engine(0)  # a batching queue: two slots per GPU with private contexts
+    try:
+        from vid_dup_finder_lib_amd.engine import HashQueue
+
+        q = HashQueue(eng, w, h, max_batch=4, max_wait_us=100, letterbox=True)
+        try:
+            for c in range(3):
+                q.submit(frames[c])
+        finally:
+            q.close()
+    finally:
+        eng.close()
+    assert lib.vdf_live_device_bytes() == before
     eng = vdf.Engine(devices=[0, 0])  # the multi-device form: per-device sub-contexts
     try:
         eng.hash_frames_letterbox(frames[:8])
