@@ -226,8 +226,7 @@ def search_roofline(backend, kernel_ms):
         extra = {"valu": valu}
         dtype = "u32 (xor + popcount over 32 dwords per hash)"
     else:
-        gen2 = os.environ.get("VDF_MFMA_KERNEL", "2") != "1"
-        kname = "hamming_mfma2_kernel" if gen2 else "hamming_mfma_kernel"
+        kname = "hamming_mfma2_kernel"
         alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
         k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
         ee_bits = int(kernel_ms[-1][6])

@@ -126,13 +126,16 @@ void vdf_ctx_destroy(vdf_ctx *ctx);
 const char *vdf_last_error(const vdf_ctx *ctx); /* ctx may be NULL: last ctx_create failure */
 const char *vdf_version(void);
 int vdf_ctx_device(const vdf_ctx *ctx);
-/* Hit-buffer capacity (entries) used by the host-level search calls; default 1<<24. */
+/* Hit-buffer capacity (entries) used by the host-level search calls; default 1<<24: 128 MB of DEVICE memory per GPU of the context
+ * (8 bytes per entry).  The page-locked host staging the lists come down through is sized by what the searches actually produce
+ * (512 KB to begin with), not by this capacity. */
 int vdf_ctx_set_hit_capacity(vdf_ctx *ctx, uint64_t capacity);
 int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out);
 int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out); /* multi-GPU context: host figures + the slowest device's */
 /* Diagnostics: bytes of device memory held by the library's growable buffers over all contexts of the process (tables, staging, hit
  * lists, crop descriptors ...).  Back to its earlier value after vdf_ctx_destroy, or a buffer was forgotten. */
 long long vdf_live_device_bytes(void);
+long long vdf_live_pinned_bytes(void); /* the same for page-locked host staging */
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------------------ */
 /* VideoHash::hamming_distance, video_hash.rs:190-192,311-317: all 16 words, padding included. */
@@ -334,6 +337,12 @@ typedef struct vdf_cache_soa {
     uint32_t *mtime_nanos;   /* n_ok */
 } vdf_cache_soa;
 int vdf_cache_decode(const uint8_t *data, size_t len, vdf_cache_soa *out); /* malformed input -> VDF_E_INVAL */
+/* The same on n_threads host threads (0 = as many as the machine has, for files of a few MB and more; what vdf_cache_decode does).
+ * bincode has no entry index, so the file is cut where the byte pattern of an Ok entry's hash words resynchronises, every range
+ * is parsed by its own thread, and the ranges must meet exactly: if they do not, the file is decoded front to back instead - the
+ * result never depends on the speculation.  10 M entries (2.4 GB): 1.2 s on one thread. */
+int vdf_cache_decode_mt(const uint8_t *data, size_t len, int n_threads, vdf_cache_soa *out);
+unsigned long long vdf_cache_decode_fallbacks(void); /* diagnostics: how often this process fell back to the front-to-back decode */
 void vdf_cache_free(vdf_cache_soa *c);
 /* Writes a cache the app can load: every entry Ok(VideoHash), key = src_path.  mtime arrays may be NULL (0).
  * *out_data is library-allocated; release with vdf_buffer_free(). */
@@ -341,6 +350,69 @@ int vdf_cache_encode(uint64_t n, const uint64_t *hashes, const uint32_t *duratio
                      const char *paths, const uint64_t *mtime_secs, const uint32_t *mtime_nanos, uint8_t **out_data,
                      size_t *out_len);
 void vdf_buffer_free(void *p);
+
+/* ---- the cache's metadata sidecar (host only) ---------------------------------------------------------
+ * Next to its cache file <dir>/<stem>.<ext> the app keeps <dir>/<stem>.metadata.txt holding
+ * "{operating_system:?},{decode_backend:?},{crop:?},{skip_forward_amount},{cache_version}"
+ * (vid_dup_finder_app/src/video_hash_filesystem_cache/cache_metadata.rs:45-51,80-89; video_hash_filesystem_cache.rs:76-139).
+ * A cache file WITHOUT its sidecar makes the app exit (video_hash_filesystem_cache.rs:113-117), and a sidecar whose fields differ
+ * from the run's options refuses the cache (:127-137) - the crop field is what keeps Cropdetect::None hashes and Letterbox hashes
+ * of the same files apart.  Writers of a cache for the app: vdf_cache_encode + vdf_cache_metadata_new / _format / _path.
+ * Readers of an app-written cache: vdf_cache_metadata_parse + _validate before the entries are mixed with this engine's hashes. */
+enum { VDF_CACHE_OS_WINDOWS = 0, VDF_CACHE_OS_UNIX = 1 };               /* cache_metadata.rs:6-10 */
+enum { VDF_CACHE_BACKEND_FFMPEG = 0, VDF_CACHE_BACKEND_GSTREAMER = 1 }; /* cache_metadata.rs:25-29 */
+enum { VDF_CROPDETECT_NONE = 0, VDF_CROPDETECT_LETTERBOX = 1, VDF_CROPDETECT_MOTION = 2 }; /* vid_dup_finder_lib/src/definitions.rs:46-54 */
+typedef struct vdf_cache_metadata {
+    int32_t operating_system;
+    int32_t decode_backend;
+    int32_t crop;
+    int32_t reserved;
+    double skip_forward_amount;
+    uint64_t cache_version;
+} vdf_cache_metadata;
+/* VdfCacheMetadata::new (cache_metadata.rs:54-78) as this library's target sees it: Unix, FfmpegBackend (the app's default
+ * features), cache_version 1. */
+int vdf_cache_metadata_new(int32_t crop, double skip_forward_amount, vdf_cache_metadata *out);
+/* to_disk_fmt (:80-89).  *out_len = the text's length (no NUL counted; one is appended when it fits); cap too small -> VDF_E_OVERFLOW. */
+int vdf_cache_metadata_format(const vdf_cache_metadata *m, char *buf, size_t cap, size_t *out_len);
+/* try_parse (:91-125): exactly five comma-separated fields; operating system and backend are trimmed and lower-cased, crop is the
+ * exact variant name, the numbers are Rust's str::parse (no white space).  VDF_E_INVAL with the app's message in err (nullable). */
+int vdf_cache_metadata_parse(const char *text, size_t len, vdf_cache_metadata *out, char *err, size_t err_cap);
+/* validate (:127-168) against new(exp_crop, exp_skip_forward_amount): VDF_OK, or VDF_E_INVAL with the first mismatch in err. */
+int vdf_cache_metadata_validate(const vdf_cache_metadata *act, int32_t exp_crop, double exp_skip_forward_amount, char *err, size_t err_cap);
+/* The sidecar's path for a cache path: file_stem() + ".metadata.txt" in the same directory (video_hash_filesystem_cache.rs:93-104).
+ * A path without a file name ("..", "/") -> VDF_E_INVAL (the app reports EINVAL there). */
+int vdf_cache_metadata_path(const char *cache_path, size_t len, char *buf, size_t cap, size_t *out_len);
+
+/* ---- Search::sort's path order for a whole cache (host only) ------------------------------------------
+ * Search::sort keys on (duration, src_path) and PathBuf orders by COMPONENTS (search_algorithm.rs:55-61; std::path::Path::cmp):
+ * [RootDir | CurDir], then one Normal component per non-empty piece between '/', inner "." skipped, ".." = ParentDir;
+ * RootDir < CurDir < ParentDir < Normal(bytes), a component-wise prefix sorts first.  "a/b" < "a.b", "a//b" == "a/b".
+ * vdf_path_compare: -1 / 0 / +1.  vdf_path_ranks: out_rank[i] = number of distinct paths that sort before path i (equal paths
+ * share a rank) for the n paths paths[path_offsets[i] .. path_offsets[i + 1]) - the layout of vdf_cache_soa - on n_threads host
+ * threads (0 = all); what vdf_sort_order_device takes as d_path_rank.  No per-entry allocation. */
+int vdf_path_compare(const char *a, size_t len_a, const char *b, size_t len_b);
+int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, uint32_t *out_rank, int n_threads);
+
+/* ---- from the entries of a decoded cache to MatchGroups in one call -----------------------------------
+ * What the app does between loading its cache and printing groups (vid_dup_finder_app/src/app/app_fns.rs:428-482: fetch the
+ * hashes of the --files paths and of the --with-refs paths, then search() or search_with_references()), on the SoA arrays of
+ * vdf_cache_decode, with no per-entry host object: PathBuf ranks of the candidate paths (vdf_path_ranks) -> upload ->
+ * Search::sort on the device (vdf_sort_order_device) -> gather -> search.
+ * cand_idx (nullable = all n entries, n_cand ignored) and ref_idx select entries of the arrays; n_ref == 0 -> search(), else
+ * search_with_references() with the references in ref_idx order.  Group members (and ref_index) are indices into the caller's
+ * arrays (NOT into cand_idx / ref_idx), in the reference's order.  timing (nullable) receives the phases. */
+typedef struct vdf_cache_search_timing {
+    float rank_ms;    /* host: vdf_path_ranks over the candidates */
+    float upload_ms;  /* host wall: hashes, durations, ranks to the device(s) */
+    float sort_ms;    /* device + host wall: Search::sort order, gather, order download */
+    float search_ms;  /* the search call proper (vdf_ctx_last_search_timing has its phases) */
+    float map_ms;     /* host: group members back to the caller's indices */
+    float total_ms;
+} vdf_cache_search_timing;
+int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, const uint64_t *path_offsets,
+                             const char *paths, size_t n, const uint64_t *cand_idx, size_t n_cand, const uint64_t *ref_idx,
+                             size_t n_ref, uint32_t tol_int, vdf_groups *out, vdf_cache_search_timing *timing);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """search_with_references at the BASELINE configs[4] shape (1 M candidates x 100 k references, log-uniform durations,
 +-5 % windows, tolerance 350): kernel time and waste ratio (pairs the tiles evaluated / pairs the windows admit) for
-the knobs in the environment (VDF_MFMA_KERNEL, VDF_MFMA_REFS_ROWS)."""
+the knobs in the environment (VDF_MFMA_REFS_ROWS)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -27,5 +27,5 @@ for i in range(6):
     if i: wall.append(time.perf_counter() - t0)
     st = eng.last_stats()
     if i: ks.append(st["kernel_ms"])
-print(f"kernel {os.environ.get('VDF_MFMA_KERNEL','2')} refs_rows {os.environ.get('VDF_MFMA_REFS_ROWS','256')}: call {np.mean(wall) * 1e3:.2f} ms, kernel_ms mean {np.mean(ks):.3f} min {np.min(ks):.3f}, "
+print(f"refs_rows {os.environ.get('VDF_MFMA_REFS_ROWS','256')}: call {np.mean(wall) * 1e3:.2f} ms, kernel_ms mean {np.mean(ks):.3f} min {np.min(ks):.3f}, "
       f"pairs {st['pairs']:.4g}, computed {st['pairs_computed']:.4g}, waste ratio {st['pairs_computed']/st['pairs']:.3f}, hits {n_hits}, tiles {st['n_tiles']}")

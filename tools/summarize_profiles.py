@@ -64,12 +64,9 @@ for k in summary.get("fetch_search", {}):
     if k.startswith("hamming_mfma2_kernel"):
         t["hamming_mfma2_kernel"] = traffic("fetch_search", "write_search", k, 2,
                                             "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
-    if k.startswith("hamming_mfma_kernel"):
-        t["hamming_mfma_kernel"] = traffic("fetch_search", "write_search", k, 2,
-                                           "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
 for k in summary.get("fetch_hash", {}):
     if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
-        t["resize_dct_hash_fused_kernel"] = traffic("fetch_hash", "write_hash", k, 2,
+        t[k.split("<")[0].split("(")[0]] = traffic("fetch_hash", "write_hash", k, 2,
                                                     "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
 for tag_, fd, wd in (("resize_mfma_frame_wavestream_kernel@1920x1080", "fetch_hd", "write_hd"),
                      ("resize_mfma_frame_stream_kernel@480x270", "fetch_sd", "write_sd"),

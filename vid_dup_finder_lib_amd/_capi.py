@@ -73,6 +73,20 @@ class VdfCacheSoa(C.Structure):
     ]
 
 
+class VdfCacheMetadata(C.Structure):
+    _fields_ = [("operating_system", C.c_int32), ("decode_backend", C.c_int32), ("crop", C.c_int32), ("reserved", C.c_int32),
+                ("skip_forward_amount", C.c_double), ("cache_version", C.c_uint64)]
+
+
+class VdfCacheSearchTiming(C.Structure):
+    _fields_ = [("rank_ms", C.c_float), ("upload_ms", C.c_float), ("sort_ms", C.c_float), ("search_ms", C.c_float),
+                ("map_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+VDF_CACHE_OS_WINDOWS, VDF_CACHE_OS_UNIX = 0, 1
+VDF_CACHE_BACKEND_FFMPEG, VDF_CACHE_BACKEND_GSTREAMER = 0, 1
+VDF_CROPDETECT_NONE, VDF_CROPDETECT_LETTERBOX, VDF_CROPDETECT_MOTION = 0, 1, 2
+
 _u64p = C.POINTER(C.c_uint64)
 _u32p = C.POINTER(C.c_uint32)
 _u8p = C.POINTER(C.c_uint8)
@@ -93,6 +107,7 @@ SIGNATURES = {
     "vdf_ctx_last_search_stats": (C.c_int, [_ctx, C.POINTER(VdfSearchStats)]),
     "vdf_ctx_last_search_timing": (C.c_int, [_ctx, C.POINTER(VdfSearchTiming)]),
     "vdf_live_device_bytes": (C.c_longlong, []),
+    "vdf_live_pinned_bytes": (C.c_longlong, []),
     "vdf_hamming_u1024": (C.c_uint32, [_u64p, _u64p]),
     "vdf_tolerance_int": (C.c_uint32, [C.c_double]),
     "vdf_count_pairs_self": (C.c_uint64, [_u32p, C.c_size_t]),
@@ -151,6 +166,17 @@ SIGNATURES = {
     "vdf_cache_encode": (C.c_int, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "vdf_buffer_free": (None, [C.c_void_p]),
+    "vdf_cache_decode_fallbacks": (C.c_ulonglong, []),
+    "vdf_cache_decode_mt": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(VdfCacheSoa)]),
+    "vdf_cache_metadata_new": (C.c_int, [C.c_int32, C.c_double, C.POINTER(VdfCacheMetadata)]),
+    "vdf_cache_metadata_format": (C.c_int, [C.POINTER(VdfCacheMetadata), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vdf_cache_metadata_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(VdfCacheMetadata), C.c_void_p, C.c_size_t]),
+    "vdf_cache_metadata_validate": (C.c_int, [C.POINTER(VdfCacheMetadata), C.c_int32, C.c_double, C.c_void_p, C.c_size_t]),
+    "vdf_cache_metadata_path": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "vdf_path_compare": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "vdf_path_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "vdf_search_cache_entries": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(VdfGroups), C.POINTER(VdfCacheSearchTiming)]),
 }
 
 _lib = None

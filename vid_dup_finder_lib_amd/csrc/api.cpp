@@ -33,7 +33,7 @@ vdf_ctx::~vdf_ctx()
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
-                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &crop_desc2, &crop_tables2, &crop_work, &sort_scratch, &hits2, &hit_bitmaps};
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &crop_desc2, &crop_tables2, &crop_work, &sort_scratch, &sort_scratch_pub, &hits2, &hit_bitmaps};
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
@@ -84,7 +84,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
-                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only)
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only, vdf_ctx::HostHits *staging)
 {
     *n_hits_out = 0;
     *overflow_row_out = 0xFFFFFFFFu;
@@ -96,10 +96,9 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     vdf::SearchLaunch L{};
     const bool mfma = ctx->search_backend == 1;
-    // second-generation MFMA kernel: 512-row workgroups for search(); reference searches may take 256-row ones (a tile's
-    // candidate range is the union of its rows' duration windows: fewer rows, narrower union)
-    const bool gen2 = mfma && ctx->mfma_kernel == 2;
-    L.tile_rows = mfma ? (gen2 ? (mode == 1 ? ctx->mfma_refs_rows : ctx->mfma_self_rows) : vdf::kMfmaRowPad) : ctx->tile_rows;
+    // MFMA kernel: 512-row workgroups for search(); reference searches may take 256-row ones (a tile's candidate range is the
+    // union of its rows' duration windows: fewer rows, narrower union)
+    L.tile_rows = mfma ? (mode == 1 ? ctx->mfma_refs_rows : ctx->mfma_self_rows) : ctx->tile_rows;
     L.chunk_cols = mfma ? ctx->mfma_chunk_cols : ctx->chunk_cols;
     L.n_row_tiles = (uint32_t)((n_rows + L.tile_rows - 1) / L.tile_rows);
     if (mfma && L.chunk_cols == 0) {
@@ -149,24 +148,21 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     // Early-exit step (both backends): the first 64-bit k-step after which unrelated hashes (partial distance bits / 2 +-
     // sqrt(bits) / 2) are, 4 sigma down, still more than tol apart - then nearly every block stops there.  Exact whatever is
-    // picked.  Kernels are instantiated for steps 6, 8, 10, 11, 12, 13 (MFMA) / 6, 10, 12 (VALU): round up; 16 = no test.
+    // picked.  Kernels are instantiated for steps 6, 8, 10, 11, 12, 13, 14 (MFMA) / 6, 10, 12 (VALU): round up; 16 = no test.
+    // (tolerance 350 -> step 12 = 832 bits; up to 387 -> 13; up to 417 -> 14 = 960 bits; beyond that unrelated hashes are no longer
+    // 4 sigma away from the tolerance after any prefix and the stream runs all 16 steps)
     L.prune_step = 16;
     if (ctx->mfma_prune_step >= 0) {
         L.prune_step = ctx->mfma_prune_step;
     } else {
-        for (int st = 6; st <= 13; st++) {
+        for (int st = 6; st <= 14; st++) {
             const double bits = 64.0 * (st + 1);
             if (bits / 2 - 2.0 * std::sqrt(bits) >= (double)tol_int + 1) { L.prune_step = st; break; }
         }
     }
-    if (mfma) L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 13 ? L.prune_step : 16;
+    if (mfma) L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 8 ? 8 : L.prune_step <= 10 ? 10 : L.prune_step <= 14 ? L.prune_step : 16;
     else L.prune_step = L.prune_step <= 6 ? 6 : L.prune_step <= 10 ? 10 : L.prune_step <= 12 ? 12 : 16;
     if (mfma) {
-#ifdef VDF_BENCH_ABLATE  // timing-experiment builds only (tools/sweep_ablate.sh): the ablated kernels report no hits
-        if (const char *ab = std::getenv("VDF_MFMA_ABLATE")) L.ablate = std::atoi(ab);
-        if (L.ablate) L.prune_step = 16;
-#endif
-        L.xcd_stripe = ctx->mfma_xcd_stripe;
         L.group_size = std::min<uint32_t>(ctx->mfma_group, L.n_row_tiles);
         L.n_groups = (L.n_row_tiles + L.group_size - 1) / L.group_size;
         if (L.n_groups > 1024) return fail(ctx, VDF_E_INVAL, "too many row-tile groups");
@@ -176,25 +172,23 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         L.group_blocks = ctx->group_blocks.as<uint32_t>();
         L.group_cmin = ctx->group_cmin.as<uint32_t>();
         L.group_offset = ctx->group_offset.as<uint32_t>();
-        // expand both operands to fp4 nibbles (512 B per hash); rows share the column copy in self mode.  The second-
-        // generation kernel takes {0, 1} nibbles plus popcount arrays, the first one +-1 nibbles.
-        const int mode01 = gen2 ? 1 : 0;
+        // expand both operands to {0, 1} fp4 nibbles (512 B per hash) plus popcount arrays; rows share the column copy in self mode
         const uint32_t k_steps = (uint32_t)(L.prune_step < 15 ? L.prune_step + 1 : 16);  // k-steps of the tested prefix
         const uint32_t col_pad = (uint32_t)((n_cols + vdf::kMfmaRowPad - 1) / vdf::kMfmaRowPad * vdf::kMfmaRowPad) + vdf::kMfmaColPad;
         VDF_HIP(ctx, ctx->exp_cols.reserve((size_t)col_pad * 512));
-        if (gen2) VDF_HIP(ctx, ctx->pop_cols.reserve((size_t)col_pad * 12));
+        VDF_HIP(ctx, ctx->pop_cols.reserve((size_t)col_pad * 12));
         // A database the caller has pinned (vdf_ctx_pin_database: "these bytes will not change") keeps its expansion between
         // searches: 0.15 ms per million hashes that a reference search of 0.9 ms need not pay again.
-        const ExpOwner want_owner{d_col_hashes, n_cols, k_steps, mode01, ctx->exp_cols.p};
+        const ExpOwner want_owner{d_col_hashes, n_cols, k_steps, ctx->exp_cols.p};
         const bool reuse = ctx->pinned_db == d_col_hashes && ctx->pinned_n == n_cols && ctx->exp_owner == want_owner;
         if (!reuse) {
             ctx->exp_owner = ExpOwner{};
-            VDF_HIP(ctx, vdf::launch_expand_fp4(L.col_hashes, (uint32_t)n_cols, col_pad, ctx->exp_cols.p, mode01, k_steps,
-                                                gen2 ? ctx->pop_cols.as<float>() : nullptr, stream));
+            VDF_HIP(ctx, vdf::launch_expand_fp4(L.col_hashes, (uint32_t)n_cols, col_pad, ctx->exp_cols.p, k_steps,
+                                                ctx->pop_cols.as<float>(), stream));
             ctx->exp_owner = want_owner;
         }
         L.col_exp = ctx->exp_cols.p;
-        L.col_pop3 = gen2 ? ctx->pop_cols.as<float>() : nullptr;
+        L.col_pop3 = ctx->pop_cols.as<float>();
         L.col_pad = col_pad;
         if (d_row_hashes == d_col_hashes) {
             L.row_exp = ctx->exp_cols.p;
@@ -203,11 +197,11 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         } else {
             const uint32_t row_pad = (uint32_t)((padded_rows + 127) / 128 * 128);
             VDF_HIP(ctx, ctx->exp_rows.reserve((size_t)row_pad * 512));
-            if (gen2) VDF_HIP(ctx, ctx->pop_rows.reserve((size_t)row_pad * 12));
-            VDF_HIP(ctx, vdf::launch_expand_fp4(L.row_hashes, (uint32_t)n_rows, row_pad, ctx->exp_rows.p, mode01, k_steps,
-                                                gen2 ? ctx->pop_rows.as<float>() : nullptr, stream));
+            VDF_HIP(ctx, ctx->pop_rows.reserve((size_t)row_pad * 12));
+            VDF_HIP(ctx, vdf::launch_expand_fp4(L.row_hashes, (uint32_t)n_rows, row_pad, ctx->exp_rows.p, k_steps,
+                                                ctx->pop_rows.as<float>(), stream));
             L.row_exp = ctx->exp_rows.p;
-            L.row_pop3 = gen2 ? ctx->pop_rows.as<float>() : nullptr;
+            L.row_pop3 = ctx->pop_rows.as<float>();
             L.row_pad = row_pad;
         }
     }
@@ -259,7 +253,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     // the windows are binary searches over the candidate durations (search_algorithm.rs:93-117,173-185 rely on Search::sort)
     if (unsorted) return fail(ctx, VDF_E_INVAL, "durations are not ascending: pass the arrays in Search::sort order");
     if (total_tiles >= 0x7FFFFFFFu) return fail(ctx, VDF_E_INVAL, "tile count exceeds the grid limit");
-    if (gen2) {
+    if (mfma) {
         // Queue of suspect pairs the stream cannot rule out (16-byte entries).  Unrelated hashes put ~2.3e-6 of the admitted
         // pairs there at the 4-sigma test point; slots are handed out in chunks of 8 per wave, so every wave may strand
         // a few.  Sized generously from the admitted pairs; if it still overflows, the hit-buffer overflow protocol takes
@@ -284,14 +278,14 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
 
     ctx->timing.prep_ms += (float)(now_ms() - t_enter);
     VDF_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    if (gen2) {
+    if (mfma) {
         VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma2(L, total_tiles, stream));
         VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
         if (total_tiles) VDF_HIP(ctx, vdf::launch_resolve_candidates(L, stream));
+    } else {
+        VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
+        VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
     }
-    else if (mfma) VDF_HIP(ctx, vdf::launch_hamming_tiles_mfma(L, total_tiles, stream));
-    else VDF_HIP(ctx, vdf::launch_hamming_tiles(L, total_tiles, stream));
-    if (!gen2) VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
     VDF_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     // Counters and - speculatively - the head of the hit list come back behind ONE synchronisation: the list is usually
     // about as long as the previous call's, and a second round trip costs more than copying a few KB too many.
@@ -312,9 +306,9 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, hipEventElapsedTime(&ms_stream, ctx->ev0, ctx->ev_mid));
     ctx->timing.stream_ms += ms_stream;
     ctx->timing.resolve_ms += ms - ms_stream;
-    if (gen2) { ctx->timing.suspects += fin[6]; ctx->timing.suspect_capacity = L.cand_capacity; }
+    if (mfma) { ctx->timing.suspects += fin[6]; ctx->timing.suspect_capacity = L.cand_capacity; }
 
-    if (gen2) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6], L.cand_capacity);  // slots this launch used
+    if (mfma) ctx->cand_dirty = (size_t)std::min<uint64_t>(fin[6], L.cand_capacity);  // slots this launch used
     const uint64_t produced = fin[0];
     uint64_t stored = std::min<uint64_t>(produced, capacity);
     ctx->hits_guess = stored;
@@ -339,6 +333,11 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
             n_out = stored;
             have = 0;  // the speculative copy held unfiltered pairs
             ctx->timing.hits_filtered += produced - stored;
+        }
+        if (staging) {  // the library's own staging grows to the list (host-level calls)
+            const size_t need = std::max<size_t>((size_t)stored, 1u << 16);
+            if (staging->size() < need && !staging->resize(need + need / 4)) return fail(ctx, VDF_E_OOM, "hit staging");
+            hits = staging->data();
         }
         if (have) std::memcpy(hits, ctx->pin_small.p, (size_t)have * sizeof(vdf_hit));
         if (stored > have) {
@@ -516,9 +515,9 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         const bool fused = ctx->resize_mode == 3 || (ctx->resize_mode == 0 && (h + 63) / 64 <= 2);
         // tightly packed frames stream linearly through LDS where that is the faster form (resize_stream_eligible)
         bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
-                        vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
+                        vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->wavestream_knob);
         DeviceMfmaTable *mh = nullptr;
-        if (streamed && vdf::resize_stream_wants_band(w)) {  // wide frames: the horizontal table in band form
+        if (streamed && vdf::resize_stream_wants_band(w, ctx->wavestream_knob)) {  // wide frames: the horizontal table in band form
             mh = mfma_table(ctx, w, vdf::kMfmaLayoutHorizontalBand, stream, &rc);
             if (rc) return rc;
             if (!mh->host.ok) { streamed = false; mh = nullptr; }
@@ -549,6 +548,7 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
             }
             a.no_persistent = ctx->hash_no_persistent;
             a.persistent_wgs_per_cu = ctx->hash_wgs_per_cu;
+            a.wavestream_knob = ctx->wavestream_knob;
             if (fused) {
                 VDF_HIP(ctx, vdf::launch_resize_dct_fused(d_frames, n_clips, w, h, frame_stride, clip_stride, buf_end, a,
                                                           ctx->cos_table.as<double>(), d_out, d_dc, stream));
@@ -644,10 +644,9 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     // -- can the full-width boxes take a ROWCROP kernel, and which?
     bool row_stream = false, row_ksplit = false, row_band = false;
     DeviceMfmaTable *row_mh = nullptr;
-    if (ctx->resize_mode == 0 && tall && !rows_clips.empty() && (vdf::resize_rowcrop_streams(w) || std::getenv("VDF_ROWCROP_ALL")) &&
-        !std::getenv("VDF_NO_ROWCROP")) {
-        row_stream = vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride);
-        row_band = row_stream && vdf::resize_stream_wants_band(w);
+    if (ctx->resize_mode == 0 && tall && !rows_clips.empty() && (vdf::resize_rowcrop_streams(w) || ctx->rowcrop_all) && !ctx->no_rowcrop) {
+        row_stream = vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->wavestream_knob);
+        row_band = row_stream && vdf::resize_stream_wants_band(w, ctx->wavestream_knob);
         row_ksplit = !row_stream && w > 1920 && vdf::resize_ksplit_eligible(d_frames, w, h, frame_stride, clip_stride);
         if (row_stream || row_ksplit) {
             int rc = VDF_OK;
@@ -724,6 +723,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         a.bias_h = row_mh->bias.as<int32_t>();
         a.prec_h = row_mh->host.precision;
         a.n_kt = row_mh->host.n_tiles;
+        a.wavestream_knob = ctx->wavestream_knob;
         if (row_band) {
             a.band_meta = row_mh->meta.as<int32_t>();
             a.band_stride = row_mh->host.band_stride;
@@ -746,6 +746,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         a.n_kt = g.mh->host.n_tiles;
         a.band_meta = g.mh->meta.as<int32_t>();
         a.band_stride = g.mh->host.band_stride;
+        a.wavestream_knob = ctx->wavestream_knob;
         VDF_HIP(ctx, vdf::launch_resize_mfma_box_wavestream(d_frames, g.ids.size(), w, h, frame_stride, clip_stride, a, g.x0, g.bw,
                                                             bd.as<vdf::CropStreamClip>() + g.first, bt.as<vdf::CropStreamTable>(),
                                                             ctx->small.as<uint8_t>(), stream));
@@ -809,7 +810,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     (row_mh ? rows_part : rest) = rows_clips;
     std::vector<BoxGroup> boxes;
     if (ctx->resize_mode == 0 && tall && ends16 && (((uintptr_t)d_frames | frame_stride | clip_stride) & 15) == 0 && !side_clips.empty() &&
-        !std::getenv("VDF_NO_BOXSTREAM") && !std::getenv("VDF_NO_ROWCROP")) {
+        !ctx->no_boxstream && !ctx->no_rowcrop) {
         std::map<uint64_t, size_t> by_range;  // (x0, width) -> group
         std::vector<BoxGroup> cand;
         for (uint32_t c : side_clips) {
@@ -822,7 +823,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
             cand[it->second].ids.push_back(c);
         }
         for (BoxGroup &g : cand) {
-            const int nw = vdf::resize_wavestream_waves_box(w, g.x0, g.bw);
+            const int nw = vdf::resize_wavestream_waves_box(w, g.x0, g.bw, ctx->wavestream_knob);
             // (a launch per range: ranges shared by fewer than four clips - a launch would leave most CUs idle - and the ranges beyond sixteen
             // are left to the gather kernel)
             if (nw && g.ids.size() >= 4 && boxes.size() < 16) {
@@ -895,7 +896,7 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
     VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(n_clips, frames_per_clip)));
     VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
-                                       ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream));
+                                       ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream, ctx->lb_side_strips));
     std::vector<uint32_t> crops(n_clips * 4);
     VDF_HIP(ctx, hipMemcpyAsync(crops.data(), ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
@@ -908,7 +909,7 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                                      size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations,
                                      size_t n_ref, uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits,
-                                     uint64_t capacity, uint64_t *n_hits, hipStream_t s)
+                                     uint64_t capacity, uint64_t *n_hits, hipStream_t s, vdf_ctx::HostHits *staging)
 {
     ctx->stats = vdf_search_stats{};
     ctx->timing = vdf_search_timing{};
@@ -932,7 +933,7 @@ int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const
         ctx->stats = vdf_search_stats{};
         rc = search_core(ctx, 1, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations,
                          ctx->perm.as<uint32_t>(), n_ref, tol_int, 0, 1, 0, 0xFFFFFFFFu, nullptr, ref_index_base, hits,
-                         capacity, n_hits, &overflow_row, s);
+                         capacity, n_hits, &overflow_row, s, false, staging);
         if (rc) { ctx->cand_scale = 1; return rc; }
         if (*n_hits > capacity) { ctx->cand_scale = 1; return fail(ctx, VDF_E_OVERFLOW, "hit buffer too small; *n_hits holds the required size"); }
         if (overflow_row == 0xFFFFFFFFu) break;  // complete
@@ -986,8 +987,6 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
         long c = std::atol(s);
         if (c >= 32 && c <= (1 << 22)) ctx->mfma_chunk_cols = (uint32_t)c;
     }
-    if (const char *s = std::getenv("VDF_MFMA_XCD_STRIPE")) ctx->mfma_xcd_stripe = std::atoi(s) != 0;
-    if (const char *s = std::getenv("VDF_MFMA_KERNEL")) { const int v = std::atoi(s); if (v == 1 || v == 2) ctx->mfma_kernel = v; }
     if (const char *s = std::getenv("VDF_CAND_CAPACITY")) { const long v = std::atol(s); if (v >= 8 && v <= 0x40000000l) ctx->cand_capacity_override = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_SELF_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_self_rows = (uint32_t)v; }
     if (const char *s = std::getenv("VDF_MFMA_REFS_ROWS")) { const int v = std::atoi(s); if (v == 256 || v == 512) ctx->mfma_refs_rows = (uint32_t)v; }
@@ -998,6 +997,15 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
         if (c >= 1 && c <= (1 << 20)) ctx->mfma_group = (uint32_t)c;
     }
     if (const char *s = std::getenv("VDF_NO_HIT_FILTER")) ctx->no_hit_filter = std::atoi(s) != 0;
+    if (std::getenv("VDF_NO_WAVESTREAM")) ctx->wavestream_knob = -1;
+    else if (const char *s = std::getenv("VDF_WAVESTREAM_NW")) { const int v = std::atoi(s); if (v >= 3 && v <= 8) ctx->wavestream_knob = v; }
+    ctx->no_rowcrop = std::getenv("VDF_NO_ROWCROP") != nullptr;
+    ctx->rowcrop_all = std::getenv("VDF_ROWCROP_ALL") != nullptr;
+    ctx->no_boxstream = std::getenv("VDF_NO_BOXSTREAM") != nullptr;
+    if (std::getenv("VDF_LB_NC16")) ctx->lb_side_strips = 16;
+    if (const char *s = std::getenv("VDF_COPY_THREADS")) { const int v = std::atoi(s); if (v >= 1 && v <= 64) ctx->copy_threads = v; }
+    if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) { const long v = std::atol(s); if (v >= 1 && v <= 1024) ctx->host_chunk_bytes = (size_t)v << 20; }
+    if (const char *s = std::getenv("VDF_HOST_DIRECT")) ctx->host_direct = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {
         int v = std::atoi(s);
@@ -1034,11 +1042,10 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     while (row_begin < n) {
         const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
         int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
-            if (d->host_hits.size() < capacity && !d->host_hits.resize(capacity)) return fail(d, VDF_E_OOM, "hit staging");
             return search_core(d, 0, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n, d->up_hashes.as<uint64_t>(),
                                d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
-                               use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, d->host_hits.data(), capacity,
-                               &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/G == 1);
+                               use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, nullptr, capacity,
+                               &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/G == 1, &d->host_hits);
         });
         if (rc) { vdf_groups_free(out); return rc; }
         uint32_t overflow_row = 0xFFFFFFFFu;
@@ -1151,11 +1158,10 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         if (ref_cnt[(size_t)k] == 0) return (int)VDF_OK;
         uint64_t capacity = capacity0;
         for (int attempt = 0; attempt < 6; attempt++) {
-            if (d->host_hits.size() < capacity && !d->host_hits.resize(capacity)) return fail(d, VDF_E_OOM, "hit staging");
             int r = search_refs_device_locked(d, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n_cand,
                                               d->up_ref_hashes.as<uint64_t>(), d->up_ref_dur.as<uint32_t>(),
-                                              ref_cnt[(size_t)k], tol_int, (uint32_t)ref_base[(size_t)k], d->host_hits.data(),
-                                              capacity, &d->r_n_hits, d->stream);
+                                              ref_cnt[(size_t)k], tol_int, (uint32_t)ref_base[(size_t)k], nullptr,
+                                              capacity, &d->r_n_hits, d->stream, &d->host_hits);
             if (r == VDF_E_OVERFLOW && d->r_n_hits > capacity) { capacity = d->r_n_hits; continue; }  // every hit is output: size up
             return r;
         }
@@ -1241,6 +1247,7 @@ int vdf_ctx_last_search_stats(const vdf_ctx *ctx, vdf_search_stats *out)
 }
 
 long long vdf_live_device_bytes(void) { return g_live_device_bytes.load(); }
+long long vdf_live_pinned_bytes(void) { return g_live_pinned_bytes.load(); }
 
 int vdf_ctx_last_search_timing(const vdf_ctx *ctx, vdf_search_timing *out)
 {
@@ -1335,7 +1342,7 @@ int vdf_cropdetect_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_
     for (size_t c0 = 0; c0 < n_clips; c0 += kMaxClipsPerLaunch)
         VDF_HIP(ctx, vdf::launch_letterbox(d_frames + c0 * clip_stride, std::min(kMaxClipsPerLaunch, n_clips - c0),
                                            frames_per_clip, w, h, frame_stride, clip_stride, d_crops + 4 * c0, ctx->crop_work.as<uint32_t>(),
-                                           stream ? (hipStream_t)stream : ctx->stream));
+                                           stream ? (hipStream_t)stream : ctx->stream, ctx->lb_side_strips));
     return VDF_OK;
 }
 
@@ -1444,8 +1451,8 @@ int vdf_sort_order_device(vdf_ctx *ctx, const uint32_t *d_durations, const uint3
     if (!d_durations || !d_perm_out) return fail(ctx, VDF_E_INVAL, "null pointer");
     if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
     VDF_HIP(ctx, hipSetDevice(ctx->device));
-    VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_order_scratch_bytes((uint32_t)n, d_path_rank != nullptr)));
-    VDF_HIP(ctx, vdf::launch_sort_order(d_durations, d_path_rank, (uint32_t)n, d_perm_out, ctx->sort_scratch.p, ctx->sort_scratch.cap,
+    VDF_HIP(ctx, ctx->sort_scratch_pub.reserve(vdf::sort_order_scratch_bytes((uint32_t)n, d_path_rank != nullptr)));
+    VDF_HIP(ctx, vdf::launch_sort_order(d_durations, d_path_rank, (uint32_t)n, d_perm_out, ctx->sort_scratch_pub.p, ctx->sort_scratch_pub.cap,
                                         stream ? (hipStream_t)stream : ctx->stream));
     return VDF_OK;
 }

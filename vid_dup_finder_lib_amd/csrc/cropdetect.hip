@@ -462,7 +462,7 @@ size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip)
 }
 
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
-                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream)
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream, int side_strips)
 {
     if (n_clips == 0) return hipSuccess;
     const uint32_t nf = frames_per_clip < VDF_DCT_SIZE ? frames_per_clip : VDF_DCT_SIZE;  // the builder keeps 16 frames
@@ -484,7 +484,7 @@ hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t fram
         const size_t want = std::min<size_t>(n_frames, (size_t)cus * per_cu);
         return (uint32_t)((want + kWorkLists - 1) / kWorkLists * kWorkLists);
     };
-    if (h >= 512 && !std::getenv("VDF_LB_NC16"))
+    if (h >= 512 && side_strips != 16)
         hipLaunchKernelGGL(letterbox_sides_kernel<32>, dim3(grid_for(4)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
                            work, n_frames);
     else if (h >= 256)

@@ -1118,9 +1118,11 @@ __global__ __launch_bounds__(64 * NW) void resize_mfma_frame_wavestream_kernel(c
             const v4i avh = geo.av[(rg * 2 + 0) * 64 + lane], avl = geo.av[(rg * 2 + 1) * 64 + lane];
             // This wave's own block has landed once the two fragments have: they were requested AFTER its DMA and VMEM returns in
             // order.  An empty asm that reads them makes the COMPILER place the vmcnt wait here and know the fragments are in -
-            // with a hand-written s_waitcnt it kept its own wait in front of the vertical products below, i.e. behind the NEXT
-            // block's DMA, and the next fragments' load latency was exposed every block.
-            asm volatile("" ::"v"(avh), "v"(avl) : "memory");
+            // with a hand-written s_waitcnt ALONE it kept its own wait in front of the vertical products below, i.e. behind the NEXT
+            // block's DMA, and the next fragments' load latency was exposed every block.  The explicit vmcnt(0) inside the same asm
+            // costs nothing (nothing else of this wave is in flight here) and no longer leaves the block's arrival to the order the
+            // compiler happens to keep between the DMA and the two loads (tools/check_isa_barriers.py looks for it in every instantiation).
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(avh), "v"(avl) : "memory");
             v4i ah = zero4, al = {bias_h, bias_h, bias_h, bias_h};
             const uint8_t *base = reinterpret_cast<const uint8_t *>(my) + r16 * Wp + 16u * g;
             auto tile = [&](int kt) __attribute__((always_inline)) {
@@ -1231,7 +1233,7 @@ static hipError_t launch_wavestream(const uint8_t *frames, size_t n_clips, uint3
                                     const MfmaResizeArgs &a, const CropStreamClip *clips, const CropStreamTable *tables, uint8_t *small,
                                     hipStream_t stream, uint32_t box_w, uint32_t x0)
 {
-    const int nw = resize_wavestream_waves_box(w, x0, box_w);
+    const int nw = resize_wavestream_waves_box(w, x0, box_w, a.wavestream_knob);
     if (n_clips * 16 > 0xFFFFFFFFull || (uint64_t)w * h >= (1ull << 31) || !a.band_meta || nw == 0 || (box_w != w && !clips) || (uint64_t)x0 + box_w > w)
         return hipErrorInvalidValue;
     if (!resize_wavestream_table_fits(nw, a.band_stride)) return hipErrorInvalidValue;
@@ -1272,8 +1274,8 @@ hipError_t launch_resize_mfma_frames_stream(const uint8_t *frames, size_t n_clip
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t n_frames = (uint32_t)(n_clips * 16);
-    if (resize_stream_wants_band(w) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
-    if (resize_wavestream_applies(w))
+    if (resize_stream_wants_band(w, a.wavestream_knob) != (a.band_meta != nullptr)) return hipErrorInvalidValue;  // the caller picks the table form by resize_stream_wants_band
+    if (resize_wavestream_applies(w, a.wavestream_knob))
         return launch_wavestream(frames, n_clips, w, h, frame_stride, clip_stride, a, clips, tables, small, stream, w, 0);
     if (cls != 1 || a.band_meta) return hipErrorInvalidValue;  // the chunk form serves the S class only (frames up to 512 wide, two workgroups per CU)
     launch_stream_mode(std::min<uint32_t>(n_frames, (uint32_t)cus * 2u), stream, frames, w, h, frame_stride, clip_stride, n_frames, make_tables(a),
@@ -1795,14 +1797,7 @@ hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_
                            const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    size_t pad = 0;
-#ifdef VDF_BENCH_ABLATE  // occupancy experiment: unused dynamic LDS limits the workgroups per CU (VDF_DCT_LDS_PAD bytes)
-    if (const char *e = std::getenv("VDF_DCT_LDS_PAD")) {
-        pad = (size_t)std::atol(e);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dct_hash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-    }
-#endif
-    hipLaunchKernelGGL(dct_hash_kernel, dim3((uint32_t)n_clips), dim3(256), pad, stream, small, small_clip_stride,
+    hipLaunchKernelGGL(dct_hash_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, small, small_clip_stride,
                        small_frame_stride, cos_table, out_hashes, out_dontcare);
     return hipGetLastError();
 }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(const uint32_t *__rest
 __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__restrict__ tile_first,
                                                           const uint32_t *__restrict__ tile_count, uint32_t n_row_tiles,
                                                           uint32_t group_size, uint32_t shard_count,
-                                                          uint32_t xcd_stripe, uint32_t *__restrict__ group_cmin,
+                                                          uint32_t *__restrict__ group_cmin,
                                                           uint32_t *__restrict__ group_blocks)
 {  // one workgroup per group: chunk range covered by its row tiles; only every shard_count-th tile is this rank's
     __shared__ uint32_t s_min[4], s_max[4];
@@ -216,8 +216,7 @@ __global__ __launch_bounds__(256) void group_tiles_kernel(const uint32_t *__rest
         cmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (cmax <= cmin) { cmin = 0; cmax = 0; }
         group_cmin[g] = cmin;
-        uint32_t n_chunks = cmax - cmin;
-        if (xcd_stripe) n_chunks = (n_chunks + 7u) & ~7u;  // whole rounds of 8 chunks: workgroup id % 8 = chunk % 8 = XCD
+        const uint32_t n_chunks = cmax - cmin;
         group_blocks[g] = n_chunks * ((group_size + shard_count - 1) / shard_count);
     }
 }
@@ -332,30 +331,29 @@ __global__ __launch_bounds__(256) void hamming_tile_kernel(
 }
 
 // ---- exact Hamming distances on the matrix cores ---------------------------------------------------------
-// With every hash bit encoded as a +-1 fp4 value (e2m1: 0x2 = +1.0, 0xA = -1.0) the dot product of two hashes is
-// (#equal bits) - (#different bits) = 1024 - 2 * hamming, an integer <= 1024 that f32 accumulation represents
-// exactly, so  hamming <= tol  <=>  dot >= 1024 - 2 tol  bit for bit.  v_mfma_scale_f32_32x32x64_f8f6f4 (both
-// operands fp4, unit E8M0 scales) evaluates 32 x 32 pairs x 64 bit positions per instruction; measured
-// 15 ns per instruction per SIMD (tools/ubench_mfma.hip) = 4.4e12 pairs/s chip-wide, 7x the VALU issue ceiling
-// of the XOR + popcount formulation (tools/ubench_valu.hip).  Layout probed with exact data
-// (tools/probe_mfma_fp4.hip): A row / B col = lane & 31, k-group = lane >> 5 (32 nibbles = 16 B per lane),
+// With every hash bit encoded as an fp4 value (e2m1: bit 0 -> 0x0 = 0.0, bit 1 -> 0x2 = +1.0) the dot product of two hashes
+// is popcount(a & b), an integer <= 1024 that f32 accumulation represents exactly, and
+// hamming = pop(a) + pop(b) - 2 dot  bit for bit.  v_mfma_f32_32x32x64_f8f6f4 (both operands fp4) evaluates 32 x 32 pairs
+// x 64 bit positions per instruction; measured 15 ns per instruction per SIMD (tools/ubench_mfma.hip) = 4.4e12 pairs/s
+// chip-wide, 7x the VALU issue ceiling of the XOR + popcount formulation (tools/ubench_valu.hip).  Layout probed with exact
+// data (tools/probe_mfma_fp4.hip): A row / B col = lane & 31, k-group = lane >> 5 (32 nibbles = 16 B per lane),
 // C row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), C col = lane & 31.
+// (Round 1's kernel encoded the bits as +-1 - dot = 1024 - 2 hamming - and tested inside the stream; round 2's {0, 1} form
+// below replaced it - 10 % less energy per MFMA at the chip's power cap, tools/ubench_mfma_energy.hip - and it was deleted
+// in round 4: DESIGN.md 4.2 keeps its measurements.)
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 // packed [n][32] u32  ->  expanded [n_pad][32 chunks][16 B]: chunk d = the 32 nibbles of packed dword d
 // (nibble q <-> bit q).  Rows n .. n_pad are zero (fp4 +0.0: dot 0, never inside a window).
-// mode01 = 0: bit 0 -> 0x2 (+1.0), bit 1 -> 0xA (-1.0): dot = 1024 - 2 hamming (first kernel).
-// mode01 = 1: bit 0 -> 0x0 (0.0), bit 1 -> 0x2 (+1.0): dot = popcount(a & b), hamming = pop(a) + pop(b) - 2 dot.  Same exact
-//   integers, but three quarters of the products are zero and nothing is negative: measured 10 % less time per MFMA at
-//   the chip's power cap (tools/ubench_mfma_energy.hip), which is what bounds this kernel.  The popcounts the threshold
-//   then needs are written here: pop[h] over all 1024 bits, popk[h] over the bits the first k_steps k-steps of the kernel
-//   cover (k-step s multiplies packed dwords s and 16 + s: the two halves of the wave take chunks s and 16 + s),
-//   and popkT = popk transposed inside groups of 128 hashes ([group][h & 31][(h >> 5) & 3]) so that a lane fetches the
-//   values of its column in the four 32-column sub-tiles of a stage with one 16-byte load.
+// Bit 0 -> 0x0 (0.0), bit 1 -> 0x2 (+1.0): three quarters of the products are zero and nothing is negative.  The popcounts
+// the threshold needs are written here: pop[h] over all 1024 bits, popk[h] over the bits the first k_steps k-steps of the
+// kernel cover (k-step s multiplies packed dwords s and 16 + s: the two halves of the wave take chunks s and 16 + s),
+// and popkT = popk transposed inside groups of 128 hashes ([group][h & 31][(h >> 5) & 3]) so that a lane fetches the
+// values of its column in the four 32-column sub-tiles of a stage with one 16-byte load.
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ packed, uint32_t n,
-                                                        uint32_t n_pad, uint4 *__restrict__ expanded, int mode01,
+                                                        uint32_t n_pad, uint4 *__restrict__ expanded,
                                                         uint32_t k_steps, float *__restrict__ pop,
                                                         float *__restrict__ popk, float *__restrict__ popkT)
 {
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
             x = (x | (x << 12)) & 0x000F000Fu;
             x = (x | (x << 6)) & 0x03030303u;
             x = (x | (x << 3)) & 0x11111111u;
-            o[j] = mode01 ? (x << 1) : ((x << 3) | 0x22222222u);
+            o[j] = x << 1;
         }
         out = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -391,264 +389,9 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
     }
 }
 
-constexpr uint32_t kMfmaWaves = VDF_MFMA_WAVES;                          // waves per workgroup sharing one staged candidate tile
-constexpr int kRowTiles = VDF_ROW_TILES;                                // 32-row MFMA tiles per wave (A operand: 64 VGPRs each)
-#ifndef VDF_PF
-#define VDF_PF (kRowTiles == 1 ? 4 : 6)
-#endif
-constexpr int kPrefetch = VDF_PF;           // LDS fragments in flight ahead of the MFMAs
-constexpr uint32_t kMfmaTileRows = 32 * kRowTiles * kMfmaWaves;
-#ifndef VDF_MFMA_SUB
-#define VDF_MFMA_SUB (VDF_MFMA_WAVES >= 8 ? 4 : 2)  // 8 waves = one workgroup per CU: 2 x 64 KB of LDS stages fit
-#endif
-constexpr uint32_t kMfmaSub = VDF_MFMA_SUB;                     // 32-column sub-tiles per LDS stage
-#ifndef VDF_DMA_SUBS
-#define VDF_DMA_SUBS 1
-#endif
-constexpr uint32_t kDmaSubs = VDF_DMA_SUBS;          // leading sub-tiles of a stage that carry the next stage's DMA pieces
-constexpr uint32_t kMfmaColStep = 32 * kMfmaSub;     // candidates per LDS stage (one barrier per stage)
-
-// ABLATE (timing experiments only; != 0 reports no hits at all): 1 = hit test off, 2 = no DMA after the first stage,
-// 3 = no DMA and no barrier, 4 = no LDS reads (B fragments stay in registers; DMA and barrier kept), 5 = no LDS reads,
-// no DMA, no barrier (the bare MFMA stream inside the kernel's workgroup structure), 6 = every other DMA piece only,
-// 7 = all DMA pieces but 4 bytes per lane instead of 16 (same instruction count, a quarter of the data).
-// CHK (< 15): early exit.  A Hamming distance only grows as more bit positions are counted, so if after k-steps 0..CHK
-// (64 (CHK + 1) bits) every pair of the wave's 32 x 32 blocks is already MORE than `tol` apart, none can be a hit and the
-// remaining 15 - CHK steps are skipped - exact for any data.  Unrelated hashes sit at (bits / 2) +- sqrt(bits) / 2, so at
-// tolerance 350 the test after 832 bits (CHK = 12) passes for ~99.8 % of the blocks and saves 3 of 16 MFMA steps; blocks that
-// do contain a near pair simply run to the end.  The host picks CHK from the tolerance (16 = no test).
-template <int ABLATE, int CHK>
-__global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles == 2 ? 2 : 1)) void hamming_mfma_kernel(
-    const uint4 *__restrict__ row_exp, const uint32_t *__restrict__ row_perm, uint32_t n_rows,
-    uint32_t row_index_base, const uint4 *__restrict__ col_exp, const uint32_t *__restrict__ row_lo,
-    const uint32_t *__restrict__ row_hi, const uint32_t *__restrict__ tile_lo, const uint32_t *__restrict__ tile_hi,
-    const uint32_t *__restrict__ tile_first, const uint32_t *__restrict__ tile_count,
-    const uint32_t *__restrict__ group_offset, const uint32_t *__restrict__ group_cmin, uint32_t n_groups,
-    uint32_t group_size, uint32_t shard_index, uint32_t shard_count, uint32_t n_row_tiles, uint32_t chunk_cols,
-    uint32_t tol,
-    const uint32_t *__restrict__ matched, int self_mode, vdf_hit *__restrict__ hits, unsigned long long capacity,
-    unsigned long long *__restrict__ counters, uint32_t *__restrict__ overflow_row, uint32_t block_base,
-    uint32_t xcd_stripe)
-{
-    constexpr bool kNoLds = ABLATE == 4 || ABLATE == 5;
-    const uint32_t bid = blockIdx.x + block_base;  // grids above 2^32 work-items are launched in slices
-    // 2 x 32 KB stages, [col][chunk ^ col] swizzled.  Two separate arrays (not s_b[2][..]) on purpose: the compiler
-    // then knows a DMA into one never aliases an LDS read of the other and does not wait on vmcnt before the reads.
-    __shared__ __attribute__((aligned(16))) uint4 s_b0[kMfmaColStep * 32];
-    __shared__ __attribute__((aligned(16))) uint4 s_b1[kMfmaColStep * 32];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c31 = lane & 31;
-    const uint32_t wave = tid >> 6;
-
-    // workgroup -> (group, chunk, row tile in group): chunk-major inside a group
-    const_u32_ptr goff = (const_u32_ptr)(uintptr_t)group_offset;
-    uint32_t gl = 0, gh = n_groups;
-    while (gh - gl > 1) {
-        const uint32_t mid = (gl + gh) >> 1;
-        if (goff[mid] <= bid) gl = mid; else gh = mid;
-    }
-    const uint32_t idx = bid - goff[gl];
-    // this rank's tiles of the group: t = t0, t0 + shard_count, ... (t % shard_count == shard_index)
-    const uint32_t per_group = (group_size + shard_count - 1) / shard_count;
-    const uint32_t g0 = gl * group_size;
-    const uint32_t t0 = g0 + (shard_index + shard_count - g0 % shard_count) % shard_count;
-    // Workgroups go to the 8 XCDs round-robin by id, and each XCD has its own L2.  Chunk-major order alone makes all 8
-    // stream the SAME chunk at the same time (8 copies in 8 L2s); striped, workgroup id % 8 selects one of 8 ADJACENT
-    // chunks, so an XCD's resident workgroups share one chunk and no two XCDs cache the same candidates.  Adjacent chunks
-    // have nearly the same number of valid row tiles, so the XCDs stay balanced.
-    const uint32_t k = xcd_stripe ? idx >> 3 : idx;
-    const uint32_t t = t0 + (k % per_group) * shard_count;
-    const uint32_t chunk = ((const_u32_ptr)(uintptr_t)group_cmin)[gl] + (xcd_stripe ? 8u * (k / per_group) + (idx & 7u) : k / per_group);
-    if (t >= n_row_tiles || t >= g0 + group_size) return;
-    {
-        const uint32_t f = ((const_u32_ptr)(uintptr_t)tile_first)[t], cnt = ((const_u32_ptr)(uintptr_t)tile_count)[t];
-        if (chunk < f || chunk >= f + cnt) return;
-    }
-    const uint32_t t_lo = ((const_u32_ptr)(uintptr_t)tile_lo)[t];
-    const uint32_t t_hi = ((const_u32_ptr)(uintptr_t)tile_hi)[t];
-    const uint32_t c_begin = max(chunk * chunk_cols, t_lo);
-    const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
-    if (c_begin >= c_end) return;
-
-    // targets: 2 row tiles of 32 per wave, all 16 k-steps (32 chunks of 16 B per hash: lane group g takes chunks 16 g ..)
-    const uint32_t row0 = t * kMfmaTileRows + wave * (32 * kRowTiles);
-    v4i a[kRowTiles][16];
-#pragma unroll
-    for (int rt = 0; rt < kRowTiles; rt++) {
-        const uint32_t p = row0 + 32 * rt + c31;
-        uint32_t src = p;
-        if (p < n_rows && row_perm) src = row_perm[p];
-        const uint4 *rp = row_exp + (size_t)src * 32 + 16 * g;  // rows >= n_rows read the zero padding
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const uint4 v = rp[s];
-            a[rt][s] = (v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-        }
-    }
-    const float thresh = 1024.0f - 2.0f * (float)min(tol, 1024u);
-    const float thresh_chk = 64.0f * (float)(CHK + 1) - 2.0f * (float)min(tol, 1024u);  // partial dot >= this <=> partial distance <= tol
-
-    // stage loader: a stage is kMfmaColStep columns of 32 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col
-    // of that column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged by
-    // LDS-DMA (buffer_load ... lds): the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane
-    // SOURCE offset; no VGPRs are spent and nothing waits until the barrier that publishes the stage.
-    const uint32_t cb0 = c_begin & ~(kMfmaColStep - 1);
-    constexpr int kDmaPerWave = (int)(kMfmaColStep * 32 / (64 * kMfmaWaves));  // 1 KB DMA instructions per wave per stage
-    // Piece i of this wave fills LDS slots L = 64 W i + 64 wave + lane (W waves): column c = 2 W i + c0 with
-    // c0 = 2 wave + g < 2 W, chunk q = lane & 31, source byte offset c * 512 + ((q ^ c) << 4).  Since c0 < 2 W,
-    // q ^ c = (q ^ c0) ^ (2 W i & 31): 16 / W per-lane offsets cover all pieces, the 1024 W i part is wave-uniform.
-    constexpr uint32_t kColsPerRound = 2 * kMfmaWaves;
-    constexpr int kOffsets = 32 / kColsPerRound;
-    static_assert(kOffsets >= 1 && (kOffsets & (kOffsets - 1)) == 0, "piece addressing");
-    const uint32_t c0 = 2 * wave + g;
-    uint32_t lane_off[kOffsets];
-#pragma unroll
-    for (int j = 0; j < kOffsets; j++) lane_off[j] = c0 * 512u + ((((lane & 31) ^ c0) << 4) ^ (16u * kColsPerRound * j));
-    // buffer_load ... lds (MUBUF), not global_load_lds: after a FLAT-encoded LDS-DMA the compiler assumes lgkmcnt may
-    // complete out of order and drains every outstanding ds_read with lgkmcnt(0) before the next MFMA.
-    // The resource covers one stage (base = wave-uniform stage address, rebuilt with SALU per stage).
-    auto stage_rsrc = [&](uint32_t cb) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(col_exp) + (size_t)cb * 512), 0, kMfmaColStep * 512u, 0x00020000);
-    };
-    auto load_piece = [&](__amdgpu_buffer_rsrc_t rs, uint4 *dst, int i) __attribute__((always_inline)) {
-        if (ABLATE == 6 && (i & 1)) return;
-        auto *lds = (__attribute__((address_space(3))) void *)&dst[64 * kMfmaWaves * i + 64 * wave];
-        const int voff = (int)lane_off[i & (kOffsets - 1)], soff = (int)(512u * kColsPerRound * (uint32_t)i);
-        if constexpr (ABLATE == 7) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 4, voff, soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
-    };
-    // one stage: MFMAs over the 64 candidates in `cur` while the next stage's DMA pieces go out to `nxt`
-    uint32_t n_early = 0;  // sub-tiles (32 columns x this wave's 32 kRowTiles rows) that took the early exit
-    auto run_stage = [&](uint32_t cb, const uint4 *cur, uint4 *nxt) __attribute__((always_inline)) {
-        // The next stage's DMA pieces are issued one at a time between the MFMAs of sub-tile 0 (a 1 KB piece costs the
-        // issuing wave 60-185 cycles when bunched with the LDS reads at the top of a stage).  Branch-free so that the
-        // pinned schedule stays one region: the last stage re-fetches itself into the idle buffer.
-        const __amdgpu_buffer_rsrc_t rs_next = stage_rsrc(cb + kMfmaColStep < c_end ? cb + kMfmaColStep : cb);
-#pragma unroll
-        for (uint32_t sub = 0; sub < kMfmaSub; sub++) {
-        if (cb + 32u * sub >= c_end) break;
-        v16f acc[kRowTiles];
-#pragma unroll
-        for (int rt = 0; rt < kRowTiles; rt++) acc[rt] = v16f{};
-        // LDS fragment reads run kPrefetch steps ahead of the MFMAs that consume them (bounded so that 128 A + 32 C +
-        // 4 kPrefetch B registers stay under the 256-VGPR budget of 2 waves per SIMD without spills)
-        const uint32_t lds_row = (32u * sub + c31) << 5;
-        uint4 bq[kPrefetch];
-#pragma unroll
-        for (int s = 0; s < kPrefetch; s++) {
-            if (kNoLds) bq[s] = make_uint4((uint32_t)a[0][s].x, (uint32_t)a[0][s].y, (uint32_t)a[0][s].z, (uint32_t)a[0][s].w);
-            else bq[s] = cur[lds_row | ((uint32_t)(s + 16 * g) ^ c31)];
-        }
-        if (!kNoLds) __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);  // keep the prologue of LDS reads up front
-        constexpr int kFirst = CHK < 15 ? CHK + 1 : 16;  // k-steps before the early-exit test; later fragments are only read
-                                                         // if the block has to run to the end (rare)
-        auto k_step = [&](int s, int limit) __attribute__((always_inline)) {  // limit: fragments >= limit are not prefetched
-            const uint4 bv = bq[s % kPrefetch];
-            const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
-#pragma unroll
-            for (int rt = 0; rt < kRowTiles; rt++) {
-                const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
-                acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 127, 0, 127);
-            }
-            if (!kNoLds && s + kPrefetch < limit) bq[s % kPrefetch] = cur[lds_row | ((uint32_t)(s + kPrefetch + 16 * g) ^ c31)];
-            constexpr int kDmaEvery = 16 * kDmaSubs / kDmaPerWave;
-            const bool dma_here = (ABLATE < 2 || ABLATE == 4 || ABLATE >= 6) && sub < kDmaSubs && (16 * (int)sub + s) % kDmaEvery == 0;
-            if (dma_here) load_piece(rs_next, nxt, (16 * (int)sub + s) / kDmaEvery);
-            // pin the software pipeline: the scheduler otherwise sinks each LDS read next to its MFMA (1-2 deep)
-            __builtin_amdgcn_sched_group_barrier(0x008, kRowTiles, 0);
-            if (!kNoLds && s + kPrefetch < limit) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (dma_here) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        };
-#pragma unroll
-        for (int s = 0; s < kFirst; s++) k_step(s, kFirst);
-        if (CHK < 15) {
-            float pm = acc[0][0];
-#pragma unroll
-            for (int rt = 0; rt < kRowTiles; rt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) pm = fmaxf(pm, acc[rt][r]);
-            if (__builtin_amdgcn_ballot_w64(pm >= thresh_chk) == 0ull) {
-                // no pair of these blocks can end within tol: skip the rest, but not the DMA pieces it would have issued
-                n_early += 1;
-#pragma unroll
-                for (int s = kFirst; s < 16; s++) {
-                    constexpr int kDmaEvery = 16 * kDmaSubs / kDmaPerWave;
-                    if ((ABLATE < 2 || ABLATE == 4 || ABLATE >= 6) && sub < kDmaSubs && (16 * (int)sub + s) % kDmaEvery == 0)
-                        load_piece(rs_next, nxt, (16 * (int)sub + s) / kDmaEvery);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int f = kFirst; f < 16 && f < kFirst + kPrefetch; f++)
-                if (!kNoLds) bq[f % kPrefetch] = cur[lds_row | ((uint32_t)(f + 16 * g) ^ c31)];
-#pragma unroll
-            for (int s = kFirst; s < 16; s++) k_step(s, 16);
-        }
-        float m = acc[0][0];
-#pragma unroll
-        for (int rt = 0; rt < kRowTiles; rt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) m = fmaxf(m, acc[rt][r]);
-        if (ABLATE >= 1) { asm volatile("" ::"v"(m)); m = -2048.0f; }
-        if (__builtin_amdgcn_ballot_w64(m >= thresh) != 0ull) {
-            // rare path: window, consumption bitmap, append.  Lane holds column j = cb + c31, rows per C layout.
-            const uint32_t j = cb + 32u * sub + c31;
-            bool col_ok = j >= c_begin && j < c_end;
-            if (col_ok && matched) col_ok = ((matched[j >> 5] >> (j & 31)) & 1u) == 0u;
-#pragma unroll
-            for (int rt = 0; rt < kRowTiles; rt++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float d = acc[rt][r];
-                    if (col_ok && d >= thresh) {
-                        const uint32_t p = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        const uint32_t lo = row_lo[p], hi = row_hi[p];
-                        if (j >= lo && j < hi) {
-                            const uint32_t src = row_perm ? row_perm[p] : p;
-                            bool ok = true;
-                            if (self_mode && matched) ok = ((matched[src >> 5] >> (src & 31)) & 1u) == 0u;
-                            if (ok) {
-                                const unsigned long long idx = atomicAdd(&counters[0], 1ull);
-                                if (idx < capacity) {
-                                    vdf_hit hp; hp.row = row_index_base + src; hp.col = j;
-                                    hits[idx] = hp;
-                                } else {
-                                    atomicMin(overflow_row, row_index_base + src);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        }
-        if (ABLATE < 3 || ABLATE == 4 || ABLATE >= 6) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
-            __syncthreads();  // the DMA has landed (every wave waited for its own pieces) and every wave is done with `cur`
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < kDmaPerWave; i++) load_piece(stage_rsrc(cb0), s_b0, i);
-    // Retire the target loads here: otherwise the loop header inherits "a[] may still be in flight" from this path and
-    // the MFMAs inside the loop wait on vmcnt(0), i.e. on the DMA pieces issued just before them.
-#pragma unroll
-    for (int rt = 0; rt < kRowTiles; rt++)
-#pragma unroll
-        for (int s = 0; s < 16; s++) asm volatile("" ::"v"(a[rt][s]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
-    __syncthreads();
-    for (uint32_t cb = cb0; cb < c_end; cb += 2 * kMfmaColStep) {
-        run_stage(cb, s_b0, s_b1);
-        if (cb + kMfmaColStep >= c_end) break;
-        run_stage(cb + kMfmaColStep, s_b1, s_b0);
-    }
-    if (tid == 0) atomicAdd(&counters[1], (unsigned long long)(c_end - c_begin) * kMfmaTileRows);
-    if (CHK < 15 && lane == 0 && n_early) atomicAdd(&counters[3], (unsigned long long)n_early * (32u * 32u * kRowTiles));
-}
-
 // ---- second-generation MFMA search kernel ----------------------------------------------------------------------
 // Two findings of round 2 shape it (profiles/r02_*, DESIGN.md "Hamming search"):
-//  (1) The first kernel does not run at the matrix pipe's issue rate but at the chip's POWER cap: a stream with 87 % pipe
+//  (1) Round 1's kernel (+-1 encoding, test inside the stream) did not run at the matrix pipe's issue rate but at the chip's POWER cap: a stream with 87 % pipe
 //      utilisation and one with 81 % take the same wall time, the chip just holds a lower clock.  What decides pairs/s is
 //      the energy per pair, and that depends on the operand VALUES: with hash bits encoded as {0, 1} instead of {-1, +1}
 //      (dot = popcount(a & b); three quarters of the products are zero, nothing is negative) the same MFMA stream takes
@@ -665,10 +408,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, (kRowTiles == 1 ? 4 : kRowTiles ==
 //      Each B fragment is read from LDS twice (once per row tile: 1 ds_read_b128 per MFMA, half of what the LDS array
 //      sustains).  The test only sets a bit in a scalar mask; flagged blocks (they may contain a pair within the
 //      tolerance: ~0.3 % on unrelated hashes) are evaluated over all 1024 bits at the end of the stage - operands from
-//      the LDS image and the target registers - where window / consumption bitmap / append are applied as in the first
+//      the LDS image and the target registers - where window / consumption bitmap / append are applied as in the VALU
 //      kernel's slow path.  LDS reads run P fragments ahead in ONE stream across block boundaries; sched_barrier(0)
 //      between slots makes the source order the schedule.
-// Exactness is unchanged: a block is skipped only if every pair in it is already more than `tol` apart after 64 K bits.
+// CHK (< 15) is the exact early exit: a Hamming distance only grows as more bit positions are counted, so if after k-steps
+// 0..CHK (64 (CHK + 1) bits) every pair of a 32 x 32 block is already MORE than `tol` apart, none can be a hit - exact for any
+// data.  Unrelated hashes sit at (bits / 2) +- sqrt(bits) / 2, so at tolerance 350 the test after 832 bits (CHK = 12) passes
+// for ~99.7 % of the blocks and saves 3 of 16 MFMA steps; the host picks CHK from the tolerance (16 = no test: K = 16).
 template <int N>
 struct IntC { static constexpr int value = N; };
 template <int I, int N, class F>
@@ -794,6 +540,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     uint32_t col_pad, CandEntry *__restrict__ cand, uint32_t cand_capacity, unsigned long long *__restrict__ cand_head)
 {
     constexpr int K = CHK < 15 ? CHK + 1 : 16;            // k-steps of the main stream (64 bit positions each)
+    // The row-term vectors (the C operand of a block's first MFMA: -paK / 2 of the block's 32 rows) take 32 registers if they are kept.
+    // Up to K = 13 (tolerance <= 0.357; 104 registers of target fragments) they are; the longer streams of larger tolerances (K = 14,
+    // 15, 16: 112 - 128 registers of targets, which spilled 6 - 9 VGPRs to scratch inside the stream) fetch them from LDS instead - a
+    // vector depends on (row tile, lane group) only: 256 B per wave - straight into the accumulator set of the NEXT block, in the four
+    // slots behind the test that last read it.
+    constexpr bool kRowcLds = K > 13;
     constexpr uint32_t kSub = WAVES >= 8 ? 4 : 2;         // 32-candidate sub-tiles per LDS stage
     constexpr uint32_t kColStep = 32 * kSub;
     constexpr int NBLK = 2 * (int)kSub;                   // blocks per stage and wave: (sub-tile, row tile)
@@ -801,7 +553,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
 #ifndef VDF_M2_P
 #define VDF_M2_P 4
 #endif
-    constexpr int P = VDF_M2_P, NB = P + 1;               // LDS fragments in flight / fragment buffers
+    constexpr int P = (K == 16 && WAVES >= 8) ? 2 : VDF_M2_P, NB = P + 1;  // LDS fragments in flight / fragment buffers (the full-length stream of the
+                                                                           // 512-row workgroup - 128 registers of targets, four thresholds - has room for two)
     constexpr uint32_t kTileRows = 64 * WAVES;
     constexpr int kDmaPerWave = (int)(kColStep * 32 / (64 * WAVES));  // 1 KB LDS-DMA pieces per wave and stage
 #ifndef VDF_M2_DMA_EVERY
@@ -817,7 +570,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 5, c31 = lane & 31;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // scalar: LDS-DMA targets (M0) need no VALU
 
-    // workgroup -> (group, chunk, row tile in group): chunk-major inside a group (as the first kernel)
+    // workgroup -> (group, chunk, row tile in group): chunk-major inside a group; this rank's tiles of the group are
+    // t0, t0 + shard_count, ... (t % shard_count == shard_index)
     const_u32_ptr goff = (const_u32_ptr)(uintptr_t)group_offset;
     uint32_t gl = 0, gh = n_groups;
     while (gh - gl > 1) {
@@ -841,14 +595,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     const uint32_t c_end = min((chunk + 1) * chunk_cols, t_hi);
     if (c_begin >= c_end) return;
 
-    // targets: 2 row tiles of 32 per wave, the K streamed k-steps in registers (the cleanup fetches the rest on demand:
-    // 24 VGPRs less at K = 13); their C-operand vectors -paK / 2 (C layout: register r of lane group g <-> row
-    // (r & 3) + 8 (r >> 2) + 4 g)
+    // targets: 2 row tiles of 32 per wave, the fragments of the K streamed k-steps in registers; their C-operand
+    // vectors -paK / 2 (C layout: register r of lane group g <-> row (r & 3) + 8 (r >> 2) + 4 g)
     const float tol_f = (float)min(tol, 1024u);
     const float *row_popk = row_pop3 + row_pad;
     const float *col_popkT = col_pop3 + 2 * (size_t)col_pad;
     const uint32_t row0 = t * kTileRows + wave * 64;
     v4i a[2][K];
+    const float4 *s_rc = nullptr;  // kRowcLds: [wave][row tile][lane group][4 x float4]
     v16f rowc[2];
     uint32_t live[2];  // bit r: the row of accumulator register r has a non-empty window in this launch (suspects of other rows are noise)
 #pragma unroll
@@ -871,7 +625,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             if (row_hi[pr] > row_lo[pr]) live[rt] |= 1u << r;  // the window arrays are padded to whole tiles
         }
     }
-    // LDS-DMA staging, identical to the first kernel: slot (col << 5 | q) holds chunk q ^ col of that column
+    if constexpr (kRowcLds) {  // the vectors go to LDS (one lane of each lane group writes; read back by this wave only, behind the barrier
+                               // in front of the stream) and their 32 registers are free for the longer stream's target fragments
+        __shared__ __attribute__((aligned(16))) float4 s_rowc[WAVES * 2 * 2 * 4];
+        float4 *mine = s_rowc + ((size_t)wave * 2 * 2 + g) * 4;
+        if (c31 == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    mine[rt * 2 * 4 + q] = float4{rowc[rt][4 * q], rowc[rt][4 * q + 1], rowc[rt][4 * q + 2], rowc[rt][4 * q + 3]};
+        }
+        s_rc = mine;
+    }
+    // Stage loader: a stage is kColStep columns of 32 chunks of 16 B; LDS slot L = (col << 5 | q) holds chunk q ^ col of that
+    // column (XOR swizzle: the 16-lane groups of ds_read_b128 then hit 16 different 4-bank groups).  Staged by LDS-DMA
+    // (buffer_load ... lds, MUBUF: after a FLAT-encoded LDS-DMA the compiler drains every outstanding ds_read with lgkmcnt(0)):
+    // the DMA writes LDS linearly (wave base + lane * 16), the swizzle goes on the per-lane SOURCE offset; no VGPRs are spent
+    // and nothing waits until the barrier that publishes the stage.  Piece i of this wave fills slots 64 W i + 64 wave + lane
+    // (W waves): column c = 2 W i + c0 with c0 = 2 wave + g < 2 W, chunk q = lane & 31, source byte offset c * 512 +
+    // ((q ^ c) << 4); since c0 < 2 W, q ^ c = (q ^ c0) ^ (2 W i & 31): 16 / W per-lane offsets cover all pieces
     const uint32_t cb0 = c_begin & ~(kColStep - 1);
     constexpr uint32_t kColsPerRound = 2 * WAVES;
     constexpr int kOffsets = 32 / kColsPerRound;
@@ -902,6 +675,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     };
 
     v16f acc[2] = {v16f{}, v16f{}};
+    if constexpr (kRowcLds) acc[0] = rowc[0];  // the stream's first block starts from its row term (the later ones fetch theirs from LDS)
     uint32_t n_early = 0;  // blocks that stopped after K steps
     const bool hi_half = wave >= WAVES / 2;
     (void)hi_half;
@@ -977,8 +751,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             const v8i b = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w, 0, 0, 0, 0};
             const v8i ar = {a[rt][s].x, a[rt][s].y, a[rt][s].z, a[rt][s].w, 0, 0, 0, 0};
             // scale operands 0 / 0: the compiler selects the unscaled opcode (same values as scales 2^0, probed)
-            if constexpr (s == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, rowc[rt], 4, 4, 0, 0, 0, 0);
-            else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 0, 0, 0);
+            if constexpr (s == 0 && !kRowcLds) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, rowc[rt], 4, 4, 0, 0, 0, 0);
+            else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 0, 0, 0);  // (kRowcLds: acc holds the row term at s == 0)
 #ifndef VDF_M2_ABL_NOLDS  // ablation: no LDS fragment reads in the stream (the first P fragments are reused)
             if constexpr (i + P < NM) fq[(i + P) % NB] = frag(i + P);
 #endif
@@ -1007,6 +781,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
 #endif
                     }
                 }
+            }
+            // kRowcLds: the other accumulator set is free once its test (slots kTestAt .. kTestAt + 3) is through; the next block - which
+            // accumulates into it - starts from the row term, a quarter of the vector per slot
+            if constexpr (kRowcLds && s >= kTestAt + 4 && s < kTestAt + 8) {
+                constexpr int q = s - (kTestAt + 4);
+                const float4 v = s_rc[((rt ^ 1) * 2) * 4 + q];
+                acc[rt ^ 1][4 * q + 0] = v.x; acc[rt ^ 1][4 * q + 1] = v.y; acc[rt ^ 1][4 * q + 2] = v.z; acc[rt ^ 1][4 * q + 3] = v.w;
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1139,7 +920,7 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, L.tile_count, L.n_row_tiles, L.tile_offset);
     if (L.n_groups) {
         hipLaunchKernelGGL(group_tiles_kernel, dim3(L.n_groups), dim3(256), 0, stream, L.tile_first, L.tile_count,
-                           L.n_row_tiles, L.group_size, L.shard_count, L.xcd_stripe, L.group_cmin, L.group_blocks);
+                           L.n_row_tiles, L.group_size, L.shard_count, L.group_cmin, L.group_blocks);
         hipLaunchKernelGGL(group_scan_kernel, dim3(1), dim3(64), 0, stream, L.group_blocks, L.n_groups, L.group_offset);
     }
     return hipGetLastError();
@@ -1228,14 +1009,14 @@ hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long
     return hipGetLastError();
 }
 
-hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, int mode01, uint32_t k_steps,
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, uint32_t k_steps,
                              float *pop3 /* nullable: [3][n_pad] = pop, popk, popkT */, hipStream_t stream)
 {
     if (n_pad == 0) return hipSuccess;
     if (pop3 && (n_pad % 128u)) return hipErrorInvalidValue;
     const size_t total = (size_t)n_pad * 32;
     hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)std::min<size_t>((total + 255) / 256, kMaxBlocksPerLaunch)), dim3(256), 0, stream, packed, n, n_pad,
-                       reinterpret_cast<uint4 *>(expanded), mode01, k_steps, pop3, pop3 ? pop3 + n_pad : nullptr,
+                       reinterpret_cast<uint4 *>(expanded), k_steps, pop3, pop3 ? pop3 + n_pad : nullptr,
                        pop3 ? pop3 + 2 * (size_t)n_pad : nullptr);
     return hipGetLastError();
 }
@@ -1262,6 +1043,7 @@ hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tile
     case 11: VDF_MFMA2_LAUNCH(11, WV); break;                                                                        \
     case 12: VDF_MFMA2_LAUNCH(12, WV); break;                                                                        \
     case 13: VDF_MFMA2_LAUNCH(13, WV); break;                                                                        \
+    case 14: VDF_MFMA2_LAUNCH(14, WV); break;                                                                        \
     default: VDF_MFMA2_LAUNCH(16, WV); break;                                                                        \
     }
         if (L.tile_rows == 512) { VDF_MFMA2_STEPS(8) } else { VDF_MFMA2_STEPS(4) }
@@ -1280,48 +1062,6 @@ hipError_t launch_resolve_candidates(const SearchLaunch &L, hipStream_t stream)
                        L.cand_head, L.cand_capacity, L.row_hashes, L.row_perm, L.n_rows, L.row_index_base, L.col_hashes, L.n_cols,
                        L.row_lo, L.row_hi, L.tol, L.matched, L.self_mode, L.hits, L.capacity, L.counters, L.overflow_row);
     return hipGetLastError();
-}
-
-hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream)
-{
-    if (total_tiles == 0) return hipSuccess;
-    if (L.tile_rows != kMfmaTileRows) return hipErrorInvalidValue;
-    for (uint32_t base = 0; base < total_tiles; base += kMaxBlocksPerLaunch) {
-        const uint32_t nb = std::min(kMaxBlocksPerLaunch, total_tiles - base);
-#define VDF_MFMA_LAUNCH(AB, CK)                                                                                     \
-    hipLaunchKernelGGL((hamming_mfma_kernel<AB, CK>), dim3(nb), dim3(64 * kMfmaWaves), 0, stream,                            \
-                       reinterpret_cast<const uint4 *>(L.row_exp), L.row_perm, L.n_rows, L.row_index_base,           \
-                       reinterpret_cast<const uint4 *>(L.col_exp), L.row_lo, L.row_hi, L.tile_lo, L.tile_hi,         \
-                       L.tile_first, L.tile_count, L.group_offset, L.group_cmin, L.n_groups, L.group_size,           \
-                       L.shard_index, L.shard_count, L.n_row_tiles, L.chunk_cols, L.tol, L.matched, L.self_mode,     \
-                       L.hits, L.capacity, L.counters, L.overflow_row, base, L.xcd_stripe)
-        switch (L.ablate) {
-#ifdef VDF_BENCH_ABLATE  // timing-experiment builds only (tools/build_variant.sh <name> -DVDF_BENCH_ABLATE): no hits reported
-        case 1: VDF_MFMA_LAUNCH(1, 16); break;
-        case 2: VDF_MFMA_LAUNCH(2, 16); break;
-        case 3: VDF_MFMA_LAUNCH(3, 16); break;
-        case 4: VDF_MFMA_LAUNCH(4, 16); break;
-        case 5: VDF_MFMA_LAUNCH(5, 16); break;
-        case 6: VDF_MFMA_LAUNCH(6, 16); break;
-        case 7: VDF_MFMA_LAUNCH(7, 16); break;
-#endif
-        default:
-            switch (L.prune_step) {  // smallest instantiated step >= the requested one
-            case 0: case 1: case 2: case 3: case 4: case 5: case 6: VDF_MFMA_LAUNCH(0, 6); break;
-            case 7: case 8: VDF_MFMA_LAUNCH(0, 8); break;
-            case 9: case 10: VDF_MFMA_LAUNCH(0, 10); break;
-            case 11: VDF_MFMA_LAUNCH(0, 11); break;
-            case 12: VDF_MFMA_LAUNCH(0, 12); break;
-            case 13: VDF_MFMA_LAUNCH(0, 13); break;
-            default: VDF_MFMA_LAUNCH(0, 16); break;
-            }
-            break;
-        }
-#undef VDF_MFMA_LAUNCH
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
 }
 
 }  // namespace vdf

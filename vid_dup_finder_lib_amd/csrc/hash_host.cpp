@@ -79,10 +79,7 @@ static CopyPool *pool_of(vdf_ctx *ctx)
     if (!ctx->copy_pool) {
         int n = (int)std::thread::hardware_concurrency() / 2;
         n = std::max(1, std::min(n, 8));
-        if (const char *s = std::getenv("VDF_COPY_THREADS")) {
-            const int v = std::atoi(s);
-            if (v >= 1 && v <= 64) n = v;
-        }
+        if (ctx->copy_threads) n = ctx->copy_threads;  // VDF_COPY_THREADS
         ctx->copy_pool = new CopyPool(n);
     }
     return ctx->copy_pool;
@@ -90,32 +87,19 @@ static CopyPool *pool_of(vdf_ctx *ctx)
 
 constexpr size_t kBatchBytes = 256ull << 20;  // device batch buffer (x 2)
 
-static size_t chunk_bytes()
-{  // pinned staging chunk (x 2); VDF_HOST_CHUNK_MB for experiments
-    static const size_t v = [] {
-        size_t mb = 32;
-        if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) {
-            const long x = std::atol(s);
-            if (x >= 1 && x <= 1024) mb = (size_t)x;
-        }
-        return mb << 20;
-    }();
-    return v;
-}
-
 int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                      size_t clip_stride, int letterbox, uint64_t *out_hashes, uint32_t *out_crops, uint32_t *out_dontcare)
 {
     VDF_HIP(ctx, hipSetDevice(ctx->device));
     const size_t fbytes = (size_t)w * h, cbytes = fbytes * VDF_DCT_SIZE;
     const size_t batch = std::max<size_t>(1, std::min<size_t>(n_clips, kBatchBytes / cbytes));
-    const size_t kChunkBytes = chunk_bytes();
+    const size_t kChunkBytes = ctx->host_chunk_bytes;  // pinned staging chunk (x 2); VDF_HOST_CHUNK_MB for experiments
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(batch, kChunkBytes / cbytes));  // clips per pinned chunk
     // Tightly packed input needs no gather: hipMemcpyAsync straight from the caller's pageable memory (the runtime stages
     // it through its own pinned buffers) measured 54.5 GB/s against 53.7 for the library's pinned chunks - both at what
     // the PCIe Gen5 x16 link delivers (tools/sweep_host_path.sh).  VDF_HOST_DIRECT=0 forces the library's staging;
     // strided input (more than 16 frames per clip, padded frames) always takes it: only the wanted bytes cross the link.
-    static const bool direct_env = !(std::getenv("VDF_HOST_DIRECT") && std::atoi(std::getenv("VDF_HOST_DIRECT")) == 0);
+    const bool direct_env = ctx->host_direct;
     const bool packed = frame_stride == fbytes && clip_stride == cbytes;
     DevBuf *d_frames[2] = {&ctx->frames, &ctx->frames2}, *d_hash[2] = {&ctx->out_hashes, &ctx->out_hashes2},
            *d_dc[2] = {&ctx->out_dc, &ctx->out_dc2};

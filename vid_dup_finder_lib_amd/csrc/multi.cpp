@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 
@@ -197,7 +198,7 @@ static int replicate(vdf_ctx *ctx, const void *const *shards, const size_t *shar
     const size_t G = ctx->subs.size();
     std::vector<size_t> off(G + 1, 0);
     for (size_t k = 0; k < G; k++) off[k + 1] = off[k] + shard_n[k];
-    const bool force = std::getenv("VDF_FORCE_RCCL") != nullptr;
+    const bool force = ctx->force_rccl;  // VDF_FORCE_RCCL, read when the context was made
     if ((G > 1 || force) && devices_distinct(ctx)) {
         int rc = ensure_comms(ctx);
         if (rc) return rc;
@@ -275,6 +276,7 @@ int vdf_ctx_create_multi(const int *device_ids, int n_devices, vdf_ctx **out)
     for (int k = 0; k < n_devices; k++) parent->workers.push_back(new Worker());
     for (int k = 0; k < n_devices; k++) parent->workers[(size_t)k]->th = std::thread(worker_main, parent, k);
     parent->hit_capacity = parent->subs[0]->hit_capacity;
+    parent->force_rccl = std::getenv("VDF_FORCE_RCCL") != nullptr;
     *out = parent;
     return VDF_OK;
 }

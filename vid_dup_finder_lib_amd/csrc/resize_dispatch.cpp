@@ -1,7 +1,5 @@
 #include "resize_dispatch.h"
 
-#include <cstdlib>
-
 namespace vdf {
 
 uint32_t stream_pitch(uint32_t w)
@@ -40,12 +38,10 @@ static bool wavestream_fits(uint32_t w, int nw)
     return need <= (uint32_t)buf && w >= 256;
 }
 
-int resize_wavestream_waves(uint32_t w)
+int resize_wavestream_waves(uint32_t w, int knob)
 {
-    if (std::getenv("VDF_NO_WAVESTREAM")) return 0;    // measurements / tests: the chunk kernel everywhere
-    const char *e = std::getenv("VDF_WAVESTREAM_NW");  // (read per call: a sweep changes it between calls)
-    const int forced = e ? std::atoi(e) : 0;
-    if (forced) return wavestream_fits(w, forced) ? forced : 0;
+    if (knob < 0) return 0;  // VDF_NO_WAVESTREAM (measurements / tests): the chunk kernel everywhere
+    if (knob > 0) return wavestream_fits(w, knob) ? knob : 0;  // VDF_WAVESTREAM_NW
     uint32_t nb = 0;
     const int cls = stream_class(w, &nb);
     // Frames up to 512 wide keep the chunk kernel (two workgroups per CU, whole table in LDS: 480 x 270 6.5 TB/s against 6.0 with eight
@@ -79,10 +75,10 @@ uint32_t box_stream_pitch(uint32_t frame_w, uint32_t x0, uint32_t box_w, int *mo
     return wp;
 }
 
-int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w)
+int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w, int knob)
 {
-    if (x0 == 0 && box_w == frame_w) return resize_wavestream_waves(frame_w);
-    if (std::getenv("VDF_NO_WAVESTREAM") || box_w < 513) return 0;  // narrower boxes: the gather kernel with two workgroups per CU
+    if (x0 == 0 && box_w == frame_w) return resize_wavestream_waves(frame_w, knob);
+    if (knob < 0 || box_w < 513) return 0;  // narrower boxes: the gather kernel with two workgroups per CU
     int mode = 0;
     const uint32_t need = ((16u * box_stream_pitch(frame_w, x0, box_w, &mode) + 1023u) & ~1023u) + 128u;
     for (int nw : {8, 6, 5, 4, 3}) {
@@ -98,9 +94,9 @@ bool resize_wavestream_table_fits(int nw, int band_stride)
     return tab_bytes <= (nw <= 4 ? kWaveStreamTabBytes : nw == 5 ? kWaveStreamTabMid : kWaveStreamTabSmall);
 }
 
-bool resize_stream_wants_band(uint32_t w) { return resize_wavestream_waves(w) != 0; }
+bool resize_stream_wants_band(uint32_t w, int knob) { return resize_wavestream_waves(w, knob) != 0; }
 
-bool resize_wavestream_applies(uint32_t w) { return resize_wavestream_waves(w) != 0; }
+bool resize_wavestream_applies(uint32_t w, int knob) { return resize_wavestream_waves(w, knob) != 0; }
 
 bool resize_rowcrop_streams(uint32_t w)
 {
@@ -111,7 +107,7 @@ bool resize_rowcrop_streams(uint32_t w)
     return w != 2048;
 }
 
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride)
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, int knob)
 {
     // narrow tall frames (portrait video) gain the most: 240 x 426 4.6 -> 6.1 TB/s, 160 x 200 3.5 -> 4.2 against the whole-line kernels
     if (w < 64 || (uint64_t)w * h >= (1ull << 31)) return false;
@@ -120,7 +116,7 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     if (((uint64_t)w * h) % 16 != 0) return false;
     if (((uintptr_t)frames | frame_stride | clip_stride) % 16 != 0) return false;
     uint32_t nb = 0;
-    return stream_class(w, &nb) == 1 || resize_wavestream_applies(w);  // the chunk form (frames up to 512 wide) or one block stream per wave
+    return stream_class(w, &nb) == 1 || resize_wavestream_applies(w, knob);  // the chunk form (frames up to 512 wide) or one block stream per wave
 }
 
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)

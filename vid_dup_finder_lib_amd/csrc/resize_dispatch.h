@@ -47,23 +47,24 @@ uint32_t stream_pitch(uint32_t w);
 uint32_t stream_blocks_per_chunk(uint32_t wp, int buf_bytes);
 // buffer class of a width: 0 none, 1 = S (the chunk kernel), 2 = M, 3 = M with the band table; *nb = 16-row blocks per chunk
 int stream_class(uint32_t w, uint32_t *nb);
-bool resize_stream_wants_band(uint32_t w);  // the width's kernel takes a.bh in kMfmaLayoutHorizontalBand form (= the per-wave form)
+bool resize_stream_wants_band(uint32_t w, int knob = 0);  // the width's kernel takes a.bh in kMfmaLayoutHorizontalBand form (= the per-wave form)
 // One block stream per wave (resize_mfma_frame_wavestream_kernel): every M-class width whose (re-pitched, whole-KB) block fits a wave's
 // buffer - 512 .. 2368 columns - with as many waves per workgroup as buffers fit (8 / 6 / 5 / 4 / 3; 0 = the width does not take this form).
-// VDF_WAVESTREAM_NW=n forces n waves where the block fits the n-wave buffer, VDF_NO_WAVESTREAM=1 switches the form off (measurements).
-int resize_wavestream_waves(uint32_t w);
-bool resize_wavestream_applies(uint32_t w);
+// knob (vdf_ctx::wavestream_knob, read once per context): 0 = the measured rule, n > 0 = VDF_WAVESTREAM_NW=n forces n waves where the block
+// fits the n-wave buffer, -1 = VDF_NO_WAVESTREAM=1 switches the form off (measurements / tests).
+int resize_wavestream_waves(uint32_t w, int knob = 0);
+bool resize_wavestream_applies(uint32_t w, int knob = 0);
 // a launch over crop boxes that share their column range (x0, box_w) of frames frame_w wide: LDS row pitch and addressing mode (0 linear
 // copy of whole rows, 1 gather, 2 gather + the operand shift for rows that start off a dword), and the wave count (0: not this kernel)
 uint32_t box_stream_pitch(uint32_t frame_w, uint32_t x0, uint32_t box_w, int *mode);
-int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w);
+int resize_wavestream_waves_box(uint32_t frame_w, uint32_t x0, uint32_t box_w, int knob = 0);
 bool resize_wavestream_table_fits(int nw, int band_stride);  // does a band table of that stride (bytes per output) fit the nw-wave kernel's table array
 // Clips whose crop boxes are full-width (top / bottom bars only): do the ROWCROP instantiations of the stream kernels beat the general
 // cropped kernels at this frame width?  (measured; the frame must also pass resize_stream_eligible / resize_ksplit_eligible)
 bool resize_rowcrop_streams(uint32_t w);
 // Does a call take a linear-stream kernel (chunk or per-wave form)?  Frames starting on 16-byte boundaries and ending on one, rows packed
 // inside a frame (frames and clips may be padded), 64 .. 1920 columns.
-bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride);
+bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, int knob = 0);
 
 // K-split form (1024..4096 columns, a multiple of 16): LDS pitch (an odd multiple of 16) and blocks per chunk (0: does not fit)
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp);

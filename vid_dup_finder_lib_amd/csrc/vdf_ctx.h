@@ -18,6 +18,7 @@
 // bytes of device memory the library's growable buffers hold right now, over all contexts of the process (vdf_live_device_bytes: a
 // context that forgets a buffer in its destructor shows up as a difference around create / use / destroy)
 inline std::atomic<long long> g_live_device_bytes{0};
+inline std::atomic<long long> g_live_pinned_bytes{0};  // the same for page-locked host staging (vdf_live_pinned_bytes)
 
 struct DevBuf {
     void *p = nullptr;
@@ -53,6 +54,7 @@ struct PinBuf {
         release();
         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) {
             pinned = true;
+            g_live_pinned_bytes += (long long)bytes;
         } else {
             (void)hipGetLastError();
             p = std::malloc(bytes);
@@ -64,7 +66,7 @@ struct PinBuf {
     }
     void release()
     {
-        if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+        if (p) { if (pinned) { (void)hipHostFree(p); g_live_pinned_bytes -= (long long)cap; } else std::free(p); }
         p = nullptr; cap = 0; pinned = false;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
@@ -91,9 +93,8 @@ struct ExpOwner {
     const void *hashes = nullptr;
     size_t n = 0;
     uint32_t k_steps = 0;
-    int mode01 = -1;
     const void *buffer = nullptr;  // exp_cols.p at the time: a reallocation invalidates
-    bool operator==(const ExpOwner &o) const { return hashes == o.hashes && n == o.n && k_steps == o.k_steps && mode01 == o.mode01 && buffer == o.buffer && hashes; }
+    bool operator==(const ExpOwner &o) const { return hashes == o.hashes && n == o.n && k_steps == o.k_steps && buffer == o.buffer && hashes; }
 };
 
 struct vdf_ctx {
@@ -114,7 +115,8 @@ struct vdf_ctx {
     DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
     DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
     DevBuf hits2, hit_bitmaps;  // replay filter: surviving hits, has-incoming / covered bitmaps
-    DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side Search::sort
+    DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side sorts inside a search call
+    DevBuf sort_scratch_pub;  // the same for vdf_sort_order_device: the caller may sort on one stream and search on another
     // hash scratch
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables, crop_desc2, crop_tables2, crop_work;
     PinBuf pin[2], pin_out[2];
@@ -132,20 +134,28 @@ struct vdf_ctx {
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
     uint32_t mfma_chunk_cols = 0, mfma_group = 8192;  // 0 = pick the chunk width per search (search_core); VDF_MFMA_CHUNK_COLS overrides
     DevBuf group_cmin, group_offset, group_blocks;
-    uint32_t mfma_xcd_stripe = 0;
     uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
-    int mfma_kernel = 2;            // 1 = first kernel (test inside the stream), 2 = branch-free stream + flagged-block cleanup (VDF_MFMA_KERNEL)
     uint64_t cand_scale = 1;              // grows (x4) while a reference search retries after a suspect-queue overflow
     uint32_t cand_capacity_override = 0;  // VDF_CAND_CAPACITY: suspect-queue entries (0 = sized from the admitted pairs)
-    uint32_t mfma_self_rows = 512;  // rows per workgroup of search() with kernel 2 (VDF_MFMA_SELF_ROWS: 256 | 512)
-    uint32_t mfma_refs_rows = 256;  // rows per workgroup of reference searches with kernel 2 (VDF_MFMA_REFS_ROWS: 256 | 512)
+    uint32_t mfma_self_rows = 512;  // rows per workgroup of search() (VDF_MFMA_SELF_ROWS: 256 | 512)
+    uint32_t mfma_refs_rows = 256;  // rows per workgroup of reference searches (VDF_MFMA_REFS_ROWS: 256 | 512)
     int mfma_prune_step = -1;  // -1 = from the tolerance, 16 = off (VDF_MFMA_PRUNE_STEP)
-    int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = +-1 fp4 Gram matrix on the matrix cores (both exact)
+    int search_backend = 1;  // 0 = XOR + popcount on the VALU, 1 = {0, 1} fp4 Gram matrix on the matrix cores (both exact)
     DevBuf exp_cols, exp_rows, pop_cols, pop_rows, cand;
     size_t cand_dirty = SIZE_MAX;  // slots of the candidate queue the last launch may have written (SIZE_MAX: never initialised)
+    // dispatch switches of measurements and tests, read ONCE per context (create_single): getenv is not safe against a concurrent setenv
+    // (Python writing os.environ while the multi-GPU worker threads hash), and decision and launcher must see the same value
+    int wavestream_knob = 0;       // resize_dispatch.h: -1 = VDF_NO_WAVESTREAM, n > 0 = VDF_WAVESTREAM_NW=n
+    bool no_rowcrop = false, rowcrop_all = false, no_boxstream = false;  // VDF_NO_ROWCROP / VDF_ROWCROP_ALL / VDF_NO_BOXSTREAM
+    int lb_side_strips = 0;        // VDF_LB_NC16: 16 = the side walk never takes the 32-strip form
+    int copy_threads = 0;          // VDF_COPY_THREADS (0: half the hardware threads, at most 8)
+    size_t host_chunk_bytes = 32u << 20;  // VDF_HOST_CHUNK_MB: pinned staging chunk (x 2) of the host-frame path
+    bool host_direct = true;       // VDF_HOST_DIRECT=0: packed input goes through the library's staging too
+    bool force_rccl = false;       // VDF_FORCE_RCCL: a one-device context replicates through librccl (multi-GPU parent)
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads, 5 MFMA linear-stream kernel where it applies, 6 its K-split form where it applies
-    // hit list of the host-level calls: pinned (a 50 MB list comes down at the link rate; a std::vector of the default
-    // 16 M entries would also be zero-filled, page by page, on first use)
+    // hit list of the host-level calls: pinned (a 50 MB list comes down at the link rate), sized by what searches actually
+    // produce - 64 k entries to begin with, grown to a launch's list once its length is known (search_core) - not by the hit
+    // capacity: the default 16 M entries would be 128 MB of page-locked memory per device for lists that are usually empty
     struct HostHits {
         PinBuf buf;
         size_t size() const { return buf.cap / sizeof(vdf_hit); }
@@ -201,11 +211,12 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
-                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only = false);
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only = false,
+                vdf_ctx::HostHits *staging = nullptr);  // staging: the list goes to this growable pinned buffer instead of `hits`
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                               size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations, size_t n_ref,
                               uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits, uint64_t capacity,
-                              uint64_t *n_hits, hipStream_t s);
+                              uint64_t *n_hits, hipStream_t s, vdf_ctx::HostHits *staging = nullptr);
 int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w,
                        uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out, uint32_t *d_dc,
                        hipStream_t stream);

@@ -26,19 +26,17 @@ struct SearchLaunch {
     uint32_t n_cols;
     // fp4-expanded copies for the MFMA backend ([n_pad][512 B], zero padded); null for the VALU backend
     const void *row_exp, *col_exp;
-    // second-generation kernel ({0, 1} encoding): popcounts of rows / columns as floats: [pop | popk | popkT] x n_pad
+    // popcounts of rows / columns as floats: [pop | popk | popkT] x n_pad
     const float *row_pop3 = nullptr, *col_pop3 = nullptr;
     uint32_t row_pad = 0, col_pad = 0;
-    void *cand = nullptr;                 // candidate queue of the second-generation kernel (16-byte entries, pre-filled with 0xFF)
+    void *cand = nullptr;                 // suspect queue of the MFMA kernel (16-byte entries, pre-filled with 0xFF)
     uint32_t cand_capacity = 0;
     unsigned long long *cand_head = nullptr;  // next free slot (advanced in per-wave chunks; keeps counting past a full queue)
     // windows + tiles (device scratch, filled by launch_windows_tiles)
     uint32_t *row_lo, *row_hi;   // [n_row_tiles * tile_rows]
     uint32_t *tile_lo, *tile_hi, *tile_first, *tile_count, *tile_offset;  // [n_row_tiles (+1)]
     uint32_t *group_cmin, *group_offset, *group_blocks;  // [n_groups (+1)]: chunk-major grouped order (MFMA backend), else null
-    int ablate = 0;                       // timing experiments only (VDF_MFMA_ABLATE), wrong results when != 0
     int prune_step = 16;                  // MFMA backend: k-step after which a block that cannot contain a hit stops (16 = never)
-    uint32_t xcd_stripe = 0;              // MFMA backend: 1 = candidate chunks striped over the 8 XCDs (chunk = base + 8 k + blockIdx % 8)
     uint32_t shard_index = 0, shard_count = 1;  // row tiles t with t % shard_count == shard_index are this launch's
     uint32_t n_groups, group_size;        // n_groups = 0 for the VALU backend (compact tile list)
     uint32_t n_row_tiles;
@@ -60,20 +58,11 @@ hipError_t launch_windows_tiles(int mode, const uint32_t *col_dur, uint32_t n_co
                                 uint32_t shard_index, uint32_t shard_count, const SearchLaunch &L,
                                 hipStream_t stream);
 hipError_t launch_hamming_tiles(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
-// MFMA backend: +-1 fp4 encoding, exact.  Rows are padded to a multiple of the tile, columns by a further 128.
-#ifndef VDF_MFMA_WAVES
-#define VDF_MFMA_WAVES 8  // waves per MFMA workgroup (64 target rows per wave).  8 x 128-column stages is the measured best once the
-                          // early exit is on (113.8 ms vs 118.1 for 8 x 64 columns and ~126 for 4 waves); 4 was best without it
-#endif
-#ifndef VDF_ROW_TILES
-#define VDF_ROW_TILES 2  // 32-row MFMA tiles per wave (build-time experiment knob)
-#endif
-constexpr uint32_t kMfmaRowPad = 32 * VDF_ROW_TILES * VDF_MFMA_WAVES, kMfmaColPad = 128;  // kMfmaRowPad = rows per MFMA workgroup tile
-// mode01 = 1: {0, 1} nibbles + popcount arrays pop3 = [pop | popk | popkT] of n_pad floats each (second-generation kernel);
-// mode01 = 0: +-1 nibbles (first kernel), pop3 = nullptr
-hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, int mode01, uint32_t k_steps,
+// MFMA backend: {0, 1} fp4 encoding, exact.  Rows are padded to a multiple of the tile, columns by a further 128.
+constexpr uint32_t kMfmaRowPad = 512, kMfmaColPad = 128;  // kMfmaRowPad = rows of the largest MFMA workgroup tile (8 waves x 64 rows)
+// {0, 1} nibbles + popcount arrays pop3 = [pop | popk | popkT] of n_pad floats each
+hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad, void *expanded, uint32_t k_steps,
                              float *pop3, hipStream_t stream);
-hipError_t launch_hamming_tiles_mfma(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream; tile_rows 512 or 256
 hipError_t launch_resolve_candidates(const SearchLaunch &L, hipStream_t stream);  // its second pass: suspects evaluated exactly
 // drops the hits of rows that can never become targets of the greedy replay (hamming.hip); needs the launch's complete hit set
@@ -103,6 +92,7 @@ struct MfmaResizeArgs {  // device pointers to the MFMA-layout tables (resize_ta
     int32_t band_stride = 0;
     int32_t no_persistent = 0;         // debugging: force the one-clip-per-workgroup fused kernel
     int32_t persistent_wgs_per_cu = 3; // resident workgroups per CU for the persistent kernel
+    int32_t wavestream_knob = 0;       // vdf_ctx::wavestream_knob (resize_dispatch.h): the launcher must decide as the caller did
 };
 hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
                                    size_t clip_stride, const uint8_t *buf_end, const MfmaResizeArgs &a,
@@ -164,8 +154,9 @@ hipError_t launch_resize_mfma_box_wavestream(const uint8_t *frames, size_t n_cli
                                              const CropStreamTable *tables, uint8_t *small, hipStream_t stream);
 // work: scratch of letterbox_work_bytes(n_clips, frames_per_clip) bytes (the list of frames whose side bars a second pass walks)
 size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip);
+// side_strips: 0 = by frame height (32 column strips per pass from 512 rows, 16 from 256, else 8), 16 = at most 16 (VDF_LB_NC16: A/B runs)
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
-                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream);
+                            size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream, int side_strips = 0);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);
