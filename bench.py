@@ -244,13 +244,11 @@ def search_roofline(backend, kernel_ms):
                                    "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
                                            "exceed the tolerance cannot contain a hit and stops there (exact)"},
                     "note": ("exact {0,1} fp4 Gram matrix (v_mfma_f32_32x32x64_f8f6f4): hamming = pop(a) + pop(b) - 2 dot; suspects of "
-                             "blocks that cannot be ruled out are evaluated exactly by resolve_candidates_kernel (inside kernel_ms); "
-                             if gen2 else "exact +-1 fp4 Gram matrix (v_mfma_scale_f32_32x32x64_f8f6f4): hamming = (1024 - dot) / 2; ") +
+                             "blocks that cannot be ruled out are evaluated exactly by resolve_candidates_kernel (inside kernel_ms); ") +
                             "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
                             "pair; integer results, bit-identical to XOR + popcount"}
         extra = {"hbm_operand_stream_model": hbm_model}
-        dtype = ("fp4 e2m1 ({0,1}) x fp4 -> f32 accumulate (exact half-integers < 2^11)" if gen2
-                 else "fp4 e2m1 (+-1) x fp4 -> f32 accumulate (exact integers <= 1024)")
+        dtype = "fp4 e2m1 ({0,1}) x fp4 -> f32 accumulate (exact half-integers < 2^11)"
     return roofline, extra, dtype
 
 

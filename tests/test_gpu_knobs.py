@@ -1,7 +1,7 @@
 """Every VDF_* switch the library reads (measurement and test knobs, csrc/api.cpp: create_single; multi.cpp) changes HOW a result is
 computed, never the result: a fresh engine per setting runs a small pass over both halves of the hot path - host-frame hashing (packed and
 strided), 64 x 64 / 640-wide / letterboxed clips, search() and search_with_references() - against the oracle.  A knob that ships without a
-test is a wrong-answer risk nobody would notice; tests/test_capi_symbols.py checks that the list below is complete."""
+test is a wrong-answer risk nobody would notice; tests/test_knob_coverage.py (CPU) checks that every getenv in csrc/ appears in a test."""
 import os
 
 import numpy as np
@@ -66,8 +66,11 @@ def workload():
             lb[c, :, :, :160] = 2
             lb[c, :, :, -160:] = 2
     w["lb"] = lb
-    w["lb_want"] = np.stack([orc.hash_clip_letterbox(c) for c in lb])
-    w["lb_crops"] = np.array([orc.cropdetect_letterbox(c) for c in lb], np.uint32)
+    res = [orc.hash_clip_letterbox(c) for c in lb]  # (rc, hash, coefs, crop) per clip
+    assert all(r[0] == 0 for r in res)
+    w["lb_want"] = np.stack([r[1] for r in res])
+    w["lb_crops"] = np.array([r[3] for r in res], np.uint32)
+    assert {tuple(c) for c in w["lb_crops"]} == {(0, 0, 90, 88), (160, 160, 0, 0), (0, 0, 0, 0)}  # the three shapes are what the oracle sees
     words, dur = hg.planted_set(rng, 3000, n_clusters=60, durations="windowed")
     order = np.argsort(dur, kind="stable")
     w["words"], w["dur"] = words[order], dur[order]
