@@ -104,7 +104,8 @@ typedef struct vdf_search_timing {
     uint64_t suspects;          /* suspect-queue entries written (matrix-core backend) */
     uint64_t suspect_capacity;  /* size of that queue in the last launch */
     uint64_t hits_filtered;     /* thresholded pairs dropped on the device because their row can never become a target of the
-                                   greedy replay (search() on one device; they are counted in vdf_search_stats.n_hits) */
+                                   greedy replay (host-level search() and the *_replay device call, sharded or not; they are counted in
+                                   vdf_search_stats.n_hits) */
 } vdf_search_timing;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -122,6 +123,7 @@ int vdf_ctx_device_at(const vdf_ctx *ctx, int slot); /* HIP device id of a slot,
 /* Per-device statistics of the last search on a multi-GPU context (vdf_ctx_last_search_stats gives the sums, with
  * kernel_ms = the slowest device's). */
 int vdf_ctx_device_search_stats(const vdf_ctx *ctx, int slot, vdf_search_stats *out);
+int vdf_ctx_device_search_timing(const vdf_ctx *ctx, int slot, vdf_search_timing *out); /* that slot's phases and hits_filtered */
 void vdf_ctx_destroy(vdf_ctx *ctx);
 const char *vdf_last_error(const vdf_ctx *ctx); /* ctx may be NULL: last ctx_create failure */
 const char *vdf_version(void);
@@ -224,6 +226,36 @@ int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_
                            uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
                            uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
                            uint64_t *n_hits, uint32_t *overflow_row, void *stream);
+
+/* The replay-only form of vdf_search_self_device for a caller that shards search() over PROCESSES (one GPU each) and feeds the
+ * merged lists to vdf_replay_self and nothing else: hits of rows that can never become targets of the greedy loop
+ * (search_algorithm.rs:131-170: a row with an incoming hit from a root - a row nobody hits - is consumed before its turn) are
+ * dropped on the device before the sort and the download; a cluster of s mutual duplicates sends down s - 1 pairs, not
+ * s (s - 1) / 2.  Whether a row is such a row is a property of the COMPLETE hit set, which a sharded launch has spread over
+ * its shards, so the shards meet three times through the caller's callbacks (every shard of the launch must make the call,
+ * also one whose tiles produce no hits; xchg = NULL with shard_count = 1 is the unsharded case, and with shard_count > 1
+ * disables the filter):
+ *   agree:     in/out *all_complete (this shard saw no buffer overflow -> AND over the shards), *total_hits (-> sum);
+ *              the filter runs only if all are complete (and the total is worth it) - the same decision on every shard;
+ *   or_bitmap: d_bitmap[0 .. n_words) (DEVICE, 1 bit per entry) |= every other shard's, in place; the library's kernels that
+ *              wrote it were queued on `stream` and the ones that read it will be - order the exchange on it or finish it
+ *              before returning (all-gather + vdf_bitmap_or_device, or an all-reduce(MAX) of a byte map: RCCL has no OR).
+ *              Called twice per filtered launch (has-incoming, covered).
+ * Callbacks return 0 or a negative vdf_status, which the call hands back.  *n_hits = the pairs kept; everything else as
+ * vdf_search_self_device (after an overflow nothing is dropped and the overflow protocol applies unchanged). */
+typedef struct vdf_shard_exchange {
+    void *user;
+    int (*agree)(void *user, int *all_complete, uint64_t *total_hits);
+    int (*or_bitmap)(void *user, uint32_t *d_bitmap, size_t n_words, void *stream);
+} vdf_shard_exchange;
+int vdf_search_self_device_replay(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
+                                  uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
+                                  uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
+                                  uint64_t *n_hits, uint32_t *overflow_row, const vdf_shard_exchange *xchg, void *stream);
+/* d_dst[w] |= d_srcs[0 * n_words + w] | ... | d_srcs[(n_srcs - 1) * n_words + w] on the device (the local half of an OR over
+ * shards after an all-gather; with n_srcs = 1 and a zeroed destination: a copy).  Single-device contexts.  Takes no lock:
+ * callable from inside an or_bitmap callback. */
+int vdf_bitmap_or_device(vdf_ctx *ctx, uint32_t *d_dst, const uint32_t *d_srcs, size_t n_words, uint32_t n_srcs, void *stream);
 
 /* vdf_search_refs_device: emits every pair (r, j) with j inside reference r's +-5% window
  * (search_algorithm.rs:173-185) and hamming <= tol_int; row = r + ref_index_base, hits (HOST

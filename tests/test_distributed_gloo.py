@@ -55,6 +55,43 @@ class FakeEngine:
         arr = np.array(sorted(hits), np.uint32).reshape(-1, 2)
         return arr, n_hits, overflow
 
+    def search_self_device_replay(self, d_hashes, d_durations, n, tol_int, shard_index=0, shard_count=1, row_begin=0,
+                                  row_end=0xFFFFFFFF, d_matched=0, capacity=1 << 22, stream=0, exchange=None):
+        """Contract of Engine.search_self_device_replay (vdf_search_self_device_replay): the shards agree that nobody overflowed,
+        OR their has-incoming / covered bitmaps through the exchange, and keep only the hits of rows that can become targets.
+        The bitmaps live in host memory here; the exchange reaches them through bitmap_or_device like the real engine's."""
+        arr, n_hits, overflow = self.search_self_device(d_hashes, d_durations, n, tol_int, shard_index, shard_count, row_begin,
+                                                        row_end, d_matched, capacity, stream)
+        complete, total = (overflow == 0xFFFFFFFF and n_hits <= capacity), n_hits
+        if exchange is not None:
+            complete, total = exchange.agree(complete, total)
+        elif shard_count != 1:
+            complete = False
+        if not (complete and total >= 1):
+            return arr, n_hits, overflow
+        words = (n + 31) // 32
+        has_in, covered = np.zeros(words, np.uint32), np.zeros(words, np.uint32)
+        bit = lambda bm, i: (int(bm[i >> 5]) >> (i & 31)) & 1  # noqa: E731
+        for _, c in arr:
+            has_in[c >> 5] |= np.uint32(1 << (c & 31))
+        if exchange is not None:
+            exchange.or_bitmap(self, has_in.ctypes.data, words, 0)
+        for r, c in arr:
+            if not bit(has_in, int(r)):
+                covered[c >> 5] |= np.uint32(1 << (c & 31))
+        if exchange is not None:
+            exchange.or_bitmap(self, covered.ctypes.data, words, 0)
+        keep = np.array([h for h in arr if not bit(covered, int(h[0]))], np.uint32).reshape(-1, 2)
+        self.filtered = getattr(self, "filtered", 0) + len(arr) - len(keep)
+        return keep, len(keep), overflow
+
+    def bitmap_or_device(self, d_dst, d_srcs, n_words, n_srcs, stream=0):
+        import ctypes as C
+
+        dst = np.ctypeslib.as_array((C.c_uint32 * n_words).from_address(d_dst))
+        src = np.ctypeslib.as_array((C.c_uint32 * (n_words * n_srcs)).from_address(d_srcs)).reshape(n_srcs, n_words)
+        dst |= np.bitwise_or.reduce(src, axis=0)
+
     def search_refs_device(self, d_cand_hashes, d_cand_durations, n_cand, d_ref_hashes, d_ref_durations, n_ref,
                            tol_int, ref_index_base=0, capacity=1 << 22, stream=0):
         rbits = np.unpackbits(self.rw.view(np.uint8), axis=1).astype(np.int16)
@@ -103,7 +140,9 @@ def _worker(rank, world, port, capacity, out_dir):
 
     torch.Tensor.to = spy_to
     try:
-        groups = mod.search_self_sharded(spy, fw, fd, 350, capacity=capacity)
+        st = {}
+        groups = mod.search_self_sharded(spy, fw, fd, 350, capacity=capacity, stats=st)
+        np.save(os.path.join(out_dir, f"filter_{rank}.npy"), np.array([getattr(eng, "filtered", 0), st["filtered_launches"], st["hits_downloaded"]]))
     finally:
         torch.Tensor.to = orig_to
     # references: contiguous split, results concatenated in rank order on rank 0
@@ -146,6 +185,11 @@ def test_two_rank_search_matches_oracle(tmp_path, capacity):
     assert res["refs"] == orc.search_refs_sorted(res["w"], res["d"], res["rw"], res["rd"], 300)
     calls = int(np.load(tmp_path / "calls.npy")[0])
     assert (calls > 1) == (capacity < 1000)  # the small buffer must have gone through the overflow protocol
+    # the replay filter across ranks (DistExchange): with room for every hit both ranks drop rows that cannot become targets - rows whose
+    # root lives on the OTHER rank included, which only the OR of the bitmaps over the ranks can tell them
+    f0, f1 = np.load(tmp_path / "filter_0.npy"), np.load(tmp_path / "filter_1.npy")
+    if capacity >= 1000:
+        assert f0[0] > 0 and f1[0] > 0 and f0[1] == 1 and f1[1] == 1
 
 
 def test_split_range_is_contiguous_and_complete():

@@ -71,11 +71,55 @@ def test_replay_filter_never_changes_the_groups(monkeypatch):
             finally:
                 eng.close()
     monkeypatch.setenv("VDF_NO_HIT_FILTER", "0")
-    two = vdf.Engine(devices=[0, 0])  # two slots: each sees only its own rows' hits, so nothing is filtered
+    two = vdf.Engine(devices=[0, 0])  # two slots: each sees only its own rows' hits, so they OR their bitmaps (multi.cpp: LocalExchange)
+    try:
+        assert two.search_self_sorted(w, d, 350) == want
+        assert all(two.device_timing(k)["hits_filtered"] > 0 for k in range(2))
+    finally:
+        two.close()
+    monkeypatch.setenv("VDF_NO_HIT_FILTER", "1")
+    two = vdf.Engine(devices=[0, 0])
     try:
         assert two.search_self_sorted(w, d, 350) == want and two.last_timing()["hits_filtered"] == 0
     finally:
         two.close()
+
+
+@pytest.mark.parametrize("slots", [2, 3])
+def test_sharded_launch_filters_like_one_device(slots):
+    """The replay filter of a SHARDED launch (row tiles dealt over the slots of a multi-GPU context; the device list repeats GPU 0
+    here): whether a row can become a target is a property of the complete hit set, so the slots OR their has-incoming and covered
+    bitmaps between the filter's steps.  Same groups as the oracle, every slot drops hits, and what comes down is the s - 1 pairs
+    per cluster a single device sends - not the s (s - 1) / 2 adjacency (consumption: search_algorithm.rs:141-161)."""
+    import torch
+
+    import bench
+    import vid_dup_finder_lib_amd as vdf
+
+    w, d, n_clusters, cluster_pairs = bench.make_dup_heavy(200_000)
+    want = orc.search_self_sorted(w, d, 350)
+    eng = vdf.Engine(devices=[0] * slots)
+    try:
+        assert eng.search_self_sorted(w, d, 350) == want and len(want) == n_clusters
+        st, tm = eng.last_stats(), eng.last_timing()
+        assert st["n_hits"] == cluster_pairs and st["n_launches"] == 1
+        per = [eng.device_timing(k)["hits_filtered"] for k in range(slots)]
+        assert all(p > 0 for p in per) and sum(per) == tm["hits_filtered"]
+        downloaded = st["n_hits"] - tm["hits_filtered"]
+        assert downloaded == 20_000 - n_clusters  # every cluster: its smallest member's s - 1 hits
+        assert downloaded <= 0.02 * cluster_pairs
+        # the shards entry point (what bench.py's dup_heavy leg and a Rust caller with resident hashes use)
+        cut = [len(d) * k // slots for k in range(slots + 1)]
+        tw = [torch.from_numpy(w[a:b].view(np.int64)).cuda() for a, b in zip(cut[:-1], cut[1:])]
+        td = [torch.from_numpy(d[a:b].view(np.int32)).cuda() for a, b in zip(cut[:-1], cut[1:])]
+        torch.cuda.synchronize()
+        assert eng.search_self_shards([t.data_ptr() for t in tw], [t.data_ptr() for t in td], [len(t) for t in td], 350) == want
+        assert eng.last_timing()["hits_filtered"] == tm["hits_filtered"]
+        # a hit buffer too small for the adjacency: nobody filters (the lists are incomplete), the overflow protocol takes over
+        eng.set_hit_capacity(100_000)
+        assert eng.search_self_sorted(w, d, 350) == want and eng.last_stats()["n_launches"] > 1
+    finally:
+        eng.close()
 
 
 def test_dense_hits_take_the_device_sort_and_the_overflow_protocol(engine):

@@ -86,8 +86,10 @@ def _worker(rank, world, port, capacity, out_dir):
     with torch.cuda.stream(side):
         fw, fd = vd.all_gather_database(torch.from_numpy(w[lo:hi].view(np.int64)).to(dev),
                                         torch.from_numpy(d[lo:hi].view(np.int32)).to(dev))
-        groups = vd.search_self_sharded(eng, fw, fd, 350, capacity=capacity)
+        st = {}
+        groups = vd.search_self_sharded(eng, fw, fd, 350, capacity=capacity, stats=st)
         calls_stream = eng.last_stats()["n_launches"]
+    np.save(os.path.join(out_dir, f"filter_{rank}.npy"), np.array([st["filtered_launches"], st["hits_downloaded"], eng.last_timing()["hits_filtered"]]))
     # and once on torch's legacy default stream (handle 0)
     groups0 = vd.search_self_sharded(eng, fw, fd, 350, capacity=capacity)
     pick = np.random.default_rng(5).choice(len(d), size=301, replace=False)
@@ -119,6 +121,14 @@ def test_two_ranks_real_engine_match_oracle(tmp_path, capacity):
     res = pickle.load(open(tmp_path / "res.pkl", "rb"))
     want = orc.search_self_sorted(res["w"], res["d"], 350)
     assert res["groups"] == want and res["groups0"] == want
+    # the 400 identical hashes alone are 79 800 thresholded pairs: with room for them the two ranks agree (gloo all-gather behind
+    # vdf_shard_exchange's callbacks) to drop the rows that cannot become targets, and OR their bitmaps twice; with the small
+    # buffer somebody overflows, nobody filters and the overflow protocol runs
+    f = [np.load(tmp_path / f"filter_{r}.npy") for r in range(2)]
+    if capacity > 100_000:
+        assert all(x[0] == 1 and x[2] > 0 for x in f) and sum(int(x[1]) for x in f) < 3000
+    else:
+        assert all(x[0] == 0 for x in f)
     assert res["refs"] == orc.search_refs_sorted(res["w"], res["d"], res["rw"], res["rd"], 300)
 
 

@@ -83,6 +83,14 @@ class VdfCacheSearchTiming(C.Structure):
                 ("map_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+AGREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint64))
+OR_BITMAP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class VdfShardExchange(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("agree", AGREE_FN), ("or_bitmap", OR_BITMAP_FN)]
+
+
 VDF_CACHE_OS_WINDOWS, VDF_CACHE_OS_UNIX = 0, 1
 VDF_CACHE_BACKEND_FFMPEG, VDF_CACHE_BACKEND_GSTREAMER = 0, 1
 VDF_CROPDETECT_NONE, VDF_CROPDETECT_LETTERBOX, VDF_CROPDETECT_MOTION = 0, 1, 2
@@ -99,6 +107,7 @@ SIGNATURES = {
     "vdf_ctx_device_count": (C.c_int, [_ctx]),
     "vdf_ctx_device_at": (C.c_int, [_ctx, C.c_int]),
     "vdf_ctx_device_search_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(VdfSearchStats)]),
+    "vdf_ctx_device_search_timing": (C.c_int, [_ctx, C.c_int, C.POINTER(VdfSearchTiming)]),
     "vdf_ctx_destroy": (None, [_ctx]),
     "vdf_last_error": (C.c_char_p, [_ctx]),
     "vdf_version": (C.c_char_p, []),
@@ -133,6 +142,10 @@ SIGNATURES = {
     "vdf_search_self_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p]),
+    "vdf_search_self_device_replay": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(VdfShardExchange), C.c_void_p]),
+    "vdf_bitmap_or_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "vdf_search_refs_device": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.c_void_p]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 #include "host_sort.h"
@@ -33,7 +34,7 @@ vdf_ctx::~vdf_ctx()
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
-                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &crop_desc2, &crop_tables2, &crop_work, &sort_scratch, &sort_scratch_pub, &hits2, &hit_bitmaps};
+                     &out_dc2, &cos_table, &crops, &crop_desc, &crop_tables, &crop_desc2, &crop_tables2, &crop_work, &sort_scratch, &sort_scratch_pub, &hits2, &hit_bitmaps, &bitmap_gather};
     for (DevBuf *b : all) b->release();
     for (PinBuf &b : pin) b.release();
     for (PinBuf &b : pin_out) b.release();
@@ -84,7 +85,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
                 const uint64_t *d_row_hashes, const uint32_t *d_row_dur, const uint32_t *d_row_perm, size_t n_rows,
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
-                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only, vdf_ctx::HostHits *staging)
+                uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only, vdf_ctx::HostHits *staging,
+                ShardExchange *fx)
 {
     *n_hits_out = 0;
     *overflow_row_out = 0xFFFFFFFFu;
@@ -313,27 +315,44 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     uint64_t stored = std::min<uint64_t>(produced, capacity);
     ctx->hits_guess = stored;
     uint64_t n_out = produced;
-    if (stored) {
-        vdf_hit *d_list = ctx->hits.as<vdf_hit>();
-        uint64_t have = std::min(stored, spec);
-        // Dense near-duplicates: most of the thresholded pairs belong to rows the greedy replay never uses as targets
-        // (hamming.hip: launch_filter_replay_hits).  With the COMPLETE hit set of an unsharded launch in hand they are
-        // dropped here, before the sort, the download and the host replay - a cluster of s mutual duplicates sends down
-        // s - 1 pairs instead of s (s - 1) / 2.
-        if (replay_only && mode == 0 && shard_count == 1 && produced <= capacity && (uint32_t)fin[4] == 0xFFFFFFFFu &&
-            stored >= kFilterHits && !ctx->no_hit_filter) {
-            VDF_HIP(ctx, ctx->hits2.reserve((size_t)stored * sizeof(vdf_hit)));
-            VDF_HIP(ctx, ctx->hit_bitmaps.reserve(2 * (((size_t)n_cols + 31) / 32) * 4 + 16));
-            VDF_HIP(ctx, vdf::launch_filter_replay_hits(d_list, stored, (uint32_t)n_cols, ctx->hit_bitmaps.as<uint32_t>(),
-                                                        ctx->hits2.as<vdf_hit>(), L.counters + 7, stream));
-            VDF_HIP(ctx, hipMemcpyAsync(fin + 7, L.counters + 7, 8, hipMemcpyDeviceToHost, stream));
-            VDF_HIP(ctx, hipStreamSynchronize(stream));
-            d_list = ctx->hits2.as<vdf_hit>();
-            stored = fin[7];
-            n_out = stored;
-            have = 0;  // the speculative copy held unfiltered pairs
-            ctx->timing.hits_filtered += produced - stored;
+    vdf_hit *d_list = ctx->hits.as<vdf_hit>();
+    uint64_t have = std::min(stored, spec);
+    // Dense near-duplicates: most of the thresholded pairs belong to rows the greedy replay never uses as targets
+    // (hamming.hip: launch_filter_*).  With the COMPLETE hit set of the launch in hand they are dropped here, before the
+    // sort, the download and the host replay - a cluster of s mutual duplicates sends down s - 1 pairs instead of
+    // s (s - 1) / 2.  A sharded launch has the complete set spread over its shards: they agree that nobody overflowed, and OR
+    // the two bitmaps (1 bit per entry: 125 KB per million) between the steps.  EVERY shard takes part, also one without hits.
+    bool filter = false;
+    if (replay_only && mode == 0 && !ctx->no_hit_filter) {
+        bool complete = produced <= capacity && (uint32_t)fin[4] == 0xFFFFFFFFu;
+        uint64_t total = produced;
+        if (fx) {
+            const int r = fx->agree(shard_index, ctx, &complete, &total);
+            if (r) return r;
+        } else if (shard_count != 1) {
+            complete = false;
         }
+        filter = complete && total >= kFilterHits;
+    }
+    if (filter) {
+        const size_t words = ((size_t)n_cols + 31) / 32;
+        VDF_HIP(ctx, ctx->hits2.reserve((size_t)std::max<uint64_t>(stored, 1) * sizeof(vdf_hit)));
+        VDF_HIP(ctx, ctx->hit_bitmaps.reserve(2 * words * 4 + 16));
+        uint32_t *bm = ctx->hit_bitmaps.as<uint32_t>();
+        VDF_HIP(ctx, vdf::launch_filter_mark_incoming(d_list, stored, (uint32_t)n_cols, bm, stream));
+        if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm, words, stream); if (r) return r; }
+        VDF_HIP(ctx, vdf::launch_filter_mark_covered(d_list, stored, (uint32_t)n_cols, bm, stream));
+        if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm + words, words, stream); if (r) return r; }
+        VDF_HIP(ctx, vdf::launch_filter_compact(d_list, stored, (uint32_t)n_cols, bm, ctx->hits2.as<vdf_hit>(), L.counters + 7, stream));
+        VDF_HIP(ctx, hipMemcpyAsync(fin + 7, L.counters + 7, 8, hipMemcpyDeviceToHost, stream));
+        VDF_HIP(ctx, hipStreamSynchronize(stream));
+        d_list = ctx->hits2.as<vdf_hit>();
+        stored = fin[7];
+        n_out = stored;
+        have = 0;  // the speculative copy held unfiltered pairs
+        ctx->timing.hits_filtered += produced - stored;
+    }
+    if (stored) {
         if (staging) {  // the library's own staging grows to the list (host-level calls)
             const size_t need = std::max<size_t>((size_t)stored, 1u << 16);
             if (staging->size() < need && !staging->resize(need + need / 4)) return fail(ctx, VDF_E_OOM, "hit staging");
@@ -1041,11 +1060,16 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     for (int k = 0; k < G; k++) { device_ctx(ctx, k)->stats = vdf_search_stats{}; device_ctx(ctx, k)->timing = vdf_search_timing{}; }
     while (row_begin < n) {
         const uint32_t row_end = (uint32_t)std::min<uint64_t>((uint64_t)row_begin + span, n);
+        // the hits feed the replay and nothing else: rows that cannot become targets are dropped on the devices, which meet for
+        // that through the context's own exchange when there are several (multi.cpp: LocalExchange)
+        std::unique_ptr<ShardExchange> fx(make_local_exchange(ctx));
         int rc = for_each_device(ctx, [&](int k, vdf_ctx *d) {
-            return search_core(d, 0, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n, d->up_hashes.as<uint64_t>(),
-                               d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
-                               use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, nullptr, capacity,
-                               &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/G == 1, &d->host_hits);
+            const int r = search_core(d, 0, d->up_hashes.as<uint64_t>(), d->up_dur.as<uint32_t>(), n, d->up_hashes.as<uint64_t>(),
+                                      d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
+                                      use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, nullptr, capacity,
+                                      &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/true, &d->host_hits, fx.get());
+            if (r && fx) fx->abort();  // the other devices must not wait for this one at the filter's meeting points
+            return r;
         });
         if (rc) { vdf_groups_free(out); return rc; }
         uint32_t overflow_row = 0xFFFFFFFFu;
@@ -1139,6 +1163,8 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
     tm.replay_ms = (float)(replay_ms + now_ms() - t_fin);
     tm.total_ms = (float)(now_ms() - t_call);
     ctx->timing = tm;
+    ctx->dev_timing.assign((size_t)G, vdf_search_timing{});
+    for (int k = 0; k < G; k++) ctx->dev_timing[(size_t)k] = device_ctx(ctx, k)->timing;
     return rc_fin;
 }
 
@@ -1188,6 +1214,8 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
         tm.suspects += q.suspects; tm.suspect_capacity = std::max(tm.suspect_capacity, q.suspect_capacity);
         tm.hits_filtered += q.hits_filtered;
     }
+    ctx->dev_timing.assign((size_t)G, vdf_search_timing{});
+    for (int k = 0; k < G; k++) ctx->dev_timing[(size_t)k] = device_ctx(ctx, k)->timing;
     const double t_group = now_ms();
     int rcg;
     if (G == 1) {
@@ -1426,6 +1454,58 @@ int vdf_search_self_device(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return search_core(ctx, 0, d_hashes, d_durations, n, d_hashes, d_durations, nullptr, n, tol_int, shard_index,
                        shard_count, row_begin, row_end, d_matched, 0, hits, capacity, n_hits, overflow_row, s);
+}
+
+namespace {
+// the caller's callbacks (include/vdf.h: vdf_shard_exchange) behind the library's exchange interface
+struct CallbackExchange final : vdf_impl::ShardExchange {
+    const vdf_shard_exchange *x;
+    explicit CallbackExchange(const vdf_shard_exchange *x_) : x(x_) {}
+    int agree(uint32_t, vdf_ctx *d, bool *all_complete, uint64_t *total_hits) override
+    {
+        int c = *all_complete ? 1 : 0;
+        const int rc = x->agree(x->user, &c, total_hits);
+        if (rc) return fail(d, rc, "the shard exchange's agree callback failed");
+        *all_complete = c != 0;
+        return VDF_OK;
+    }
+    int or_bitmap(uint32_t, vdf_ctx *d, uint32_t *d_bitmap, size_t n_words, hipStream_t stream) override
+    {
+        const int rc = x->or_bitmap(x->user, d_bitmap, n_words, (void *)stream);
+        if (rc) return fail(d, rc, "the shard exchange's or_bitmap callback failed");
+        return VDF_OK;
+    }
+};
+}  // namespace
+
+int vdf_search_self_device_replay(vdf_ctx *ctx, const uint64_t *d_hashes, const uint32_t *d_durations, size_t n,
+                                  uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin,
+                                  uint32_t row_end, const uint32_t *d_matched, vdf_hit *hits, uint64_t capacity,
+                                  uint64_t *n_hits, uint32_t *overflow_row, const vdf_shard_exchange *xchg, void *stream)
+{
+    if (!ctx || !n_hits || !overflow_row || (capacity && !hits)) return VDF_E_INVAL;
+    if (xchg && (!xchg->agree || !xchg->or_bitmap)) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
+    ctx->stats = vdf_search_stats{};
+    ctx->timing = vdf_search_timing{};
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    CallbackExchange fx(xchg);
+    return search_core(ctx, 0, d_hashes, d_durations, n, d_hashes, d_durations, nullptr, n, tol_int, shard_index,
+                       shard_count, row_begin, row_end, d_matched, 0, hits, capacity, n_hits, overflow_row, s,
+                       /*replay_only=*/true, nullptr, xchg ? &fx : nullptr);
+}
+
+int vdf_bitmap_or_device(vdf_ctx *ctx, uint32_t *d_dst, const uint32_t *d_srcs, size_t n_words, uint32_t n_srcs, void *stream)
+{
+    // takes no lock and touches no scratch of the context: it is what an or_bitmap callback calls from INSIDE
+    // vdf_search_self_device_replay, which holds the context's lock
+    if (!ctx || !ctx->subs.empty()) return VDF_E_INVAL;
+    if (n_words == 0 || n_srcs == 0) return VDF_OK;
+    if (!d_dst || !d_srcs) return VDF_E_INVAL;
+    VDF_HIP(ctx, hipSetDevice(ctx->device));
+    VDF_HIP(ctx, vdf::launch_bitmap_or(d_dst, d_srcs, n_words, n_srcs, stream ? (hipStream_t)stream : ctx->stream));
+    return VDF_OK;
 }
 
 int vdf_search_refs_device(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,

@@ -891,19 +891,57 @@ __global__ __launch_bounds__(256) void hits_compact_kernel(const vdf_hit *__rest
     }
 }
 
-// bitmaps: 2 x ceil(n_entries / 32) words (has_in | covered), zeroed here; *counter (device) receives the survivors' count
-hipError_t launch_filter_replay_hits(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps,
-                                     vdf_hit *out, unsigned long long *counter, hipStream_t stream)
+// dst[w] |= srcs[0][w] | srcs[1][w] | ... (n_srcs bitmaps of n_words words each, laid out back to back): the local half of the
+// cross-shard OR of the filter's bitmaps, after an all-gather put every shard's copy into `srcs`
+__global__ __launch_bounds__(256) void bitmap_or_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ srcs, size_t n_words,
+                                                        uint32_t n_srcs)
+{
+    for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < n_words; w += (size_t)gridDim.x * 256) {
+        uint32_t v = dst[w];
+        for (uint32_t r = 0; r < n_srcs; r++) v |= srcs[(size_t)r * n_words + w];
+        dst[w] = v;
+    }
+}
+
+hipError_t launch_bitmap_or(uint32_t *dst, const uint32_t *srcs, size_t n_words, uint32_t n_srcs, hipStream_t stream)
+{
+    if (n_words == 0 || n_srcs == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)std::min<size_t>((n_words + 255) / 256, 4096);
+    hipLaunchKernelGGL(bitmap_or_kernel, dim3(grid), dim3(256), 0, stream, dst, srcs, n_words, n_srcs);
+    return hipGetLastError();
+}
+
+// The filter in three steps, so that a SHARDED launch (every shard holds the hits of its own row tiles) can OR the bitmaps of
+// all shards between them: has_in and covered are properties of the COMPLETE hit set.
+//   1. filter_mark_incoming: zero both bitmaps (2 x ceil(n_entries / 32) words: has_in | covered), mark has_in from this shard's hits
+//      -> OR has_in over the shards
+//   2. filter_mark_covered: covered[col] for every hit whose row is a root          -> OR covered over the shards
+//   3. filter_compact: keep the hits whose row is not covered; *counter (device) receives the survivors' count
+static inline uint32_t filter_grid(unsigned long long n_hits) { return (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>((n_hits + 255) / 256, 1ull), 8192ull); }
+
+hipError_t launch_filter_mark_incoming(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps, hipStream_t stream)
 {
     const size_t words = ((size_t)n_entries + 31) / 32;
     hipError_t e = hipMemsetAsync(bitmaps, 0, 2 * words * 4, stream);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(counter, 0, 8, stream);
+    if (n_hits) hipLaunchKernelGGL(hits_mark_incoming_kernel, dim3(filter_grid(n_hits)), dim3(256), 0, stream, hits, n_hits, bitmaps);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_mark_covered(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps, hipStream_t stream)
+{
+    const size_t words = ((size_t)n_entries + 31) / 32;
+    if (n_hits) hipLaunchKernelGGL(hits_mark_covered_kernel, dim3(filter_grid(n_hits)), dim3(256), 0, stream, hits, n_hits, bitmaps, bitmaps + words);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_compact(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, const uint32_t *bitmaps, vdf_hit *out,
+                                 unsigned long long *counter, hipStream_t stream)
+{
+    const size_t words = ((size_t)n_entries + 31) / 32;
+    hipError_t e = hipMemsetAsync(counter, 0, 8, stream);
     if (e != hipSuccess) return e;
-    const uint32_t grid = (uint32_t)std::min<unsigned long long>((n_hits + 255) / 256, 8192ull);
-    hipLaunchKernelGGL(hits_mark_incoming_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps);
-    hipLaunchKernelGGL(hits_mark_covered_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps, bitmaps + words);
-    hipLaunchKernelGGL(hits_compact_kernel, dim3(grid), dim3(256), 0, stream, hits, n_hits, bitmaps + words, out, counter);
+    if (n_hits) hipLaunchKernelGGL(hits_compact_kernel, dim3(filter_grid(n_hits)), dim3(256), 0, stream, hits, n_hits, bitmaps + words, out, counter);
     return hipGetLastError();
 }
 

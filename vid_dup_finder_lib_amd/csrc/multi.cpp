@@ -247,6 +247,101 @@ static int replicate(vdf_ctx *ctx, const void *const *shards, const size_t *shar
     return VDF_OK;
 }
 
+// ---- the replay filter's meeting points for the worker threads of ONE multi-GPU context ---------------------------------------
+// A reusable barrier whose last arriver runs a step for everybody (sums the hit counts; queues the all-gather of the shards' bitmaps
+// on every device's stream - the same replicate() as the database: ONE grouped RCCL collective over xGMI on distinct devices, plain
+// device copies when the device list repeats a GPU).  A shard that fails calls abort(): the others return instead of waiting.
+struct LocalExchange final : ShardExchange {
+    vdf_ctx *parent;
+    size_t G;
+    std::mutex m;
+    std::condition_variable cv;
+    size_t arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    int step_rc = VDF_OK;
+    bool acc_complete = true, res_complete = true;
+    uint64_t acc_total = 0, res_total = 0;
+    std::vector<const void *> ptrs;
+    std::vector<size_t> counts;
+
+    explicit LocalExchange(vdf_ctx *p) : parent(p), G(p->subs.size()), ptrs(p->subs.size(), nullptr), counts(p->subs.size(), 0) {}
+
+    // returns when all G shards have arrived (and the last one has run `last_step`), or the exchange broke
+    int meet(vdf_ctx *d, const std::function<int()> &last_step)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (broken) return fail(d, VDF_E_HIP, "another device of the sharded launch failed");
+        if (++arrived == G) {
+            arrived = 0;
+            step_rc = last_step ? last_step() : (int)VDF_OK;
+            if (step_rc) broken = true;
+            generation++;
+            cv.notify_all();
+            if (step_rc) d->err = parent->err;
+            return step_rc;
+        }
+        const uint64_t gen = generation;
+        cv.wait(lk, [&] { return generation != gen || broken; });
+        if (broken) return fail(d, step_rc ? step_rc : (int)VDF_E_HIP, "another device of the sharded launch failed");
+        return VDF_OK;
+    }
+
+    int agree(uint32_t, vdf_ctx *d, bool *all_complete, uint64_t *total_hits) override
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            acc_complete = acc_complete && *all_complete;
+            acc_total += *total_hits;
+        }
+        const int rc = meet(d, [&] {
+            res_complete = acc_complete; res_total = acc_total;
+            acc_complete = true; acc_total = 0;
+            return (int)VDF_OK;
+        });
+        if (rc) return rc;
+        *all_complete = res_complete;  // stable until every shard has passed the next meeting point
+        *total_hits = res_total;
+        return VDF_OK;
+    }
+
+    int or_bitmap(uint32_t shard, vdf_ctx *d, uint32_t *d_bitmap, size_t n_words, hipStream_t stream) override
+    {
+        VDF_HIP(d, d->bitmap_gather.reserve(G * n_words * 4 + 16));
+        // peers read this bitmap (device copies on THEIR streams in the repeated-device form): the marking kernels must be done
+        VDF_HIP(d, hipStreamSynchronize(stream));
+        {
+            std::lock_guard<std::mutex> lk(m);
+            ptrs[shard] = d_bitmap;
+            counts[shard] = n_words;
+        }
+        int rc = meet(d, [&] {  // one thread queues the exchange for all devices, as for the database
+            DeviceGuard restore_device;
+            return replicate(parent, ptrs.data(), counts.data(), 4, [](vdf_ctx *q) { return q->bitmap_gather.p; });
+        });
+        if (rc) return rc;
+        if (!devices_distinct(parent) || G == 1) {
+            // plain copies: nobody may change its bitmap before every device's copies of it have finished
+            VDF_HIP(d, hipSetDevice(d->device));
+            VDF_HIP(d, hipStreamSynchronize(d->stream));
+            rc = meet(d, nullptr);
+            if (rc) return rc;
+        }
+        VDF_HIP(d, hipSetDevice(d->device));
+        VDF_HIP(d, vdf::launch_bitmap_or(d_bitmap, d->bitmap_gather.as<uint32_t>(), n_words, (uint32_t)G, stream));
+        return VDF_OK;
+    }
+
+    void abort() override
+    {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
+ShardExchange *make_local_exchange(vdf_ctx *ctx) { return ctx->subs.size() > 1 ? new LocalExchange(ctx) : nullptr; }
+
 }  // namespace vdf_impl
 
 using namespace vdf_impl;
@@ -295,6 +390,15 @@ int vdf_ctx_device_search_stats(const vdf_ctx *ctx, int k, vdf_search_stats *out
     if (ctx->subs.empty()) { *out = ctx->stats; return VDF_OK; }
     if ((size_t)k >= ctx->dev_stats.size()) { *out = vdf_search_stats{}; return VDF_OK; }
     *out = ctx->dev_stats[(size_t)k];
+    return VDF_OK;
+}
+
+int vdf_ctx_device_search_timing(const vdf_ctx *ctx, int k, vdf_search_timing *out)
+{
+    if (!ctx || !out || k < 0 || k >= device_count(ctx)) return VDF_E_INVAL;
+    if (ctx->subs.empty()) { *out = ctx->timing; return VDF_OK; }
+    if ((size_t)k >= ctx->dev_timing.size()) { *out = vdf_search_timing{}; return VDF_OK; }
+    *out = ctx->dev_timing[(size_t)k];
     return VDF_OK;
 }
 

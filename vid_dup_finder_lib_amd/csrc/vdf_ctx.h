@@ -86,6 +86,19 @@ namespace vdf_impl {
 struct Worker;     // one host thread bound to one device (multi.cpp)
 struct RcclState;  // communicators of a multi-GPU context (multi.cpp)
 struct CopyPool;   // host threads that gather caller frames into pinned staging (hash_host.cpp)
+
+// The steps every shard of ONE sharded search() launch enters together, so that the replay filter (hamming.hip: has_in / covered are
+// properties of the COMPLETE hit set) also works when the row tiles are dealt over several devices or processes.  Implementations:
+// the worker threads of a multi-GPU context (multi.cpp: LocalExchange) and the caller's callbacks (include/vdf.h: vdf_shard_exchange).
+// Every shard makes the same sequence of calls; abort() releases the others when a shard leaves early with an error.
+struct ShardExchange {
+    virtual ~ShardExchange() = default;
+    // in: this shard's "my hit list is complete" and its hit count; out: AND / sum over all shards
+    virtual int agree(uint32_t shard, vdf_ctx *d, bool *all_complete, uint64_t *total_hits) = 0;
+    // d_bitmap[0 .. n_words) |= every other shard's, in place, ordered on `stream` (the marking kernels were queued there)
+    virtual int or_bitmap(uint32_t shard, vdf_ctx *d, uint32_t *d_bitmap, size_t n_words, hipStream_t stream) = 0;
+    virtual void abort() {}
+};
 }
 
 // What the fp4 expansion in exp_cols was made from (reused only for a database the caller pinned)
@@ -115,6 +128,7 @@ struct vdf_ctx {
     DevBuf row_lo, row_hi, tile_lo, tile_hi, tile_first, tile_count, tile_offset, counters, hits, perm, matched;
     DevBuf up_hashes, up_dur, up_ref_hashes, up_ref_dur;
     DevBuf hits2, hit_bitmaps;  // replay filter: surviving hits, has-incoming / covered bitmaps
+    DevBuf bitmap_gather;       // sharded replay filter: every shard's copy of one bitmap, before the local OR
     DevBuf sort_scratch;  // keys / indices / rocPRIM temporary storage of the device-side sorts inside a search call
     DevBuf sort_scratch_pub;  // the same for vdf_sort_order_device: the caller may sort on one stream and search on another
     // hash scratch
@@ -173,6 +187,7 @@ struct vdf_ctx {
     std::vector<vdf_impl::Worker *> workers;      // one host thread per sub-context
     vdf_impl::RcclState *rccl = nullptr;
     std::vector<vdf_search_stats> dev_stats;      // per-device statistics of the last search
+    std::vector<vdf_search_timing> dev_timing;    // per-device phase times / filter counts of the last search
 
     ~vdf_ctx();
 };
@@ -212,7 +227,8 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
                 uint32_t tol_int, uint32_t shard_index, uint32_t shard_count, uint32_t row_begin, uint32_t row_end,
                 const uint32_t *d_matched, uint32_t row_index_base, vdf_hit *hits, uint64_t capacity,
                 uint64_t *n_hits_out, uint32_t *overflow_row_out, hipStream_t stream, bool replay_only = false,
-                vdf_ctx::HostHits *staging = nullptr);  // staging: the list goes to this growable pinned buffer instead of `hits`
+                vdf_ctx::HostHits *staging = nullptr,  // staging: the list goes to this growable pinned buffer instead of `hits`
+                ShardExchange *fx = nullptr);          // replay_only launches of shard_count > 1: how the shards meet for the filter
 int search_refs_device_locked(vdf_ctx *ctx, const uint64_t *d_cand_hashes, const uint32_t *d_cand_durations,
                               size_t n_cand, const uint64_t *d_ref_hashes, const uint32_t *d_ref_durations, size_t n_ref,
                               uint32_t tol_int, uint32_t ref_index_base, vdf_hit *hits, uint64_t capacity,
@@ -241,5 +257,7 @@ int for_each_device(vdf_ctx *ctx, const std::function<int(int, vdf_ctx *)> &f);
 inline int device_count(const vdf_ctx *ctx) { return ctx->subs.empty() ? 1 : (int)ctx->subs.size(); }
 inline vdf_ctx *device_ctx(vdf_ctx *ctx, int k) { return ctx->subs.empty() ? ctx : ctx->subs[k]; }
 void destroy_multi(vdf_ctx *ctx);  // joins the workers, destroys communicators and sub-contexts
+// the exchange of the context's own worker threads (one per launch round); nullptr for a single-device context
+ShardExchange *make_local_exchange(vdf_ctx *ctx);
 
 }  // namespace vdf_impl

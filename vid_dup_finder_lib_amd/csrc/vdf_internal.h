@@ -65,9 +65,13 @@ hipError_t launch_expand_fp4(const uint32_t *packed, uint32_t n, uint32_t n_pad,
                              float *pop3, hipStream_t stream);
 hipError_t launch_hamming_tiles_mfma2(const SearchLaunch &L, uint32_t total_tiles, hipStream_t stream);  // branch-free stream; tile_rows 512 or 256
 hipError_t launch_resolve_candidates(const SearchLaunch &L, hipStream_t stream);  // its second pass: suspects evaluated exactly
-// drops the hits of rows that can never become targets of the greedy replay (hamming.hip); needs the launch's complete hit set
-hipError_t launch_filter_replay_hits(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps,
-                                     vdf_hit *out, unsigned long long *counter, hipStream_t stream);
+// drops the hits of rows that can never become targets of the greedy replay (hamming.hip); needs the COMPLETE hit set: a sharded
+// launch ORs has_in (after step 1) and covered (after step 2) over its shards.  bitmaps = has_in | covered, ceil(n_entries / 32) words each
+hipError_t launch_filter_mark_incoming(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps, hipStream_t stream);
+hipError_t launch_filter_mark_covered(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, uint32_t *bitmaps, hipStream_t stream);
+hipError_t launch_filter_compact(const vdf_hit *hits, unsigned long long n_hits, uint32_t n_entries, const uint32_t *bitmaps, vdf_hit *out,
+                                 unsigned long long *counter, hipStream_t stream);
+hipError_t launch_bitmap_or(uint32_t *dst, const uint32_t *srcs, size_t n_words, uint32_t n_srcs, hipStream_t stream);  // dst |= OR of n_srcs bitmaps
 hipError_t launch_group_max_distance(const uint32_t *hashes, const unsigned long long *offsets,
                                      const unsigned long long *members, const uint32_t *ref_hashes,
                                      const long long *ref_index, uint32_t n_groups, uint32_t *out, hipStream_t stream);

@@ -116,13 +116,64 @@ def _coll_device(group=None) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
 
+class DistExchange:
+    """How the ranks of one sharded search() launch meet for the replay filter (include/vdf.h: vdf_shard_exchange; the library
+    drops hits of rows that can never become targets, which is a property of the COMPLETE hit set): one all-gather of
+    (complete, hits) per launch, and - only when the filter runs - two all-gathers of a bitmap of 1 bit per entry (125 KB
+    per million entries and rank), OR-ed on the device by the library (RCCL has no bitwise-OR reduction)."""
+
+    def __init__(self, device: torch.device, group=None):
+        self.dev, self.group = device, group
+        self.rank, self.world = _world(group)
+        self.filtered_launches = 0
+
+    def agree(self, complete: bool, total_hits: int):
+        cdev = _coll_device(self.group)
+        mine = torch.tensor([1 if complete else 0, int(total_hits)], dtype=torch.int64, device=cdev)
+        allv = torch.empty(2 * self.world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(allv, mine, group=self.group)
+        v = allv.view(self.world, 2).cpu()
+        return bool(v[:, 0].min().item()), int(v[:, 1].sum().item())
+
+    def or_bitmap(self, engine, d_bitmap: int, n_words: int, stream: int):
+        dev = self.dev
+        on_gpu = dev.type == "cuda"
+        # the library runs on `stream`; torch's tensors and collectives are ordered on torch's current stream
+        foreign = on_gpu and int(stream) != int(torch.cuda.current_stream(dev).cuda_stream)
+
+        def fence():
+            if foreign:
+                torch.cuda.synchronize(dev)
+
+        local = torch.zeros(n_words, dtype=torch.int32, device=dev)
+        fence()
+        engine.bitmap_or_device(local.data_ptr(), d_bitmap, n_words, 1, stream)  # a copy: the destination is zero
+        fence()
+        if on_gpu and dist.get_backend(self.group) == "nccl":
+            gathered = torch.empty(self.world * n_words, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+        else:  # test route (gloo): the collective runs on host copies
+            host = torch.empty(self.world * n_words, dtype=torch.int32)
+            dist.all_gather_into_tensor(host, local.cpu(), group=self.group)
+            gathered = host.to(dev)
+        fence()
+        engine.bitmap_or_device(d_bitmap, gathered.data_ptr(), n_words, self.world, stream)
+        fence()  # `gathered` goes back to torch's allocator when this returns
+        self.filtered_launches += 1
+
+
 def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_int: int, capacity: int = 1 << 22,
-                        group=None, stream: Optional[int] = None) -> Optional[List[List[int]]]:
+                        group=None, stream: Optional[int] = None, stats: Optional[dict] = None) -> Optional[List[List[int]]]:
     """search() over a replicated, sorted database.  Returns the groups (lists of sorted indices, reference
     order) on rank 0 and None elsewhere.  d_words/d_dur live on this rank's GPU.  stream=None: torch's current stream
-    (the one the all-gather and the consumption-bitmap copies are ordered on)."""
+    (the one the all-gather and the consumption-bitmap copies are ordered on).  The hits feed the replay only, so every
+    rank drops the rows that cannot become targets before its list leaves the device (DistExchange).
+    stats (optional dict) receives hits_downloaded (this rank) and filtered_launches."""
     rank, world = _world(group)
     stream = _stream_for(d_words, stream)
+    replay_call = getattr(engine, "search_self_device_replay", None)
+    xchg = DistExchange(d_words.device, group) if (world > 1 and replay_call is not None) else None
+    downloaded = 0
     n = int(d_dur.shape[0])
     if n == 0:
         return [] if rank == 0 else None
@@ -133,10 +184,13 @@ def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_
     row_end = UINT32_MAX
     while row_begin < n:
         _before_engine_call(d_words, stream)
-        hits, n_hits, overflow = engine.search_self_device(
-            d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, shard_index=rank, shard_count=world,
-            row_begin=row_begin, row_end=row_end, d_matched=(d_matched.data_ptr() if d_matched is not None else 0),
-            capacity=capacity, stream=stream)
+        kw = dict(shard_index=rank, shard_count=world, row_begin=row_begin, row_end=row_end,
+                  d_matched=(d_matched.data_ptr() if d_matched is not None else 0), capacity=capacity, stream=stream)
+        if replay_call is not None:
+            hits, n_hits, overflow = replay_call(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, exchange=xchg, **kw)
+        else:
+            hits, n_hits, overflow = engine.search_self_device(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, **kw)
+        downloaded += len(hits)
         if world > 1:
             t = torch.tensor([overflow], dtype=torch.int64, device=_coll_device(group))
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
@@ -168,6 +222,9 @@ def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_
         if world > 1:
             dist.broadcast(bm, src=0, group=group)
         d_matched = bm.to(d_words.device)
+    if stats is not None:
+        stats["hits_downloaded"] = downloaded
+        stats["filtered_launches"] = xchg.filtered_launches // 2 if xchg is not None else 0
     if rank != 0:
         return None
     if groups is None:

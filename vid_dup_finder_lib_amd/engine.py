@@ -114,6 +114,11 @@ class Engine:
         self._check(self.lib.vdf_ctx_device_search_stats(self.ctx, int(slot), C.byref(s)))
         return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
 
+    def device_timing(self, slot: int) -> dict:
+        t = VdfSearchTiming()
+        self._check(self.lib.vdf_ctx_device_search_timing(self.ctx, int(slot), C.byref(t)))
+        return {k: getattr(t, k) for k, _ in VdfSearchTiming._fields_}
+
     # ------------------------------------------------------- multi-GPU contexts: device-resident shards
     def search_self_shards(self, d_hash_shards: Sequence[int], d_dur_shards: Sequence[int], shard_n: Sequence[int],
                            tol_int: int, as_arrays: bool = False):
@@ -295,6 +300,53 @@ class Engine:
                                                     C.byref(overflow), stream or None))
         k = min(int(n_hits.value), capacity)
         return hits[:k].copy(), int(n_hits.value), int(overflow.value)
+
+    def search_self_device_replay(self, d_hashes: int, d_durations: int, n: int, tol_int: int, shard_index: int = 0,
+                                  shard_count: int = 1, row_begin: int = 0, row_end: int = UINT32_MAX, d_matched: int = 0,
+                                  capacity: int = 1 << 22, stream: int = 0, exchange=None):
+        """search_self_device for a caller that only replays the hits (vdf_search_self_device_replay): rows that can never
+        become targets are dropped on the device.  `exchange` (sharded launches) is how the shards meet for that:
+            exchange.agree(complete: bool, total_hits: int) -> (all_complete, total_hits_of_all_shards)
+            exchange.or_bitmap(engine, d_bitmap: int, n_words: int, stream: int)   # OR over the shards, in place, on the device
+        Returns (hits [k, 2] u32 sorted, hits kept, overflow_row)."""
+        hits = self._hit_buffer(capacity)
+        n_hits = C.c_uint64(0)
+        overflow = C.c_uint32(0)
+        x = None
+        errors = []
+        if exchange is not None:
+            def _agree(_user, p_complete, p_total):
+                try:
+                    c, t = exchange.agree(bool(p_complete[0]), int(p_total[0]))
+                    p_complete[0] = 1 if c else 0
+                    p_total[0] = int(t)
+                    return 0
+                except Exception as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+                    errors.append(e)
+                    return _capi.VDF_E_INVAL
+
+            def _or(_user, d_bitmap, n_words, strm):
+                try:
+                    exchange.or_bitmap(self, int(d_bitmap or 0), int(n_words), int(strm or 0))
+                    return 0
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+                    return _capi.VDF_E_INVAL
+
+            x = _capi.VdfShardExchange(None, _capi.AGREE_FN(_agree), _capi.OR_BITMAP_FN(_or))
+        rc = self.lib.vdf_search_self_device_replay(self.ctx, d_hashes, d_durations, n, int(tol_int), shard_index, shard_count,
+                                                    row_begin, min(row_end, UINT32_MAX), d_matched or None, hits.ctypes.data,
+                                                    capacity, C.byref(n_hits), C.byref(overflow),
+                                                    C.byref(x) if x is not None else None, stream or None)
+        if errors:
+            raise errors[0]
+        self._check(rc)
+        k = min(int(n_hits.value), capacity)
+        return hits[:k].copy(), int(n_hits.value), int(overflow.value)
+
+    def bitmap_or_device(self, d_dst: int, d_srcs: int, n_words: int, n_srcs: int, stream: int = 0):
+        """d_dst[w] |= OR over n_srcs bitmaps of n_words u32 words laid out back to back at d_srcs (device pointers)."""
+        self._check(self.lib.vdf_bitmap_or_device(self.ctx, d_dst, d_srcs, int(n_words), int(n_srcs), stream or None))
 
     def search_refs_device(self, d_cand_hashes: int, d_cand_durations: int, n_cand: int, d_ref_hashes: int,
                            d_ref_durations: int, n_ref: int, tol_int: int, ref_index_base: int = 0,
