@@ -68,6 +68,25 @@ def _shard_sizes(n, G, kind):
 
 
 @needs_two
+def test_replay_filter_over_distinct_devices(multi):
+    """A duplicate-dense database over DISTINCT GPUs: the devices OR their has-incoming / covered bitmaps through ONE grouped
+    ncclAllGather each (csrc/multi.cpp: LocalExchange -> replicate) and every device drops the rows that cannot become targets
+    (search_algorithm.rs:141-161); what comes down is s - 1 pairs per cluster.  tests/test_gpu_dup_heavy.py runs the same on a
+    repeated device 0, where the exchange is plain device copies."""
+    import bench
+
+    G = multi.n_devices
+    w, d, n_clusters, cluster_pairs = bench.make_dup_heavy(200_000)
+    want = orc.search_self_sorted(w, d, 350)
+    for _ in range(2):
+        assert multi.search_self_sorted(w, d, 350) == want
+        st, tm = multi.last_stats(), multi.last_timing()
+        per = [multi.device_timing(k)["hits_filtered"] for k in range(G)]
+        assert st["n_hits"] == cluster_pairs and all(p > 0 for p in per) and sum(per) == tm["hits_filtered"]
+        assert st["n_hits"] - tm["hits_filtered"] == 20_000 - n_clusters <= 0.02 * cluster_pairs
+
+
+@needs_two
 @pytest.mark.parametrize("kind", ["equal", "uneven", "empty"])
 def test_shards_on_distinct_devices_match_the_oracle(multi, kind):
     """vdf_search_self_shards / vdf_search_refs_shards with shard k resident on GPU k: equal shards take ncclAllGather,
