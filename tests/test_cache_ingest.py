@@ -54,6 +54,37 @@ def test_path_ranks_equal_the_python_sort_key(n_threads):
     assert vc.path_ranks([], n_threads).shape == (0,)
 
 
+@pytest.mark.parametrize("n_threads", [1, 4])
+def test_path_ranks_of_plain_paths_take_the_byte_order_road(n_threads):
+    """Paths as a directory walk produces them (no empty, "." or ".." component - csrc/path_order.cpp: is_plain) are ranked without
+    component iteration: byte order with '/' below everything, 8-byte words riding along with the indices.  The traps of that road:
+    bytes below '/' (' ', '!', '-', '.', 0x01) next to a separator, names that are prefixes of each other (a path that ends against
+    one that goes on with '/' or with a byte), dot-names that are NOT special (".a", "..a", "..."), bytes >= 0x80, absolute against
+    relative, long shared prefixes, exact duplicates, and sizes on both sides of the sample sort's threshold."""
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"\x01 !-.0Aa~\x80\xff", np.uint8)
+
+    def name(lo, hi):
+        while True:
+            b = bytes(alphabet[rng.integers(len(alphabet), size=int(rng.integers(lo, hi)))])
+            if b not in (b".", b".."):
+                return b
+
+    for n in (300, 6000, 40000):
+        roots = [b"", b"/", b"/mnt/library/videos/", b"mnt/library/videos/", b"/mnt/library/videos.old/", b"/mnt/library/videos/x/"]
+        dirs = [name(1, 4) for _ in range(12)]
+        paths = []
+        for _ in range(n):
+            depth = int(rng.integers(0, 4))
+            comps = [dirs[int(rng.integers(len(dirs)))] for _ in range(depth)] + [name(1, 12)]
+            paths.append(roots[int(rng.integers(len(roots)))] + b"/".join(comps))
+        paths += paths[: n // 10] + [b"", b"/", b"/mnt", b"/mnt/library/videos", b"mnt"]
+        assert np.array_equal(vc.path_ranks(paths, n_threads), _dense_ranks(paths)), n
+    # one non-plain path among them sends the whole call down the general road: same answer
+    paths[17] = b"/mnt//library/./videos/a"
+    assert np.array_equal(vc.path_ranks(paths, n_threads), _dense_ranks(paths))
+
+
 def test_path_ranks_take_the_decoders_blob_without_objects():
     paths = [f"/v/d{i % 13}/c{i * 7919 % 5000}.mkv" for i in range(5000)]
     rng = np.random.default_rng(2)
@@ -86,6 +117,10 @@ def test_metadata_parse_follows_try_parse():
     m = P("Unix,FfmpegBackend,Letterbox,15,1")
     assert m == vc.CacheMetadata.new("letterbox", 15.0) and P(m.to_disk_fmt()) == m
     assert P("  WINDOWS\t, gstreamerBACKEND ,Motion,+1.5e1,+2") == vc.CacheMetadata(0, 1, 2, 15.0, 2)
+    # str::trim takes Unicode White_Space, not only ASCII: NBSP, NEL, EN QUAD, IDEOGRAPHIC SPACE, LINE SEPARATOR (ZERO WIDTH SPACE is not one)
+    assert P("\u00a0\u0085Unix\u2000\u3000,\u2028FfmpegBackend\u205f,None,0,1") == vc.CacheMetadata.new("none", 0.0)
+    with pytest.raises(vc.CacheMetadataError, match="Could not parse operating_system"):
+        P("\u200bUnix,FfmpegBackend,None,0,1")
     for f, v in [("1.", 1.0), (".5", 0.5), ("1e3", 1000.0), ("1E-2", 0.01), ("-3", -3.0), ("inf", float("inf")), ("-Infinity", float("-inf")),
                  ("1e999", float("inf")), ("1e-999", 0.0), ("007", 7.0)]:
         assert P(f"unix,ffmpegbackend,None,{f},1").skip_forward_amount == v
@@ -128,7 +163,10 @@ def test_metadata_path_is_file_stem_plus_suffix():
     """video_hash_filesystem_cache.rs:93-104: Path::file_stem + with_file_name."""
     for p, want in [("/home/u/.cache/vid_dup_finder/vid_dup_finder_cache.bin", "/home/u/.cache/vid_dup_finder/vid_dup_finder_cache.metadata.txt"),
                     ("cache", "cache.metadata.txt"), ("c.tar.gz", "c.tar.metadata.txt"), (".hidden", ".hidden.metadata.txt"), ("d/.h.bin", "d/.h.metadata.txt"),
-                    ("d/c.bin/", "d/c.metadata.txt"), ("d/c.bin/.", "d/c.metadata.txt"), ("/c.", "/c.metadata.txt"), ("a/b.c/d", "a/b.c/d.metadata.txt")]:
+                    ("d/c.bin/", "d/c.metadata.txt"), ("d/c.bin/.", "d/c.metadata.txt"), ("/c.", "/c.metadata.txt"), ("a/b.c/d", "a/b.c/d.metadata.txt"),
+                    # with_file_name pops to Path::parent(), which normalises the directory's tail: repeated separators and "." pieces go
+                    ("d//c.bin", "d/c.metadata.txt"), ("d/./c.bin", "d/c.metadata.txt"), ("//c.bin", "/c.metadata.txt"), ("./c.bin", "./c.metadata.txt"),
+                    ("d/s/.//c.bin/", "d/s/c.metadata.txt"), ("/c.bin", "/c.metadata.txt")]:
         assert vc.metadata_path(p) == want, p
     for bad in ["..", "/", "a/..", ".", ""]:
         with pytest.raises(VdfError):

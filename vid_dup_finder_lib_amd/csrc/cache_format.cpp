@@ -17,8 +17,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../include/vdf.h"
 
@@ -159,6 +163,20 @@ static const uint8_t *find_entry_start(const uint8_t *from, const uint8_t *end)
 
 std::atomic<unsigned long long> g_decode_fallbacks{0};
 
+// The decoder's output arrays: first touched by the copy pass, i.e. one page fault per 4 KB of a few hundred MB (10 M entries: 1.5 GB)
+// - which costs more than parsing the bytes.  Large arrays are 2 MB-aligned and ask for transparent huge pages (the usual system setting
+// is "madvise"); freed with free() like the small ones.
+void *big_alloc(size_t bytes)
+{
+    constexpr size_t kHuge = 2u << 20;
+    if (bytes < 4 * kHuge) return std::malloc(std::max<size_t>(bytes, 1));
+    void *p = nullptr;
+    const size_t rounded = (bytes + kHuge - 1) / kHuge * kHuge;
+    if (posix_memalign(&p, kHuge, rounded) != 0) return std::malloc(bytes);
+    (void)madvise(p, rounded, MADV_HUGEPAGE);  // advisory: failure changes nothing but the fault count
+    return p;
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,12 +202,12 @@ int vdf_cache_decode_mt(const uint8_t *data, size_t len, int n_threads, vdf_cach
     // Every array is allocated once at its upper bound and filled in place: an Ok entry takes at least 22 bytes of input (two
     // one-byte strings, mtime, variant, 16 words, duration), so a hostile count cannot make the allocations larger than the file.
     const uint64_t cap = std::min<uint64_t>(n, len / 22 + 1);
-    out->hashes = (uint64_t *)std::malloc((size_t)cap * VDF_HASH_WORDS * sizeof(uint64_t));
-    out->durations = (uint32_t *)std::malloc((size_t)cap * sizeof(uint32_t));
-    out->path_offsets = (uint64_t *)std::malloc(((size_t)cap + 1) * sizeof(uint64_t));
-    out->paths = (char *)std::malloc(std::max<size_t>(len, 1));  // the paths are a subset of the file's bytes
-    out->mtime_secs = (uint64_t *)std::malloc((size_t)cap * sizeof(uint64_t));
-    out->mtime_nanos = (uint32_t *)std::malloc((size_t)cap * sizeof(uint32_t));
+    out->hashes = (uint64_t *)big_alloc((size_t)cap * VDF_HASH_WORDS * sizeof(uint64_t));
+    out->durations = (uint32_t *)big_alloc((size_t)cap * sizeof(uint32_t));
+    out->path_offsets = (uint64_t *)big_alloc(((size_t)cap + 1) * sizeof(uint64_t));
+    out->paths = (char *)big_alloc(std::max<size_t>(len, 1));  // the paths are a subset of the file's bytes
+    out->mtime_secs = (uint64_t *)big_alloc((size_t)cap * sizeof(uint64_t));
+    out->mtime_nanos = (uint32_t *)big_alloc((size_t)cap * sizeof(uint32_t));
     if (!out->hashes || !out->durations || !out->path_offsets || !out->paths || !out->mtime_secs || !out->mtime_nanos) {
         vdf_cache_free(out);
         return VDF_E_OOM;
@@ -199,25 +217,48 @@ int vdf_cache_decode_mt(const uint8_t *data, size_t len, int n_threads, vdf_cach
     const uint8_t *body = r.p, *end = data + len;
     // ---- ranges: one for a small file; else cut where find_entry_start resynchronises (a 1 M-entry cache decodes in 0.11 s on one
     // thread - 1.9 GB/s - so a 10 M-entry cache would spend 1.2 s here in front of a 10 s search)
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
-    const size_t kMinRange = n_threads > 0 ? 4096 : (4u << 20);
+    // Automatic thread count (n_threads = 0): one thread per 8 MB, at most 32 and at most the host's - a 2 MB cache is not worth a thread
+    // start, and beyond ~32 ranges the page faults of the output arrays, not the parsing, set the pace.
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t kMinRange = n_threads > 0 ? 4096 : (8u << 20);
     nt = (unsigned)std::min<size_t>(nt, std::max<size_t>((size_t)(end - body) / kMinRange, 1));
-    std::vector<const uint8_t *> cut{body};
-    for (unsigned k = 1; k < nt; k++) {
-        const uint8_t *guess = body + (size_t)(end - body) / nt * k;
-        const uint8_t *q = guess > cut.back() ? find_entry_start(guess, end) : nullptr;
-        if (q && q > cut.back() && q < end) cut.push_back(q);
+    std::vector<const uint8_t *> cut;
+    std::vector<RangeCounts> cnt;
+    std::vector<uint8_t> ok;
+    try {
+        cut.push_back(body);
+        const size_t range_len = (size_t)(end - body) / nt;
+        for (unsigned k = 1; k < nt; k++) {
+            const uint8_t *guess = body + range_len * k;
+            if (guess <= cut.back()) continue;
+            // a scan that finds nothing within one range length (a stretch of Err entries, hashes whose words are not all 9-byte varints)
+            // gives up: later guesses would only scan a suffix of the same bytes again
+            const uint8_t *q = find_entry_start(guess, std::min(end, guess + range_len + 4096));
+            if (!q) break;
+            if (q > cut.back() && q < end) cut.push_back(q);
+        }
+        cut.push_back(end);
+        cnt.resize(cut.size() - 1);
+        ok.assign(cut.size() - 1, 0);
+    } catch (const std::bad_alloc &) {
+        vdf_cache_free(out);
+        return VDF_E_OOM;
     }
-    cut.push_back(end);
     const size_t n_ranges = cut.size() - 1;
-    std::vector<RangeCounts> cnt(n_ranges);
+    // Threads may fail to start (a pids cgroup, RLIMIT_NPROC): what was started is joined, the ranges that got no thread run here -
+    // nothing may be thrown through the C ABI.
     auto for_ranges = [&](const std::function<void(size_t)> &f) {
         if (n_ranges == 1) { f(0); return; }
         std::vector<std::thread> th;
-        for (size_t k = 0; k < n_ranges; k++) th.emplace_back(f, k);
+        size_t started = 0;
+        try {
+            th.reserve(n_ranges);
+            for (; started < n_ranges; started++) th.emplace_back(f, started);
+        } catch (...) {
+        }
+        for (size_t k = started; k < n_ranges; k++) f(k);
         for (auto &t : th) t.join();
     };
-    std::vector<uint8_t> ok(n_ranges, 0);
     // pass 1: every range is parsed and counted; it must end exactly where the next one begins
     for_ranges([&](size_t k) {
         Reader rr{cut[k], end};
@@ -235,7 +276,14 @@ int vdf_cache_decode_mt(const uint8_t *data, size_t len, int n_threads, vdf_cach
     }
     if (!all_ok || total != n) return bad();  // malformed, trailing bytes, or fewer entries than the count says
     // pass 2: fill the arrays, every range from its own position
-    std::vector<uint64_t> ok_base(n_ranges + 1, 0), blob_base(n_ranges + 1, 0);
+    std::vector<uint64_t> ok_base, blob_base;
+    try {
+        ok_base.assign(n_ranges + 1, 0);
+        blob_base.assign(n_ranges + 1, 0);
+    } catch (const std::bad_alloc &) {
+        vdf_cache_free(out);
+        return VDF_E_OOM;
+    }
     for (size_t k = 0; k < n_ranges; k++) { ok_base[k + 1] = ok_base[k] + cnt[k].n_ok; blob_base[k + 1] = blob_base[k] + cnt[k].blob; }
     if (ok_base[n_ranges] > cap) return bad();
     for_ranges([&](size_t k) {

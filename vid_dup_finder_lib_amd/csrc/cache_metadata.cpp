@@ -31,12 +31,32 @@ void set_err(char *err, size_t cap, const std::string &msg)
     err[n] = 0;
 }
 
+// length of the Unicode White_Space character (what str::trim removes) that STARTS at s[i] / ENDS at s[i - 1], 0 if none:
+// U+0009..000D, U+0020, U+0085, U+00A0, U+1680, U+2000..200A, U+2028, U+2029, U+202F, U+205F, U+3000 in UTF-8
+size_t ws_at(const std::string &s, size_t i)
+{
+    const auto u = [&](size_t k) { return k < s.size() ? (unsigned char)s[k] : 0u; };
+    const unsigned c = u(i);
+    if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+    if (c == 0xC2 && (u(i + 1) == 0x85 || u(i + 1) == 0xA0)) return 2;
+    if (c == 0xE1 && u(i + 1) == 0x9A && u(i + 2) == 0x80) return 3;
+    if (c == 0xE2 && u(i + 1) == 0x80 && ((u(i + 2) >= 0x80 && u(i + 2) <= 0x8A) || u(i + 2) == 0xA8 || u(i + 2) == 0xA9 || u(i + 2) == 0xAF)) return 3;
+    if (c == 0xE2 && u(i + 1) == 0x81 && u(i + 2) == 0x9F) return 3;
+    if (c == 0xE3 && u(i + 1) == 0x80 && u(i + 2) == 0x80) return 3;
+    return 0;
+}
+
 std::string trim_lower(const std::string &s)
-{  // str::trim (ASCII white space is all that can matter for these keywords) + to_lowercase
+{  // str::trim + to_lowercase (the keywords are ASCII, so ASCII lower-casing decides every comparison the same way)
     size_t a = 0, b = s.size();
-    auto ws = [](unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); };
-    while (a < b && ws((unsigned char)s[a])) a++;
-    while (b > a && ws((unsigned char)s[b - 1])) b--;
+    for (size_t w; a < b && (w = ws_at(s, a)) != 0;) a += w;
+    for (;;) {
+        size_t w = 0;
+        for (size_t len = 1; len <= 3 && len <= b - a; len++)
+            if (ws_at(s, b - len) == len) { w = len; break; }
+        if (!w) break;
+        b -= w;
+    }
     std::string r = s.substr(a, b - a);
     for (char &c : r)
         if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
@@ -249,7 +269,19 @@ int vdf_cache_metadata_path(const char *cache_path, size_t len, char *buf, size_
     std::string stem = name;
     const size_t dot = name.rfind('.');
     if (dot != std::string::npos && dot != 0) stem = name.substr(0, dot);
-    const std::string res = std::string(cache_path, start) + stem + ".metadata.txt";
+    // the directory part as Path::parent() yields it (with_file_name pops to the parent, then pushes): trailing separators and "."
+    // pieces go, a lone root stays "/", a leading "." stays
+    size_t dend = start;
+    for (;;) {
+        while (dend > 1 && cache_path[dend - 1] == '/') dend--;
+        if (dend >= 3 && cache_path[dend - 1] == '.' && cache_path[dend - 2] == '/') { dend -= 1; continue; }
+        break;
+    }
+    std::string dir(cache_path, dend);
+    if (dir == "/" && start > 0) dir = "/";
+    else if (!dir.empty() && dir.back() == '/' && dir.size() > 1) dir.pop_back();
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    const std::string res = dir + stem + ".metadata.txt";
     *out_len = res.size();
     if (!buf || cap < res.size()) return VDF_E_OVERFLOW;
     std::memcpy(buf, res.data(), res.size());

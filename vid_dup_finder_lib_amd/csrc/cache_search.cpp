@@ -6,6 +6,7 @@
 // gathers; hashes go up once and are put into Search::sort order on the device.
 #include <chrono>
 #include <cstring>
+#include <new>
 
 #include "vdf_ctx.h"
 
@@ -22,12 +23,28 @@ struct Scratch {  // device buffers of one call, released on every exit path
 
 }  // namespace
 
+static int search_cache_entries_impl(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, const uint64_t *path_offsets,
+                                     const char *paths, size_t n, const uint64_t *cand_idx, size_t n_cand, const uint64_t *ref_idx,
+                                     size_t n_ref, uint32_t tol_int, vdf_groups *out, vdf_cache_search_timing *timing);
+
 extern "C" int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, const uint64_t *path_offsets,
                                         const char *paths, size_t n, const uint64_t *cand_idx, size_t n_cand, const uint64_t *ref_idx,
                                         size_t n_ref, uint32_t tol_int, vdf_groups *out, vdf_cache_search_timing *timing)
 {
     if (!ctx || !out) return VDF_E_INVAL;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    try {
+        return search_cache_entries_impl(ctx, hashes, durations, path_offsets, paths, n, cand_idx, n_cand, ref_idx, n_ref, tol_int, out, timing);
+    } catch (const std::bad_alloc &) {  // the host staging vectors: nothing may be thrown through the C ABI
+        vdf_groups_free(out);
+        return fail(ctx, VDF_E_OOM, "host staging");
+    }
+}
+
+static int search_cache_entries_impl(vdf_ctx *ctx, const uint64_t *hashes, const uint32_t *durations, const uint64_t *path_offsets,
+                                     const char *paths, size_t n, const uint64_t *cand_idx, size_t n_cand, const uint64_t *ref_idx,
+                                     size_t n_ref, uint32_t tol_int, vdf_groups *out, vdf_cache_search_timing *timing)
+{
     std::memset(out, 0, sizeof *out);
     if (timing) std::memset(timing, 0, sizeof *timing);
     ctx->stats = vdf_search_stats{};
@@ -36,18 +53,37 @@ extern "C" int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, co
     const bool refs = n_ref != 0;
     if (nc == 0 || n == 0) return refs ? vdf_groups_from_ref_hits(nullptr, 0, out) : vdf_groups_finish_self(out);
     if (!hashes || !durations || !path_offsets || !paths || (refs && !ref_idx)) return fail(ctx, VDF_E_INVAL, "null pointer");
-    if (n >= 0xFFFFFFFFull || n_ref >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
+    if (n >= 0xFFFFFFFFull || n_ref >= 0xFFFFFFFFull || nc >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 hashes");
     if (cand_idx)
         for (size_t i = 0; i < nc; i++)
             if (cand_idx[i] >= n) return fail(ctx, VDF_E_INVAL, "candidate index out of range");
     for (size_t i = 0; i < n_ref; i++)
         if (ref_idx[i] >= n) return fail(ctx, VDF_E_INVAL, "reference index out of range");
 
-    // ---- PathBuf order of the candidates' paths: ranks over all n entries order any subset of them too
-    std::vector<uint32_t> rank(n);
+    // Host staging first, device scratch second, the stream drain last: whatever path leaves this function, the streams are drained
+    // BEFORE the buffers an asynchronous copy may still be reading or writing go away (destruction runs in reverse order).
+    std::vector<uint32_t> rank, sel32, sel_dur, sel_rank, perm, ref_d;
+    std::vector<uint64_t> ref_h;
+    Scratch sc;
+    struct Drain {
+        vdf_ctx *ctx;
+        ~Drain()
+        {
+            for (int k = 0; k < device_count(ctx); k++) {
+                vdf_ctx *d = device_ctx(ctx, k);
+                if (hipSetDevice(d->device) == hipSuccess) (void)hipStreamSynchronize(d->stream);
+            }
+            (void)hipGetLastError();
+        }
+    };
+    DeviceGuard restore_device;  // (destroyed after `drain`, which moves the calling thread over the devices)
+    Drain drain{ctx};
+
+    // ---- PathBuf order of the candidates' paths: ranks over all n entries order any subset of them too (the cost is that of all n
+    // whatever the selection: a caller with a small selection of a huge cache may pass a compacted blob instead)
+    rank.resize(n);
     int rc = vdf_path_ranks(paths, path_offsets, n, rank.data(), 0);
     if (rc) return fail(ctx, rc, "path offsets are not ascending");
-    std::vector<uint32_t> sel32, sel_dur, sel_rank;
     if (cand_idx) {
         sel32.resize(nc); sel_dur.resize(nc); sel_rank.resize(nc);
         for (size_t i = 0; i < nc; i++) {
@@ -60,10 +96,8 @@ extern "C" int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, co
     // ---- upload to the first device; Search::sort there
     const int G = device_count(ctx);
     vdf_ctx *d0 = device_ctx(ctx, 0);
-    DeviceGuard restore_device;
     VDF_HIP(ctx, hipSetDevice(d0->device));
     hipStream_t s = d0->stream;
-    Scratch sc;
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         int r = upload(d0, b, src, bytes, s);
         if (r && d0 != ctx) ctx->err = d0->err;
@@ -90,7 +124,7 @@ extern "C" int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, co
     VDF_HIP(ctx, d0->up_dur.reserve(std::max<size_t>(nc * 4, 16)));
     VDF_HIP(ctx, vdf::launch_gather_hashes(d_src_h, sc.sel_d.as<uint32_t>(), sc.perm.as<uint32_t>(), (uint32_t)nc, d0->up_hashes.as<uint64_t>(),
                                            d0->up_dur.as<uint32_t>(), s));
-    std::vector<uint32_t> perm(nc);
+    perm.resize(nc);
     VDF_HIP(ctx, hipMemcpyAsync(perm.data(), sc.perm.p, nc * 4, hipMemcpyDeviceToHost, s));
     // the other devices of a multi-GPU context receive the sorted database from the first (device-to-device, on its stream)
     for (int k = 1; k < G; k++) {
@@ -104,8 +138,6 @@ extern "C" int vdf_search_cache_entries(vdf_ctx *ctx, const uint64_t *hashes, co
     }
     // references: gathered on the host in ref_idx order, split contiguously over the devices (as vdf_search_refs does)
     std::vector<size_t> cnt((size_t)G, 0), base((size_t)G, 0);
-    std::vector<uint64_t> ref_h;
-    std::vector<uint32_t> ref_d;
     if (refs) {
         ref_h.resize(n_ref * VDF_HASH_WORDS);
         ref_d.resize(n_ref);

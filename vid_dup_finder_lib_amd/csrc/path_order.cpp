@@ -17,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -90,11 +91,135 @@ int path_cmp(const char *a, size_t la, const char *b, size_t lb)
     }
 }
 
+// A PLAIN path is one whose bytes spell its components and nothing else: no empty component ("//", a trailing '/' - the root "/"
+// itself excepted), no "." or ".." component, no NUL byte.  That is what a directory walk produces, i.e. every path of a real cache.
+// For two plain paths Path::cmp is the byte order in which '/' sorts below every other byte (a component that ends is smaller than
+// one that goes on; RootDir - a leading '/' - is smaller than any Normal component; a path that ends is smaller than one that goes
+// on): one pass to the first differing byte decides, no component iteration, no backing up.
+bool is_plain(const char *s, size_t n)
+{
+    if (n == 0 || (n == 1 && s[0] == '/')) return true;
+    if (s[n - 1] == '/') return false;
+    size_t len = 0, dots = 0;  // of the component being read
+    bool bad = false;
+    for (size_t i = s[0] == '/' ? 1 : 0; i < n; i++) {
+        const char c = s[i];
+        if (c == '/') {
+            bad = bad || len == 0 || (dots == len && len <= 2);
+            len = dots = 0;
+        } else {
+            bad = bad || c == 0;
+            len++;
+            dots += c == '.';
+        }
+    }
+    return !(bad || (dots == len && len <= 2));  // (the last component is not empty: the path does not end in '/')
+}
+
+// both plain; the first `skip` bytes are known to be equal
+inline int plain_cmp(const char *a, size_t la, const char *b, size_t lb, size_t skip)
+{
+    size_t m = skip;
+    const size_t lmin = std::min(la, lb);
+    while (m + 8 <= lmin) {
+        uint64_t x, y;
+        std::memcpy(&x, a + m, 8);
+        std::memcpy(&y, b + m, 8);
+        if (x != y) { m += (size_t)(__builtin_ctzll(x ^ y) >> 3); break; }
+        m += 8;
+    }
+    while (m < lmin && a[m] == b[m]) m++;
+    if (m >= lmin) return la < lb ? -1 : la > lb ? 1 : 0;
+    const unsigned x = (unsigned char)a[m] == '/' ? 0u : (unsigned char)a[m], y = (unsigned char)b[m] == '/' ? 0u : (unsigned char)b[m];
+    return x < y ? -1 : 1;
+}
+
+inline size_t common_prefix(const char *a, size_t la, const char *b, size_t lb)
+{
+    size_t m = 0;
+    const size_t lmin = std::min(la, lb);
+    while (m < lmin && a[m] == b[m]) m++;
+    return m;
+}
+
 struct Blob {
     const char *paths;
     const uint64_t *off;
-    int cmp(uint32_t i, uint32_t j) const { return path_cmp(paths + off[i], (size_t)(off[i + 1] - off[i]), paths + off[j], (size_t)(off[j + 1] - off[j])); }
+    bool plain = false;  // every path of the blob is plain: plain_cmp decides
+    size_t shared = 0;   // plain: leading bytes all paths of the blob have in common
+    int cmp(uint32_t i, uint32_t j, size_t skip = 0) const
+    {
+        const char *a = paths + off[i], *b = paths + off[j];
+        const size_t la = (size_t)(off[i + 1] - off[i]), lb = (size_t)(off[j + 1] - off[j]);
+        return plain ? plain_cmp(a, la, b, lb, std::max(skip, shared)) : path_cmp(a, la, b, lb);
+    }
+    // PLAIN paths: the 8 bytes from `skip` on as one big-endian word in the order's alphabet ('/' -> 0; beyond the end -> 0).  Monotone:
+    // key8(i) < key8(j) implies path i < path j; equal words decide nothing (a path that ends and one that goes on with '/' tie).
+    uint64_t key8(uint32_t i, size_t skip) const
+    {
+        const unsigned char *a = reinterpret_cast<const unsigned char *>(paths + off[i]);
+        const size_t la = (size_t)(off[i + 1] - off[i]);
+        uint64_t k = 0;
+        for (size_t q = 0; q < 8; q++) {
+            const unsigned c = skip + q < la ? a[skip + q] : 0u;
+            k = (k << 8) | (c == '/' ? 0u : c);
+        }
+        return k;
+    }
+    size_t lcp(uint32_t i, uint32_t j) const  // bytes two PLAIN paths share (everything ordered between them shares them too)
+    {
+        return common_prefix(paths + off[i], (size_t)(off[i + 1] - off[i]), paths + off[j], (size_t)(off[j + 1] - off[j]));
+    }
 };
+
+// Sorting a group of PLAIN paths that share their first `depth` bytes without comparing paths: find what the whole group shares
+// (one pass), let the next 8 bytes ride along with each index as one integer (Blob::key8), sort the integers, and descend into the
+// runs of equal words 8 bytes further on.  Directory-walk paths differ late ("/lib/show_0412/season_03/clip_000012" + 2 digits), so a
+// comparison sort spends its time re-reading what all its operands share; here every byte of a path is looked at about once.
+struct KeyIdx { uint64_t key; uint32_t idx; };
+
+void keyed_sort(const Blob &B, KeyIdx *v, size_t n, size_t depth)
+{
+    auto by_path = [&](const KeyIdx &x, const KeyIdx &y) { const int c = B.cmp(x.idx, y.idx, depth); return c ? c < 0 : x.idx < y.idx; };
+    while (n > 1) {
+        if (n <= 8) { std::sort(v, v + n, by_path); return; }
+        // what the group shares beyond `depth`, measured against its first member
+        const char *p0 = B.paths + B.off[v[0].idx];
+        const size_t l0 = (size_t)(B.off[v[0].idx + 1] - B.off[v[0].idx]);
+        size_t g = l0;
+        for (size_t i = 1; i < n && g > depth; i++) {
+            const char *q = B.paths + B.off[v[i].idx];
+            const size_t lq = std::min<size_t>((size_t)(B.off[v[i].idx + 1] - B.off[v[i].idx]), g);
+            size_t m = depth;
+            while (m < lq && p0[m] == q[m]) m++;
+            g = m;
+        }
+        depth = std::max(depth, std::min(g, l0));
+        bool ends = false;  // a member that ends inside the window: its word ties with one that goes on with '/', the comparator decides
+        for (size_t i = 0; i < n; i++) {
+            v[i].key = B.key8(v[i].idx, depth);
+            ends = ends || (size_t)(B.off[v[i].idx + 1] - B.off[v[i].idx]) < depth + 8;
+        }
+        if (ends) {
+            std::sort(v, v + n, [&](const KeyIdx &x, const KeyIdx &y) { return x.key != y.key ? x.key < y.key : by_path(x, y); });
+            return;
+        }
+        std::sort(v, v + n, [](const KeyIdx &x, const KeyIdx &y) { return x.key < y.key; });
+        // runs of equal words share depth + 8 bytes: all but the last are sorted by recursion, the last by this loop
+        size_t last_b = 0, last_n = 0;
+        for (size_t b = 0; b < n;) {
+            size_t e = b + 1;
+            while (e < n && v[e].key == v[b].key) e++;
+            if (e - b > 1) {
+                if (last_n > 1) keyed_sort(B, v + last_b, last_n, depth + 8);
+                last_b = b; last_n = e - b;
+            }
+            b = e;
+        }
+        if (last_n <= 1) return;
+        v += last_b; n = last_n; depth += 8;
+    }
+}
 
 // Worker threads that live for one vdf_path_ranks call and run its phases one after the other (threads started per phase spend
 // the short phases being placed by the scheduler: 8 threads gave the partition pass no speed-up at all on the build container).
@@ -126,7 +251,10 @@ class Pool {
 public:
     explicit Pool(unsigned n_threads)
     {
-        for (unsigned t = 1; t < n_threads; t++) th_.emplace_back([this] { work(); });  // the caller is worker 0
+        try {
+            for (unsigned t = 1; t < n_threads; t++) th_.emplace_back([this] { work(); });  // the caller is worker 0
+        } catch (...) {  // a pids cgroup / RLIMIT_NPROC: the threads that did start (possibly none) and the caller do the work
+        }
     }
     ~Pool()
     {
@@ -160,7 +288,20 @@ int vdf_path_compare(const char *a, size_t len_a, const char *b, size_t len_b)
     return path_cmp(a ? a : "", a ? len_a : 0, b ? b : "", b ? len_b : 0);
 }
 
+static int path_ranks_impl(const char *paths, const uint64_t *path_offsets, size_t n, uint32_t *out_rank, int n_threads);
+
 int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, uint32_t *out_rank, int n_threads)
+{
+    try {
+        return path_ranks_impl(paths, path_offsets, n, out_rank, n_threads);
+    } catch (const std::bad_alloc &) {  // nothing may be thrown through the C ABI
+        return VDF_E_OOM;
+    } catch (...) {
+        return VDF_E_INVAL;
+    }
+}
+
+static int path_ranks_impl(const char *paths, const uint64_t *path_offsets, size_t n, uint32_t *out_rank, int n_threads)
 {
     if (n == 0) return VDF_OK;
     if (!paths || !path_offsets || !out_rank || n >= 0xFFFFFFFFull) return VDF_E_INVAL;
@@ -169,9 +310,32 @@ int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, ui
     unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 256u));
     if (n < 4096) nt = 1;
-    const Blob B{paths, path_offsets};
+    Blob B{paths, path_offsets};
     Pool pool(nt);
     std::vector<uint32_t> idx(n);
+    {   // are all paths plain (path_order.cpp: is_plain)?  One linear pass; a single exception sends the whole call down the general road
+        // (the same pass finds how many leading bytes ALL paths share - "/mnt/videos/" - which no comparison needs to look at again)
+        const size_t n_sl = (size_t)nt * 4;
+        std::atomic<bool> all_plain{true};
+        std::vector<size_t> sl_lcp(n_sl, SIZE_MAX);
+        const char *p0 = paths + path_offsets[0];
+        const size_t l0 = (size_t)(path_offsets[1] - path_offsets[0]);
+        pool.run(n_sl, [&](size_t sl) {
+            const size_t lo = sl * n / n_sl, hi = (sl + 1) * n / n_sl;
+            size_t g = l0;
+            for (size_t i = lo; i < hi && all_plain.load(std::memory_order_relaxed); i++) {
+                const char *q = paths + path_offsets[i];
+                const size_t lq = (size_t)(path_offsets[i + 1] - path_offsets[i]);
+                if (!is_plain(q, lq)) all_plain = false;
+                if (g) g = common_prefix(p0, std::min(g, l0), q, lq);
+            }
+            sl_lcp[sl] = g;
+        });
+        B.plain = all_plain.load();
+        if (B.plain) B.shared = *std::min_element(sl_lcp.begin(), sl_lcp.end());
+    }
+    std::vector<uint8_t> is_new(n);     // position k of the sorted order starts a new (distinct) path
+    std::vector<uint8_t> new_known(n, 0);  // ... already decided while its bucket was sorted
     // ---- sample sort: splitters -> bucket of every entry -> counting scatter -> per-bucket sort
     // (also on one thread: a bucket's paths fit the cache, a std::sort over the whole blob misses on every comparison - 2 M paths 6.5 s against 2.4)
     const size_t n_buckets = n < 4096 ? 1 : std::min<size_t>(std::max<size_t>(n / 2048, 2), 8192);
@@ -188,14 +352,48 @@ int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, ui
         for (size_t k = 1; k < n_buckets; k++) split[k - 1] = samples[k * n_samples / n_buckets];
         // bucket(i) = number of splitters <= path i in (path, index) order: equal paths may straddle a splitter only by index,
         // and the per-bucket sort uses the same (path, index) order, so the concatenation is sorted
+        // plain paths: what the smallest and the largest SAMPLE share is not shared by everything (entries outside the samples' range), so
+        // the partition compares from byte 0; inside bucket k everything lies between two splitters and shares what they share
+        std::vector<uint32_t> bucket_skip(n_buckets, 0);
+        if (B.plain)
+            for (size_t k = 1; k + 1 < n_buckets; k++) bucket_skip[k] = (uint32_t)B.lcp(split[k - 1], split[k]);
+        // plain paths: the splitters' key words (ascending, like the splitters) narrow the binary search with integer comparisons
+        // before the first path comparison: only splitters whose word equals the entry's remain to be compared byte by byte
+        std::vector<uint64_t> split_key(B.plain ? split.size() : 0);
+        for (size_t k = 0; k < split_key.size(); k++) split_key[k] = B.key8(split[k], B.shared);
         std::vector<uint16_t> bucket(n);
         const size_t n_slices = (size_t)nt * 4;
         std::vector<std::vector<uint32_t>> counts(n_slices, std::vector<uint32_t>(n_buckets, 0));
+        // and the splitters' bytes (beyond what everything shares) sit back to back in one small array: the binary search of an entry then
+        // walks ~0.4 MB of cache-resident bytes instead of 8 k offsets and 8 k paths scattered over the whole blob
+        std::vector<char> split_bytes;
+        std::vector<uint32_t> split_at(B.plain ? split.size() + 1 : 0, 0);
+        if (B.plain) {
+            for (size_t k = 0; k < split.size(); k++) {
+                const size_t len = (size_t)(path_offsets[split[k] + 1] - path_offsets[split[k]]);
+                split_at[k + 1] = split_at[k] + (uint32_t)(len - B.shared);
+            }
+            split_bytes.resize(split_at.back() + 8);
+            for (size_t k = 0; k < split.size(); k++)
+                std::memcpy(split_bytes.data() + split_at[k], paths + path_offsets[split[k]] + B.shared, split_at[k + 1] - split_at[k]);
+        }
         pool.run(n_slices, [&](size_t sl) {
             const size_t lo = sl * n / n_slices, hi = (sl + 1) * n / n_slices;
             std::vector<uint32_t> &cnt = counts[sl];
             for (size_t i = lo; i < hi; i++) {
                 size_t a = 0, b = split.size();  // first splitter that is greater than entry i
+                if (B.plain) {
+                    const uint64_t ki = B.key8((uint32_t)i, B.shared);
+                    a = (size_t)(std::lower_bound(split_key.begin(), split_key.end(), ki) - split_key.begin());
+                    b = (size_t)(std::upper_bound(split_key.begin() + (ptrdiff_t)a, split_key.end(), ki) - split_key.begin());
+                    const char *q = paths + path_offsets[i] + B.shared;
+                    const size_t lq = (size_t)(path_offsets[i + 1] - path_offsets[i]) - B.shared;
+                    while (a < b) {
+                        const size_t m = (a + b) / 2;
+                        const int c = plain_cmp(split_bytes.data() + split_at[m], split_at[m + 1] - split_at[m], q, lq, 0);
+                        if (c < 0 || (c == 0 && split[m] <= (uint32_t)i)) a = m + 1; else b = m;
+                    }
+                }
                 while (a < b) {
                     const size_t m = (a + b) / 2;
                     const int c = B.cmp(split[m], (uint32_t)i);
@@ -221,19 +419,30 @@ int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, ui
             for (size_t i = lo; i < hi; i++) idx[at[bucket[i]]++] = (uint32_t)i;
         });
         pool.run(n_buckets, [&](size_t k) {
-            std::sort(idx.begin() + (ptrdiff_t)bucket_begin[k], idx.begin() + (ptrdiff_t)bucket_begin[k + 1],
-                      [&](uint32_t x, uint32_t y) { const int c = B.cmp(x, y); return c ? c < 0 : x < y; });
+            const size_t skip = std::max<size_t>(bucket_skip[k], B.shared);
+            const size_t b0 = bucket_begin[k], b1 = bucket_begin[k + 1];
+            if (!B.plain) {
+                std::sort(idx.begin() + (ptrdiff_t)b0, idx.begin() + (ptrdiff_t)b1,
+                          [&](uint32_t x, uint32_t y) { const int c = B.cmp(x, y); return c ? c < 0 : x < y; });
+                return;
+            }
+            // plain: every path of the bucket shares `skip` bytes (keyed_sort takes it from there)
+            std::vector<KeyIdx> tmp(b1 - b0);
+            for (size_t q = b0; q < b1; q++) tmp[q - b0] = KeyIdx{0, idx[q]};
+            keyed_sort(B, tmp.data(), tmp.size(), skip);
+            for (size_t q = b0; q < b1; q++) idx[q] = tmp[q - b0].idx;
+            // "does a new path start here" for all but the bucket's first position, while the bucket's paths are still in the cache
+            for (size_t q = b0 + 1; q < b1; q++) { is_new[q] = B.cmp(idx[q - 1], idx[q], skip) != 0; new_known[q] = 1; }
         });
     }
     // ---- dense ranks: equal paths share one
     const size_t n_slices = nt == 1 ? 1 : (size_t)nt * 4;
     std::vector<uint32_t> first(n_slices + 1, 0);  // distinct-run starts inside each slice (position 0 of the array counts as one)
-    std::vector<uint8_t> is_new(n);
     pool.run(n_slices, [&](size_t sl) {
         const size_t lo = sl * n / n_slices, hi = (sl + 1) * n / n_slices;
         uint32_t c = 0;
         for (size_t k = lo; k < hi; k++) {
-            const bool nw = k == 0 || B.cmp(idx[k - 1], idx[k]) != 0;
+            const bool nw = new_known[k] ? is_new[k] != 0 : (k == 0 || B.cmp(idx[k - 1], idx[k]) != 0);
             is_new[k] = nw;
             c += nw;
         }
