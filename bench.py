@@ -24,8 +24,13 @@ Named legs in the same line (sizes are flags, so tests run them small):
   c5_end_to_end    BASELINE configs[4]: 1 M candidate + 100 k reference clips of 16 x 64 x 64 hashed per rank, hashes
                    all-gathered, Search::sort on the device, search_with_references, groups - with a phase breakdown
   dup_heavy        a duplicate-DENSE database (10 % of 1 M hashes in clusters of 2-200): what hits, suspect queue,
-                   download and replay cost when the finder finds a lot (N = 1)
+                   download and replay cost when the finder finds a lot (N = 1; also sharded over two slots of one GPU)
+  cache_ingest     SURVEY 8f N1 at the scale it exists for: a synthetic 10 M-entry app cache (bincode bytes) -> vdf_cache_decode_mt ->
+                   vdf_search_cache_entries (PathBuf ranks, upload, Search::sort on the device, search, map), phase by phase (N = 1)
   windowed, valu_backend, refs_c5_shape, hash.* (N = 1), cpu_baseline (the oracle on host cores; N = 1)
+The line is kept short (what each leg runs is written down in DESIGN.md section 6, not repeated in every line) and ENDS with
+"hash_summary": BASELINE's metric is "pairs/s + frames/s", and whoever keeps only the tail of the line still reads the second half.
+Side legs report the median and the minimum over their steps.
 """
 import argparse
 import json
@@ -174,20 +179,48 @@ def cpu_baseline_hash(clips_per_thread=96):
                       f"(single thread: {n1} clips)"}
 
 
-def read_traffic(name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+LIB_PATH = os.path.join(ROOT, "vid_dup_finder_lib_amd", "libvdf_hip.so")
+TRAFFIC_PATH = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+_lib_sha = {}
+
+
+def lib_sha256(path=None):
+    """sha256 of the library file this process loads (what ties a committed rocprofv3 figure to the binary being timed)."""
+    import hashlib
+
+    path = path or LIB_PATH
+    if path not in _lib_sha:
+        try:
+            with open(path, "rb") as f:
+                _lib_sha[path] = hashlib.sha256(f.read()).hexdigest()
+        except OSError:
+            _lib_sha[path] = None
+    return _lib_sha[path]
+
+
+def read_traffic(name, scale=1.0):
+    """(HBM bytes per launch, source): the committed rocprofv3 --pmc figure of kernel `name` (profiles/pmc_traffic.json, written by
+    tools/summarize_profiles.py from a tools/profile_round.sh run) - but only if that profile was taken with THE library being timed:
+    the file records the sha256 of the libvdf_hip.so it profiled, and a figure of another binary is reported as null with the reason."""
     try:
-        with open(p) as f:
-            return json.load(f).get(name, {}).get("hbm_bytes_per_launch")
+        with open(TRAFFIC_PATH) as f:
+            t = json.load(f)
     except Exception:
-        return None
+        return None, "profiles/pmc_traffic.json missing"
+    sha = lib_sha256()
+    if not t.get("lib_sha256") or t.get("lib_sha256") != sha:
+        return None, "profiles/pmc_traffic.json was measured on another libvdf_hip.so (sha256 %s, loaded %s): run tools/profile_round.sh" % (
+            str(t.get("lib_sha256"))[:12], str(sha)[:12])
+    v = t.get(name, {}).get("hbm_bytes_per_launch")
+    if v is None:
+        return None, f"no entry for {name} in profiles/pmc_traffic.json"
+    return v * scale, "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this library, sha256 %s)" % sha[:12]
 
 
-def scaled_traffic(name, clips, profiled_clips):
-    """Committed PMC bytes of a hash kernel, measured at profiled_clips clips per launch, for a launch of `clips` clips."""
-    t = read_traffic(name)
-    return None if t is None else t * clips / profiled_clips
+def med_min(xs):
+    """(median, min) of a leg's per-step figures."""
+    a = np.asarray(list(xs), dtype=np.float64)
+    return float(np.median(a)), float(a.min())
 
 
 def executed_pairs(st):
@@ -200,56 +233,79 @@ def executed_pairs(st):
 def search_roofline(backend, kernel_ms):
     """roofline (+ companions) of the dominant search kernel from the library's per-step statistics:
     kernel_ms = [(kernel_ms, n_launches, pairs, pairs_computed, n_hits, pairs_early_exit, early_exit_bits)] per step,
-    of ONE device (HIP-event time recorded by the library on the kernel's own stream)."""
+    of ONE device (HIP-event time recorded by the library on the kernel's own stream).  What the figures mean: DESIGN.md section 6."""
     k_ms = float(np.mean([k[0] / max(k[1], 1) for k in kernel_ms]))
     k_pairs = float(np.mean([k[2] for k in kernel_ms]))  # pairs admitted on THIS rank per launch
     k_comp = float(np.mean([k[3] for k in kernel_ms]))   # pairs the tiles evaluated (>= admitted)
+    k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
+    ee_bits = int(kernel_ms[-1][6])
+    executed_p = k_comp - k_early * ((1.0 - ee_bits / 1024.0) if ee_bits else 0.0)
     stream_gbs = k_pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9
-    hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "x_of_hbm_model": stream_gbs / HBM_PEAK_GBS,
-                 "note": "BASELINE.md section 4 / SURVEY 8d operand-stream MODEL of the reference loop: 128 B per pair "
-                         "against 8 TB/s (north_star target x >= 0.5).  Not a physical bandwidth: tiles keep targets in "
-                         "registers and share candidates through LDS/SGPRs, so real HBM traffic is a few 1e-2..1e-1 B per "
-                         "pair (see roofline.traffic); x_of_hbm_model is how many times the model's roofline the kernel runs at"}
+    # SURVEY 8d operand-stream MODEL of the reference loop (128 B per pair against 8 TB/s; north_star target x >= 0.5): not a bandwidth
+    hbm_model = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "x_of_hbm_model": stream_gbs / HBM_PEAK_GBS}
     if backend == "valu":
         kname = "hamming_tile_kernel"
-        roofline = {"bound": "hbm", "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": stream_gbs / HBM_PEAK_GBS, "note": hbm_model["note"], "kernel": kname,
-                    "traffic": read_traffic(kname),
-                    "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc run; not measured in this run)",
+        traffic, src = read_traffic(kname)
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": stream_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": stream_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                     "kernel_ms": k_ms, "pairs_per_launch": k_pairs}
-        k_early = float(np.mean([k[5] for k in kernel_ms]))
-        ee_bits = int(kernel_ms[-1][6])
-        lane_ops = (k_comp - k_early * ((1.0 - ee_bits / 1024.0) if ee_bits else 0.0)) * LANEOPS_PER_PAIR
-        valu = {"achieved": lane_ops / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
+        valu = {"achieved": executed_p * LANEOPS_PER_PAIR / (k_ms * 1e-3), "peak": VALU_PEAK_LANEOPS, "unit": "lane-ops/s"}
         valu["frac"] = valu["achieved"] / valu["peak"]
         extra = {"valu": valu}
         dtype = "u32 (xor + popcount over 32 dwords per hash)"
     else:
         kname = "hamming_mfma2_kernel"
         alg_tflops = k_comp * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-        k_early = float(np.mean([k[5] for k in kernel_ms]))  # pair comparisons that took the exact early exit
-        ee_bits = int(kernel_ms[-1][6])
-        executed = (k_comp - k_early * (1.0 - ee_bits / 1024.0 if ee_bits else 0.0)) * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
-        # frac prices the MFMA work the kernel EXECUTED (blocks that take the exact early exit stop after ee_bits of the
-        # 1024 bit positions); the algorithmic 2048 FLOP per pair are reported beside it, never as the headline fraction
+        executed = executed_p * FLOP_PER_PAIR / (k_ms * 1e-3) / 1e12
+        traffic, src = read_traffic(kname)
+        # frac prices the MFMA work the kernel EXECUTED (blocks that take the exact early exit stop after ee_bits of the 1024 bit
+        # positions); the algorithmic 2048 FLOP per pair are reported beside it, never as the headline fraction
         roofline = {"bound": "mfma", "kernel": kname, "achieved": executed, "peak": MFMA_FP4_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": executed / MFMA_FP4_PEAK_TFLOPS,
                     "algorithmic_achieved": alg_tflops, "algorithmic_frac": alg_tflops / MFMA_FP4_PEAK_TFLOPS,
-                    "traffic": read_traffic(kname),
-                    "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the committed "
-                                      "profile run of this workload; not measured in this run)",
-                    "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
-                    "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0),
-                                   "note": "a 32 x 32 block whose partial distances over the first after_bits bits all "
-                                           "exceed the tolerance cannot contain a hit and stops there (exact)"},
-                    "note": ("exact {0,1} fp4 Gram matrix (v_mfma_f32_32x32x64_f8f6f4): hamming = pop(a) + pop(b) - 2 dot; suspects of "
-                             "blocks that cannot be ruled out are evaluated exactly by resolve_candidates_kernel (inside kernel_ms); ") +
-                            "achieved/frac = FLOP of the MFMAs actually executed; algorithmic_* = 2048 FLOP per admitted-tile "
-                            "pair; integer results, bit-identical to XOR + popcount"}
+                    "traffic": traffic, "traffic_source": src, "kernel_ms": k_ms, "pairs_per_launch": k_pairs,
+                    "early_exit": {"after_bits": ee_bits, "pairs_fraction": k_early / max(k_comp, 1.0)}}
         extra = {"hbm_operand_stream_model": hbm_model}
         dtype = "fp4 e2m1 ({0,1}) x fp4 -> f32 accumulate (exact half-integers < 2^11)"
     return roofline, extra, dtype
+
+
+METRIC = "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash_summary']"
+
+
+def headline(value, steps, warmup, ms_per_step, n_gpus, dtype, n_hashes, shard, pairs, tol_int, parallelism, roofline):
+    """The keys of the driver's contract, in its order."""
+    return {"metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, durations 0, all-pairs search() at tolerance 350, "
+                                   "near-duplicates planted every 1000th hash",
+                       "n_hashes": n_hashes, "hashes_per_gpu_shard": shard, "pairs": pairs, "tolerance_int": tol_int,
+                       "parallelism": parallelism},
+            "roofline": roofline}
+
+
+def hash_summary(hash_leg):
+    """BASELINE's second half (frames/sec DCT-hash, configs[2]) in a form short enough to survive at the END of the line."""
+    r = hash_leg["roofline"]
+    out = {"metric": "frames/sec DCT-hash, BASELINE configs[2]: clips of 16 x 64 x 64 u8 -> VideoHash", "value": hash_leg["value"],
+           "unit": "frames/s", "clips_per_gpu": hash_leg["clips_per_gpu"], "n_gpus": hash_leg["n_gpus"],
+           "ms_per_step": hash_leg["ms_per_step"], "dtype": "u8 -> i8 MFMA fixed point (exact) -> f64 DCT",
+           "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
+    cb = hash_leg.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    return out
+
+
+def finish_line(out):
+    """Order of the one JSON line: the contract's keys first, the legs, and hash_summary LAST (a reader of the line's tail gets it)."""
+    if "hash" in out and "roofline" in out["hash"]:
+        out["hash_summary"] = hash_summary(out["hash"])
+    hs = out.pop("hash_summary", None)
+    if hs is not None:
+        out["hash_summary"] = hs
+    return json.dumps(out)
 
 
 def free_port():
@@ -313,12 +369,27 @@ def single_process_leg(args, timeout_s=600):
         return {"rccl": "error: rc %d: %s" % (proc.returncode, " | ".join(tail)[-600:]), "wall_s": time.perf_counter() - t0}
     d = json.loads(lines[-1])
     out = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "per_device_kernel_ms", "per_device_pairs", "match_groups",
-                                 "devices", "replication")}
+                                 "devices", "replication", "rccl_ranks_seen")}
     out["rccl"] = "ok"
     out["roofline_frac"] = d.get("roofline", {}).get("frac")
     out["c4_10m_sharded"] = d.get("c4_10m_sharded")
     out["form"] = d["config"]["parallelism"]
     out["wall_s"] = time.perf_counter() - t0
+    return out
+
+
+C4_N1_REFERENCE_MS = 10375.4  # ten_million at one GPU, driver run of round 4 (BENCH_r04.json): what N ranks are compared with
+
+
+def c4_summary(n10, n_gpus, ms):
+    """BASELINE configs[3] (all-pairs search() over 10 M hashes sharded over the GPUs; strong scaling): the figures to read first on an
+    8-GPU run.  speedup_vs_n1_model = (one GPU's measured time / N) / this run's time: 1.0 = perfect strong scaling."""
+    p10 = n10 * (n10 - 1) // 2
+    out = {"workload": "BASELINE configs[3]", "n_hashes": n10, "pairs": p10, "scaling": "strong", "n_gpus": n_gpus, "steps": 1,
+           "ms_per_step": ms, "pairs_per_s": p10 / (ms * 1e-3), "hbm_operand_stream_x": p10 / (ms * 1e-3) * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
+    if n10 == 10_000_000:
+        out["n1_reference_ms"] = C4_N1_REFERENCE_MS
+        out["speedup_vs_n1_model"] = C4_N1_REFERENCE_MS / n_gpus / ms
     return out
 
 
@@ -405,22 +476,15 @@ def run_single_process(args):
                   q["early_exit_bits"]) for q in slow]
     roofline, extra, dtype = search_roofline(backend, kernel_ms)
     distinct = len(set(devices)) == len(devices)
-    out = {
-        "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
-        "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": G, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, all durations 0, all-pairs "
-                               "search_self at tolerance 350, planted near-duplicates every 1000th hash",
-                   "n_hashes": n_total, "hashes_per_gpu_shard": sizes[0], "pairs": pairs, "tolerance_int": tol_int,
-                   "parallelism": f"ONE process, vdf_ctx_create_multi over devices {devices}: shards resident per GPU, "
-                                  "RCCL all-gather inside the library, row tiles round-robin, one host replay"},
-        "roofline": roofline, "match_groups": n_groups, "search_backend": backend, "devices": devices,
-        "replication": ("ncclAllGather over xGMI (librccl loaded by the library)" if distinct and G > 1
-                        else "device-to-device copies (repeated or single device: RCCL takes one rank per device)"),
-        "per_device_kernel_ms": [float(np.mean([st[k]["kernel_ms"] for st in per_dev])) for k in range(G)],
-        "per_device_pairs": [int(per_dev[-1][k]["pairs"]) for k in range(G)],
-    }
+    out = headline(pairs * args.steps / dt, args.steps, args.warmup, dt / args.steps * 1e3, G, dtype, n_total, sizes[0], pairs, tol_int,
+                   f"ONE process, vdf_ctx_create_multi over devices {devices}: shards resident per GPU, RCCL all-gather inside the "
+                   "library, row tiles round-robin, one host replay", roofline)
+    out.update({"match_groups": n_groups, "search_backend": backend, "devices": devices,
+                "replication": ("ncclAllGather over xGMI (librccl loaded by the library)" if distinct and G > 1
+                                else "device-to-device copies (repeated or single device: RCCL takes one rank per device)"),
+                "rccl_ranks_seen": eng.rccl_ranks(),
+                "per_device_kernel_ms": [float(np.mean([st[k]["kernel_ms"] for st in per_dev])) for k in range(G)],
+                "per_device_pairs": [int(per_dev[-1][k]["pairs"]) for k in range(G)]})
     out.update(extra)
     del sw, sd
     # ---- BASELINE configs[3] in this form: 10 M hashes, shard k generated on GPU k, one vdf_search_self_shards call
@@ -444,12 +508,9 @@ def run_single_process(args):
         sync_all()
         dt10 = time.perf_counter() - t1
         p10 = n10 * (n10 - 1) // 2
-        out["c4_10m_sharded"] = {"workload": f"BASELINE configs[3]: all-pairs search() over {n10} random VideoHashes sharded over "
-                                             f"{G} device(s), one call of vdf_search_self_shards", "n_hashes": n10, "pairs": p10,
-                                 "scaling": "strong", "steps": 1, "ms_per_step": dt10 * 1e3, "pairs_per_s": p10 / dt10,
-                                 "match_groups": len(g10), "planted_pairs": planted,
-                                 "per_device_kernel_ms": [eng.device_stats(k)["kernel_ms"] for k in range(G)],
-                                 "timing": eng.last_timing()}
+        out["c4_10m_sharded"] = dict(c4_summary(n10, G, dt10 * 1e3), match_groups=len(g10), planted_pairs=planted,
+                                     per_device_kernel_ms=[eng.device_stats(k)["kernel_ms"] for k in range(G)],
+                                     rccl_ranks_seen=eng.rccl_ranks(), timing=eng.last_timing())
         del sh, sdur
     if args.hash_clips > 0:
         nc = args.hash_clips
@@ -469,13 +530,11 @@ def run_single_process(args):
             eng.hash_frames_shards(fp, ns, 16, 64, 64, op)  # returns when every device has finished
         ms = (time.perf_counter() - t1) / args.steps * 1e3
         h_gbs = nc * 16 / (ms * 1e-3) * BYTES_PER_FRAME / 1e9
-        out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": G * nc * 16 / (ms * 1e-3),
-                       "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": G, "ms_per_step": ms,
-                       "dtype": "u8 -> i8 MFMA fixed point (exact) -> f64 DCT",
+        out["hash"] = {"value": G * nc * 16 / (ms * 1e-3), "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": G, "ms_per_step": ms,
                        "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": h_gbs,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS, "traffic": None,
-                                    "note": "host wall time per call incl. launch + join of the per-device threads"}}
-    print(json.dumps(out))
+                                    "timed": "host wall per call incl. launch + join of the per-device threads"}}
+    print(finish_line(out))
     eng.close()
 
 
@@ -496,6 +555,8 @@ def main():
     ap.add_argument("--c5-cands", type=int, default=1_000_000, help="BASELINE configs[4] leg: candidate clips, all ranks together (0 = skip)")
     ap.add_argument("--c5-refs", type=int, default=100_000, help="BASELINE configs[4] leg: reference clips")
     ap.add_argument("--dup-heavy", type=int, default=1_000_000, help="size of the duplicate-dense leg (0 = skip; --gpus 1 only)")
+    ap.add_argument("--cache-entries", type=int, default=10_000_000,
+                    help="entries of the synthetic app cache of the cache_ingest leg (0 = skip; --gpus 1 only)")
     ap.add_argument("--no-valu", dest="valu_leg", action="store_false", help="skip the XOR+popcount backend leg")
     ap.add_argument("--no-refs", dest="refs_leg", action="store_false", help="skip the search_with_references leg")
     ap.add_argument("--no-single-process-leg", dest="sp_leg", action="store_false",
@@ -607,23 +668,18 @@ def main():
 
     backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
     roofline, extra, dtype = search_roofline(backend, kernel_ms)
-    out = {
-        "metric": "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash']",
-        "value": pairs * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: random 1000-bit VideoHashes, all durations 0, all-pairs "
-                               "search_self at tolerance 350, planted near-duplicates every 1000th hash",
-                   "n_hashes": n_total, "hashes_per_gpu_shard": hi - lo, "pairs": pairs, "tolerance_int": tol_int,
-                   "parallelism": f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1
-                   else "single GPU"},
-        "roofline": roofline, "match_groups": n_groups, "search_backend": backend,
-        "n_launches": int(round(float(np.mean(launches)))), "suspects": int(round(float(np.mean(suspects)))),
-    }
+    out = headline(pairs * args.steps / dt, args.steps, args.warmup, dt / args.steps * 1e3, world, dtype, n_total, hi - lo, pairs, tol_int,
+                   f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU", roofline)
+    out.update({"match_groups": n_groups, "search_backend": backend, "n_launches": int(round(float(np.mean(launches)))),
+                "suspects": int(round(float(np.mean(suspects))))})
+    if world > 1:  # ranks that took part in the collectives of the timed steps
+        out["rccl_ranks_seen"] = dist.get_world_size() if dist_backend == "nccl" else 0
+        out["dist_backend"] = dist_backend
     out.update(extra)
+    legs = {}  # named legs, inserted behind the headline in the order chosen at the end
 
     # ---- windowed-durations variant: same hashes, durations = floor(exp(U(ln 5, ln 7200))) sorted, so the
-    # one-sided x1.1 window admits ~1 % of the triangle; shows what the window/tile culling costs.  rank 0 only.
+    # one-sided x1.1 window (search_algorithm.rs:99) admits ~1 % of the triangle; shows what the window/tile culling costs.  rank 0 only.
     if rank == 0 and args.windowed:
         rng = np.random.default_rng(20250613)
         dur = np.sort(np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=args.n_hashes))).astype(np.uint32))
@@ -632,17 +688,17 @@ def main():
         torch.cuda.synchronize()
         for _ in range(max(min(args.warmup, 2), 1)):
             eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
-        w_k = []
-        t1 = time.perf_counter()
+        w_k, w_ms = [], []
         for _ in range(leg_steps):
+            t1 = time.perf_counter()
             hits_w, _, _ = eng.search_self_device(ww.data_ptr(), wd.data_ptr(), args.n_hashes, tol_int, stream=stream)
+            w_ms.append((time.perf_counter() - t1) * 1e3)
             w_k.append(eng.last_stats()["kernel_ms"])
-        dtw = (time.perf_counter() - t1) / leg_steps
         st = eng.last_stats()
-        out["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"],
-                           "waste_ratio": st["pairs_computed"] / max(st["pairs"], 1), "kernel_ms": float(np.mean(w_k)),
-                           "ms": dtw * 1e3, "steps": leg_steps, "pairs_per_s": st["pairs"] / dtw, "hits": len(hits_w),
-                           "note": "log-uniform durations, one-sided x1.1 window (search_algorithm.rs:99); mean over steps"}
+        ms_med, ms_min = med_min(w_ms)
+        legs["windowed"] = {"pairs": st["pairs"], "pairs_computed": st["pairs_computed"],
+                            "waste_ratio": st["pairs_computed"] / max(st["pairs"], 1), "kernel_ms": med_min(w_k)[0],
+                            "ms": ms_med, "ms_min": ms_min, "steps": leg_steps, "pairs_per_s": st["pairs"] / (ms_med * 1e-3), "hits": len(hits_w)}
         del ww, wd
 
     # ---- the north_star's literal formulation next to the default one: XOR + popcount on the VALU (hamming_tile_kernel),
@@ -669,23 +725,17 @@ def main():
         # zeros - not counted), waves that take the early exit stop after early_exit_bits
         pad_rows = (-n_total) % 512
         lane_ops = executed_pairs(sv) * (1.0 - pad_rows / (n_total + pad_rows)) * LANEOPS_PER_PAIR
-        out["valu_backend"] = {"kernel": "hamming_tile_kernel", "pairs_per_s": pairs / dtv, "ms_per_step": dtv * 1e3,
-                               "kernel_ms": sv["kernel_ms"], "match_groups": len(gv), "steps": 1,
-                               "valu": {"achieved": lane_ops / (sv["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
-                                        "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS,
-                                        "note": "xor + bcnt lane-ops of rows < n_rows only (64 per full pair, 52 for a wave that "
-                                                "leaves after 832 bits; the kernel's other VALU work is not counted); peak = 16 lanes/clk/SIMD "
-                                                "x 1024 SIMDs x the NOMINAL 2.4 GHz (rocminfo's Max Clock): the kernel sits on the VALU issue "
-                                                "rate, so frac reads the box's real VALU clock / 2.4 GHz - 0.998 .. 1.005 over this round's boxes"},
-                               "note": "XOR + v_bcnt over 32 dwords per pair, candidates streamed through SGPRs; same exact "
-                                       "early exit; identical MatchGroups"}
+        legs["valu_backend"] = {"kernel": "hamming_tile_kernel", "pairs_per_s": pairs / dtv, "ms_per_step": dtv * 1e3,
+                                "kernel_ms": sv["kernel_ms"], "match_groups": len(gv), "steps": 1,
+                                "valu": {"achieved": lane_ops / (sv["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                                         "unit": "lane-ops/s", "frac": lane_ops / (sv["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS}}
         assert len(gv) == n_groups, "VALU and MFMA backends disagree"
         eng_v.close()
     del shard_w, shard_d
 
     # ---- BASELINE configs[3]: all-pairs search() over 10 M VideoHashes, the database sharded over the ranks (shard r
     # generated on GPU r), ONE all-gather, row tiles dealt round-robin, one replay on rank 0.  STRONG scaling: the work is
-    # fixed, expect ~10.7 s / N + the all-gather.  At one GPU this is the north_star's own target ("ten_million").
+    # fixed, expect ~10.4 s / N + the all-gather.  At one GPU this is the north_star's own target ("ten_million").
     if args.c4_hashes > 0:
         n10 = args.c4_hashes
         lo10, hi10 = vd.split_range(n10, rank, world)
@@ -705,27 +755,25 @@ def main():
         barrier()
         dt10 = max_over_ranks(time.perf_counter() - t10)
         s10 = eng.last_stats()
-        p10 = n10 * (n10 - 1) // 2
         k10 = max_over_ranks(s10["kernel_ms"]) * 1e-3
         ex_all = sum_over_ranks(executed_pairs(s10))
         comp_all = sum_over_ranks(s10["pairs_computed"])
         if rank == 0:
-            c4 = {"workload": f"BASELINE configs[3]: all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
-                              f"{tol_int}, database sharded over {world} GPU(s): one all-gather, row tiles round-robin, one replay",
-                  "n_hashes": n10, "pairs": p10, "scaling": "strong", "n_gpus": world, "steps": 1, "ms_per_step": dt10 * 1e3,
-                  "pairs_per_s": p10 / dt10, "all_gather_ms": t_gather * 1e3, "kernel_ms": k10 * 1e3,
-                  "n_launches": s10["n_launches"], "match_groups": len(g10r), "planted_pairs": planted,
-                  "hbm_operand_stream_x": p10 / dt10 * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS}
-            if backend != "valu":
+            c4 = dict(c4_summary(n10, world, dt10 * 1e3), all_gather_ms=t_gather * 1e3, kernel_ms=k10 * 1e3, n_launches=s10["n_launches"],
+                      match_groups=len(g10r), planted_pairs=planted)
+            if world > 1:
+                c4["rccl_ranks_seen"] = out.get("rccl_ranks_seen")
+            if backend != "valu":  # per GPU: executed MFMA FLOP of all ranks / N / the slowest rank's kernel time
                 c4["roofline"] = {"bound": "mfma", "kernel": roofline["kernel"], "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "achieved": ex_all * FLOP_PER_PAIR / k10 / 1e12 / world,
                                   "frac": ex_all * FLOP_PER_PAIR / k10 / 1e12 / world / MFMA_FP4_PEAK_TFLOPS,
                                   "algorithmic_frac": comp_all * FLOP_PER_PAIR / k10 / 1e12 / world / MFMA_FP4_PEAK_TFLOPS,
-                                  "traffic": None, "note": "per GPU: executed MFMA FLOP of all ranks / N / the slowest rank's kernel time"}
-            out["c4_10m_sharded"] = c4
-            if world == 1:
-                out["ten_million"] = dict(c4, workload=f"all-pairs search() over {n10} random VideoHashes, durations 0, tolerance "
-                                                       f"{tol_int}, ONE GPU (north_star target; BASELINE configs[3] database)")
+                                  "traffic": None}
+            legs["c4_10m_sharded"] = c4
+            if world == 1:  # the north_star's own target, under the name it has had since round 1
+                legs["ten_million"] = {"same_as": "c4_10m_sharded", "ms_per_step": c4["ms_per_step"], "pairs_per_s": c4["pairs_per_s"],
+                                       "match_groups": c4["match_groups"], "planted_pairs": planted,
+                                       "roofline_frac": c4.get("roofline", {}).get("frac")}
         del w10, d10, fw, fd
 
     # ---- search_with_references at the BASELINE configs[4] shape (hash-less half): 1 M candidates x 100 k references,
@@ -742,6 +790,7 @@ def main():
         rw, rdur = rw[pr], rdur[pr]
         tt = [torch.from_numpy(a).to(dev) for a in (cw.view(np.int64), cdur.view(np.int32), rw.view(np.int64), rdur.view(np.int32))]
         torch.cuda.synchronize()
+
         def refs_runs(reps):
             kms, wall, tms = [], [], []
             for i in range(reps + 2):
@@ -749,24 +798,20 @@ def main():
                 hr, nh = eng.search_refs_device(tt[0].data_ptr(), tt[1].data_ptr(), n_c, tt[2].data_ptr(), tt[3].data_ptr(), n_r, tol_int,
                                                 stream=stream)
                 if i >= 2:
-                    wall.append(time.perf_counter() - t1)
+                    wall.append((time.perf_counter() - t1) * 1e3)
                     kms.append(eng.last_stats()["kernel_ms"])
                     tms.append(eng.last_timing())
-            return float(np.mean(kms)), float(np.mean(wall)), {k: float(np.mean([t[k] for t in tms])) for k in ("prep_ms", "stream_ms", "resolve_ms", "download_ms")}, int(nh)
+            return med_min(kms)[0], med_min(wall), {k: float(np.median([t[k] for t in tms])) for k in ("prep_ms", "stream_ms", "resolve_ms", "download_ms")}, int(nh)
 
         k_un, w_un, t_un, nh = refs_runs(leg_steps)
         eng.pin_database(tt[0].data_ptr(), n_c)  # the app's situation: ONE cache database, searched with reference set after reference set
         k_pin, w_pin, t_pin, nh = refs_runs(leg_steps)
         eng.pin_database(0, 0)
         sr = eng.last_stats()
-        out["refs_c5_shape"] = {"workload": "search_with_references, 1 M candidates x 100 k references (BASELINE configs[4] without the "
-                                            "hashing half), log-uniform durations, +-5 % windows, half of the references planted; the "
-                                            "candidate database pinned (vdf_ctx_pin_database), as when one cache is searched repeatedly",
-                                "pairs": sr["pairs"], "pairs_computed": sr["pairs_computed"],
-                                "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "workgroups": sr["n_tiles"], "kernel_ms": k_pin,
-                                "ms": w_pin * 1e3, "hits": nh, "pairs_per_s": sr["pairs"] / w_pin, "timing": t_pin,
-                                "unpinned": {"ms": w_un * 1e3, "kernel_ms": k_un, "timing": t_un,
-                                             "note": "every call expands the candidate database again (0.15 ms per million hashes)"}}
+        legs["refs_c5_shape"] = {"pairs": sr["pairs"], "pairs_computed": sr["pairs_computed"],
+                                 "waste_ratio": sr["pairs_computed"] / max(sr["pairs"], 1), "workgroups": sr["n_tiles"], "kernel_ms": k_pin,
+                                 "ms": w_pin[0], "ms_min": w_pin[1], "hits": nh, "pairs_per_s": sr["pairs"] / (w_pin[0] * 1e-3), "timing": t_pin,
+                                 "unpinned": {"ms": w_un[0], "ms_min": w_un[1], "kernel_ms": k_un, "timing": t_un}}
         del tt
 
     # ---- BASELINE configs[4] END TO END: candidate and reference clips (16 x 64 x 64 u8) resident per rank -> hashes ->
@@ -776,15 +821,20 @@ def main():
         out_c5 = leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stream, barrier, max_over_ranks,
                         sum_over_ranks, leg_steps)
         if rank == 0:
-            out["c5_end_to_end"] = out_c5
+            legs["c5_end_to_end"] = out_c5
 
     # ---- a duplicate-DENSE database: the product's own case.  Whole call through the C ABI on device-resident shards
     # (vdf_search_self_shards on a one-device context: replication = one device copy), with the library's phase timing.
     if rank == 0 and world == 1 and args.dup_heavy > 0:
-        out["dup_heavy"] = leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, words, leg_steps)
+        legs["dup_heavy"] = leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, words, leg_steps)
+
+    # ---- SURVEY 8f N1 at its own scale: app cache bytes -> decode -> vdf_search_cache_entries, phase by phase.  Host + 1 GPU, rank 0.
+    if rank == 0 and world == 1 and args.cache_entries > 0:
+        legs["cache_ingest"] = leg_cache_ingest(args, vdf, eng, tol_int)
 
     # ---- DCT-hash leg (configs[2]): frame stacks resident in HBM; clips are independent, so every rank hashes its
     # own args.hash_clips clips with no communication (weak scaling) and the job rate is the sum -----------------
+    hash_leg = None
     if args.hash_clips > 0:
         nc = args.hash_clips
         g = torch.Generator(device=dev)
@@ -803,15 +853,26 @@ def main():
         ms = max_over_ranks(ev0.elapsed_time(ev1) / args.steps)
         fps = world * nc * 16 / (ms * 1e-3)
         h_gbs = nc * 16 / (ms * 1e-3) * BYTES_PER_FRAME / 1e9  # per GPU: the kernel's own roofline
-        out["hash"] = {"metric": "frames/sec DCT-hash (16 x 64x64 u8 -> 1000-bit VideoHash)", "value": fps,
-                       "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": world, "ms_per_step": ms,
-                       "dtype": "u8 -> i8 MFMA fixed point (exact) -> f64 DCT",
-                       "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": h_gbs,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS,
-                                    "traffic": read_traffic("resize_dct_hash_fused_kernel")}}
+        h_traffic, h_src = read_traffic("resize_dct_hash_persistent_kernel", nc / 100_000)  # profiled at 100 k clips per launch
+        hash_leg = {"value": fps, "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": world, "ms_per_step": ms,
+                    "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": h_gbs,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS,
+                                 "traffic": h_traffic, "traffic_source": h_src}}
         del frames, out_h
         # the same path at the size decoders really hand over (informational; the headline stays the 64 x 64 config)
         if args.hash_hd_clips > 0 and world == 1:
+            def timed_steps(fn):
+                """per-step HIP-event times (ms) of leg_steps calls on the bench's stream"""
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(leg_steps + 1)]
+                barrier()
+                evs[0].record()
+                res = None
+                for i in range(leg_steps):
+                    res = fn()
+                    evs[i + 1].record()
+                torch.cuda.synchronize()
+                return [evs[i].elapsed_time(evs[i + 1]) for i in range(leg_steps)], res
+
             def big_leg(name, n, w, h, kernel, key, profiled):
                 buf = torch.empty((n, 16, h, w), dtype=torch.uint8, device=dev)
                 chunk = max(1, (1 << 31) // (16 * h * w))
@@ -819,19 +880,14 @@ def main():
                     buf[c0:c0 + chunk] = torch.randint(0, 256, (min(chunk, n - c0), 16, h, w), dtype=torch.uint8, device=dev, generator=g)
                 oh = torch.zeros((n, 16), dtype=torch.int64, device=dev)
                 eng.hash_frames_device(buf.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
-                barrier()
-                ev0.record()
-                for _ in range(leg_steps):
-                    eng.hash_frames_device(buf.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
-                ev1.record()
-                torch.cuda.synchronize()
-                ms_l = ev0.elapsed_time(ev1) / leg_steps
+                ts, _ = timed_steps(lambda: eng.hash_frames_device(buf.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream))
+                ms_l, ms_lo = med_min(ts)
                 gbs = n * 16 * (w * h + 8) / (ms_l * 1e-3) / 1e9
-                out["hash"][name] = {"workload": f"{n} clips of 16 x {h} x {w} u8 per GPU", "ms_per_step": ms_l,
-                                     "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3),
-                                     "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                                  "traffic": scaled_traffic(key, n, profiled)}}
+                hash_leg[name] = {"clips": n, "w": w, "h": h, "ms_per_step": ms_l, "ms_min": ms_lo,
+                                  "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3),
+                                  "roofline": {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                               "traffic": read_traffic(key, n / profiled)[0]}}
                 del buf, oh
 
             big_leg("full_hd", args.hash_hd_clips, 1920, 1080, "resize_mfma_frame_wavestream_kernel",
@@ -842,11 +898,10 @@ def main():
             big_leg("uhd_3840x2160", 250, 3840, 2160, "resize_mfma_frame_ksplit_kernel", "resize_mfma_frame_ksplit_kernel@3840x2160", 250)
 
             # SURVEY 8f N3, the builder's default (Cropdetect::Letterbox before from_frames) at the decoder's native size: detect + crop +
-            # hash of 1080p clips with bars, one vdf_hash_frames_u8_letterbox_device call per step (it downloads the boxes in between)
+            # hash of 1080p clips with bars, one vdf_hash_frames_u8_letterbox_device call per step (it downloads the boxes in between).
+            # box_GB_per_s counts the bytes of the crop boxes (what the resize has to read); the probe reads of the detect pass are on top.
             def letterbox_leg(n, w, h):
-                res = {"workload": f"{n} clips of 16 x {h} x {w} u8 per GPU, detect + crop + hash in one call "
-                                   "(letterbox_kernel, then the ROWCROP stream kernels for full-width boxes / resize_mfma_cropped_stream_kernel)",
-                       "GB_per_s_counts": "bytes of the crop boxes (what the resize has to read); the probe reads of the detect pass are on top"}
+                res = {"clips": n, "w": w, "h": h}
                 base = torch.empty((n, 16, h, w), dtype=torch.uint8, device=dev)
                 chunk = max(1, (1 << 31) // (16 * h * w))
                 for c0 in range(0, n, chunk):
@@ -865,41 +920,42 @@ def main():
                         fr[:, :, :, w - bar_s:] = 16
                     elif name == "one_black_probe_frame_in_1000":  # a fade-in: every strip is letterbox, the edges converge, "no crop"
                         fr[::1000, 0] = 16
-                    crops = eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
-                    barrier()
-                    ev0.record()
-                    for _ in range(leg_steps):
-                        crops = eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
-                    ev1.record()
-                    torch.cuda.synchronize()
-                    ms_l = ev0.elapsed_time(ev1) / leg_steps
+                    eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
+                    ts, crops = timed_steps(lambda: eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream))
+                    ms_l, ms_lo = med_min(ts)
                     c0 = [int(x) for x in crops[0]]
                     kept = (w - c0[0] - c0[1]) * (h - c0[2] - c0[3])
-                    res[name] = {"ms_per_step": ms_l, "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3), "crop_of_clip_0": c0,
+                    res[name] = {"ms_per_step": ms_l, "ms_min": ms_lo, "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3), "crop_of_clip_0": c0,
                                  "box_GB_per_s": n * 16 * kept / (ms_l * 1e-3) / 1e9}
                     if fr is not base:
                         del fr
-                out["hash"]["letterbox_full_hd"] = res
+                hash_leg["letterbox_full_hd"] = res
                 del base, oh
 
-            if args.hash_hd_clips > 0:
-                letterbox_leg(args.hash_hd_clips, 1920, 1080)
+            letterbox_leg(args.hash_hd_clips, 1920, 1080)
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)
-        if args.hash_clips > 0:
-            out["hash"]["cpu_baseline"] = cpu_baseline_hash()
+        if hash_leg is not None:
+            hash_leg["cpu_baseline"] = cpu_baseline_hash()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
     if rank == 0:
+        # order of the line: contract keys (+ roofline, cpu_baseline), then BASELINE configs[3] - strong scaling, the leg to read first
+        # on a multi-GPU run - then the other legs, the long hash leg, and hash_summary last (finish_line)
+        for k in ("c4_10m_sharded", "ten_million", "c5_end_to_end", "dup_heavy", "cache_ingest", "refs_c5_shape", "windowed", "valu_backend"):
+            if k in legs:
+                out[k] = legs[k]
         if world > 1 and args.sp_leg:
             # the ranks are gone (or going: their memory is not needed - 288 GB per GPU); this process never execs
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             out["single_process"] = single_process_leg(args)
-        print(json.dumps(out), flush=True)
+        if hash_leg is not None:
+            out["hash"] = hash_leg
+        print(finish_line(out), flush=True)
 
 
 def leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stream, barrier, max_over_ranks, sum_over_ranks,
@@ -934,12 +990,14 @@ def leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stre
     d_cd, d_rd = torch.from_numpy(cd).to(dev), torch.from_numpy(rd).to(dev)
     n_planted = int(round(sum_over_ranks(len(planted))))
     res = vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False)  # allocations, tables
-    barrier()
-    t0 = time.perf_counter()
+    step_ms = []
     for _ in range(leg_steps):
+        barrier()
+        t0 = time.perf_counter()
         res = vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False)
-    barrier()
-    dt = max_over_ranks((time.perf_counter() - t0) / leg_steps)
+        barrier()
+        step_ms.append(max_over_ranks((time.perf_counter() - t0) * 1e3))
+    dt_med, dt_min = med_min(step_ms)
     tm = {}
     vd.hash_and_search_refs(eng, cand, d_cd, ref, d_rd, tol_int, stream=stream, as_lists=False, timings=tm)  # phases, each behind a sync
     sr = eng.last_stats()
@@ -952,61 +1010,172 @@ def leg_c5(args, torch, dist, vd, eng, dev, rank, world, use_dist, tol_int, stre
         return None
     offsets, members, ref_index = res[0]
     clips = n_c + n_r
-    # device work of a step: hashing at the hash kernel's rate + the search kernel: what the wall time is compared with
-    return {"workload": f"BASELINE configs[4] end to end: {n_c} candidate + {n_r} reference clips of 16 x 64 x 64 u8 resident in HBM "
-                        f"({clips * 65536 / 1e9:.1f} GB over {world} GPU(s)) -> VideoHash -> all-gather -> Search::sort (device) -> "
-                        "search_with_references (+-5 % windows) -> groups",
-            "n_candidates": n_c, "n_references": n_r, "n_gpus": world, "scaling": "strong", "steps": leg_steps,
-            "ms_per_step": dt * 1e3, "clips_per_s": clips / dt, "frames_per_s": clips * 16 / dt,
-            "phases_ms": tm, "phases_note": "one extra call with a device synchronisation after every phase (max over ranks); "
-                                            "group_ms = hit gather + CSR groups + order download on rank 0",
+    # phases_ms: one extra call with a device synchronisation after every phase (max over ranks); group_ms = hit gather + CSR groups +
+    # order download on rank 0.  ms_per_step: median over the steps (each between two barriers)
+    return {"workload": "BASELINE configs[4] end to end", "n_candidates": n_c, "n_references": n_r, "n_gpus": world, "scaling": "strong",
+            "steps": leg_steps, "ms_per_step": dt_med, "ms_min": dt_min, "clips_per_s": clips / (dt_med * 1e-3),
+            "frames_per_s": clips * 16 / (dt_med * 1e-3), "resident_GB": clips * 65536 / 1e9, "phases_ms": tm,
             "search_pairs": pairs, "search_kernel_ms": sr["kernel_ms"], "search_call_timing": stl,
             "groups": int(len(ref_index)), "members": int(len(members)), "planted_references": n_planted}
 
 
 def leg_dup_heavy(args, torch, vdf, dev, local_rank, tol_int, sparse_words, leg_steps):
+    """search() over a duplicate-dense database (make_dup_heavy: 10 % of the hashes in clusters of 2..200 near-copies sharing their centre's
+    duration, log-uniform durations): the whole vdf_search_self_shards call on the device-resident database, on a one-device context and
+    - "two_slots" - sharded over two slots of the same GPU, where the slots meet to OR the replay filter's bitmaps (csrc/multi.cpp:
+    LocalExchange) and what comes down must stay s - 1 pairs per cluster.  sparse_same_windows: the headline's random hashes under the
+    same sorted durations."""
     n = args.dup_heavy
     t_gen = time.perf_counter()
     words, dur, n_clusters, cluster_pairs = make_dup_heavy(n)
     t_gen = time.perf_counter() - t_gen
-    eng1 = vdf.Engine(devices=[local_rank])
-    out = {}
-    try:
-        def run(w, d, reps):
-            tw = torch.from_numpy(w.view(np.int64)).to(dev)
-            td = torch.from_numpy(d.view(np.int32)).to(dev)
-            torch.cuda.synchronize()
-            eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int)  # allocations
-            wall, tms, sts, ng = [], [], [], 0
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                offsets, mem = eng1.search_self_shards([tw.data_ptr()], [td.data_ptr()], [len(d)], tol_int, as_arrays=True)
-                wall.append((time.perf_counter() - t0) * 1e3)
-                tms.append(eng1.last_timing())
-                sts.append(eng1.last_stats())
-                ng = len(offsets) - 1
-                members = len(mem)
-            tm = {k: float(np.mean([t[k] for t in tms])) for k in tms[0]}
-            return float(np.mean(wall)), tm, sts[-1], ng, members
 
+    def run(eng1, w, d, reps, slots=1):
+        cut = [len(d) * k // slots for k in range(slots + 1)]
+        tw = [torch.from_numpy(w[a:b].view(np.int64)).to(dev) for a, b in zip(cut[:-1], cut[1:])]
+        td = [torch.from_numpy(d[a:b].view(np.int32)).to(dev) for a, b in zip(cut[:-1], cut[1:])]
+        pw, pd, sz = [t.data_ptr() for t in tw], [t.data_ptr() for t in td], [len(t) for t in td]
+        torch.cuda.synchronize()
+        eng1.search_self_shards(pw, pd, sz, tol_int)  # allocations
+        wall, tms, sts, ng, members = [], [], [], 0, 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            offsets, mem = eng1.search_self_shards(pw, pd, sz, tol_int, as_arrays=True)
+            wall.append((time.perf_counter() - t0) * 1e3)
+            tms.append(eng1.last_timing())
+            sts.append(eng1.last_stats())
+            ng = len(offsets) - 1
+            members = len(mem)
+        tm = {k: float(np.median([t[k] for t in tms])) for k in tms[0]}
+        return med_min(wall), tm, sts[-1], ng, members
+
+    out = {}
+    eng1 = vdf.Engine(devices=[local_rank])
+    try:
         ns = min(n, len(sparse_words))
         sp_dur = np.ascontiguousarray(dur[np.linspace(0, n - 1, ns).astype(np.int64)])  # the same (sorted) duration profile
-        sp_ms, sp_tm, sp_st, sp_groups, _ = run(np.ascontiguousarray(sparse_words[:ns]), sp_dur, leg_steps)
-        dn_ms, dn_tm, dn_st, dn_groups, dn_members = run(words, dur, leg_steps)
-        out = {"workload": f"search() over {n} hashes, {n_clusters} clusters of 2..200 near-copies ({int(0.10 * n)} hashes) within "
-                           "tolerance 350 sharing their centre's duration, log-uniform durations (one-sided x1.1 windows); whole "
-                           "vdf_search_self_shards call on the device-resident database (one-device context)",
-               "n_hashes": n, "clusters": n_clusters, "pairs_inside_clusters": cluster_pairs, "steps": leg_steps,
-               "ms_per_call": dn_ms, "pairs": dn_st["pairs"], "pairs_per_s": dn_st["pairs"] / (dn_ms * 1e-3),
+        sp_ms, sp_tm, sp_st, sp_groups, _ = run(eng1, np.ascontiguousarray(sparse_words[:ns]), sp_dur, leg_steps)
+        dn_ms, dn_tm, dn_st, dn_groups, dn_members = run(eng1, words, dur, leg_steps)
+        out = {"n_hashes": n, "clusters": n_clusters, "pairs_inside_clusters": cluster_pairs, "steps": leg_steps,
+               "ms_per_call": dn_ms[0], "ms_min": dn_ms[1], "pairs": dn_st["pairs"], "pairs_per_s": dn_st["pairs"] / (dn_ms[0] * 1e-3),
                "n_hits": dn_st["n_hits"], "n_launches": dn_st["n_launches"], "kernel_ms": dn_st["kernel_ms"],
                "timing": dn_tm, "suspect_queue_fill": dn_tm["suspects"] / max(dn_tm["suspect_capacity"], 1),
                "match_groups": dn_groups, "grouped_hashes": dn_members,
-               "sparse_same_windows": {"ms_per_call": sp_ms, "n_hits": sp_st["n_hits"], "match_groups": sp_groups, "timing": sp_tm,
-                                       "note": "the headline's random hashes (planted every 1000th) under the same sorted durations"},
-               "dense_over_sparse": dn_ms / sp_ms, "generation_s": t_gen}
+               "sparse_same_windows": {"ms_per_call": sp_ms[0], "ms_min": sp_ms[1], "n_hits": sp_st["n_hits"], "match_groups": sp_groups, "timing": sp_tm},
+               "dense_over_sparse": dn_ms[0] / sp_ms[0], "generation_s": t_gen}
     finally:
         eng1.close()
+    eng2 = vdf.Engine(devices=[local_rank, local_rank])
+    try:
+        t2_ms, t2_tm, t2_st, t2_groups, t2_members = run(eng2, words, dur, leg_steps, slots=2)
+        out["two_slots"] = {"ms_per_call": t2_ms[0], "ms_min": t2_ms[1], "n_hits": t2_st["n_hits"], "hits_filtered": t2_tm["hits_filtered"],
+                            "hits_downloaded": t2_st["n_hits"] - t2_tm["hits_filtered"],
+                            "downloaded_fraction": (t2_st["n_hits"] - t2_tm["hits_filtered"]) / max(t2_st["n_hits"], 1),
+                            "per_slot_hits_filtered": [eng2.device_timing(k)["hits_filtered"] for k in range(2)],
+                            "match_groups": t2_groups, "grouped_hashes": t2_members, "timing": t2_tm}
+        assert t2_groups == out["match_groups"] and t2_members == out["grouped_hashes"], "sharded and one-device searches disagree"
+    finally:
+        eng2.close()
     return out
+
+
+def synth_paths(n, seed=20250620):
+    """(blob u8, offsets u64[n + 1]): n paths like /srv/media/lib_07/show_0412/season_03/clip_00001234.mkv in arbitrary (HashMap) order over
+    ~n / 40 directories - shared directory prefixes, as a real library has - built with numpy column arithmetic, no per-entry Python strings."""
+    rng = np.random.default_rng(seed)
+    tmpl = np.frombuffer(b"/srv/media/lib_00/show_0000/season_00/clip_00000000.mkv", np.uint8)
+    blob = np.tile(tmpl, (n, 1))
+    ids = rng.permutation(n).astype(np.int64)
+    show = ids // 40
+    for at, width, val in ((15, 2, show // 2000 % 100), (23, 4, show % 2000 * 5 % 10000), (35, 2, ids // 8 % 5), (43, 8, ids)):
+        v = val.copy()
+        for k in range(width - 1, -1, -1):
+            blob[:, at + k] = 48 + v % 10
+            v //= 10
+    return blob.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(len(tmpl))
+
+
+def synth_cache(n, seed=20250620, plant_every=1000):
+    """The bytes of an app cache file with n Ok entries (vdf_cache_encode: bincode-2 standard(), key = src_path) plus the arrays they were
+    made from: random hashes, log-uniform durations, every plant_every-th entry a near-copy (<= 300 flipped bits, same duration) of
+    its predecessor - so the search has something to find.  Returns (bytes u8, hashes, durations, path blob, path offsets, planted)."""
+    import ctypes as C
+
+    from vid_dup_finder_lib_amd import _capi
+
+    lib = _capi.load()
+    rng = np.random.default_rng(seed)
+    hashes = rng.integers(0, 2**64, size=(n, 16), dtype=np.uint64)
+    hashes[:, 15] &= np.uint64((1 << 40) - 1)
+    dur = np.floor(np.exp(rng.uniform(np.log(5), np.log(7200), size=n))).astype(np.uint32)
+    src = np.arange(0, n - 1, plant_every)
+    if len(src):
+        flips = rng.random((len(src), 1024), dtype=np.float32) < rng.uniform(0.0, 0.29, size=(len(src), 1)).astype(np.float32)
+        hashes[src + 1] = hashes[src] ^ np.packbits(flips, axis=1, bitorder="little").view(np.uint64)
+        hashes[src + 1, 15] &= np.uint64((1 << 40) - 1)
+        dur[src + 1] = dur[src]
+    blob, offs = synth_paths(n, seed)
+    secs = rng.integers(1_600_000_000, 1_760_000_000, size=n, dtype=np.uint64)
+    nanos = rng.integers(0, 10**9, size=n, dtype=np.uint32)
+    out, out_len = C.c_void_p(), C.c_size_t()
+    rc = lib.vdf_cache_encode(n, hashes.ctypes.data, dur.ctypes.data, offs.ctypes.data, blob.ctypes.data, secs.ctypes.data,
+                              nanos.ctypes.data, C.byref(out), C.byref(out_len))
+    if rc:
+        raise RuntimeError(f"vdf_cache_encode failed: {rc}")
+    data = np.ctypeslib.as_array((C.c_uint8 * out_len.value).from_address(out.value)).copy()
+    lib.vdf_buffer_free(out)
+    return data, hashes, dur, blob, offs, len(src)
+
+
+def leg_cache_ingest(args, vdf, eng, tol_int):
+    """SURVEY 8f N1 at the scale the row exists for (the load it replaces: base_fs_cache.rs:167-223 -> app_fns.rs:428-482): the bytes of an
+    app cache with --cache-entries entries -> vdf_cache_decode_mt (all host threads by the library's own choice, and ONE thread beside it)
+    -> vdf_search_cache_entries (PathBuf ranks on the host threads, upload, Search::sort on the device, search(), map back to entries).
+    host_ms = everything but the search kernel's call: what a user waits for on top of the search itself."""
+    import ctypes as C
+
+    from vid_dup_finder_lib_amd import _capi
+    from vid_dup_finder_lib_amd import cache as vc
+
+    n = args.cache_entries
+    t0 = time.perf_counter()
+    data, hashes, dur, blob, offs, planted = synth_cache(n)
+    t_gen = time.perf_counter() - t0
+    del hashes, dur, blob, offs
+    lib = _capi.load()
+
+    def decode_ms(nt, reps):
+        ts = []
+        for _ in range(reps):
+            soa = _capi.VdfCacheSoa()
+            t1 = time.perf_counter()
+            rc = lib.vdf_cache_decode_mt(data.ctypes.data, data.size, nt, C.byref(soa))
+            ts.append((time.perf_counter() - t1) * 1e3)
+            assert rc == 0 and soa.n_ok == n
+            lib.vdf_cache_free(C.byref(soa))
+        return med_min(ts)
+
+    dec_auto = decode_ms(0, 3)
+    dec_one = decode_ms(1, 1)
+    t1 = time.perf_counter()
+    cache = vc.decode_cache(data)
+    t_dec = (time.perf_counter() - t1) * 1e3
+    runs = []
+    for _ in range(2):  # the first call allocates the device buffers
+        t1 = time.perf_counter()
+        offsets, members, refs, tm = vc.search_cache_arrays(cache, args.tolerance, engine=eng)
+        tm["wall_ms"] = (time.perf_counter() - t1) * 1e3
+        runs.append(tm)
+    tm = runs[-1]
+    st = eng.last_stats()
+    host_ms = t_dec + tm["rank_ms"] + tm["upload_ms"] + tm["sort_ms"] + tm["map_ms"]
+    return {"entries": n, "cache_MB": data.size / 1e6, "host_threads": os.cpu_count(), "generation_s": t_gen,
+            "decode_ms": dec_auto[0], "decode_ms_min": dec_auto[1], "decode_GB_per_s": data.size / (dec_auto[1] * 1e-3) / 1e9,
+            "decode_one_thread_ms": dec_one[0], "decode_in_this_call_ms": t_dec,
+            "search_cache_entries": {k: tm[k] for k in ("rank_ms", "upload_ms", "sort_ms", "search_ms", "map_ms", "total_ms", "wall_ms")},
+            "first_call_total_ms": runs[0]["total_ms"], "host_ms": host_ms, "search_pairs": st["pairs"], "search_kernel_ms": st["kernel_ms"],
+            "match_groups": int(len(offsets) - 1), "grouped_entries": int(len(members)), "planted_pairs": planted,
+            "tolerance_int": tol_int}
 
 
 if __name__ == "__main__":

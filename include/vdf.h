@@ -124,6 +124,9 @@ int vdf_ctx_device_at(const vdf_ctx *ctx, int slot); /* HIP device id of a slot,
  * kernel_ms = the slowest device's). */
 int vdf_ctx_device_search_stats(const vdf_ctx *ctx, int slot, vdf_search_stats *out);
 int vdf_ctx_device_search_timing(const vdf_ctx *ctx, int slot, vdf_search_timing *out); /* that slot's phases and hits_filtered */
+/* RCCL communicators (= ranks, one per GPU) the context has initialised so far: 0 until a *_shards call replicated through librccl
+ * (a device list that repeats a GPU, or a single-device context, never does: plain device copies). */
+int vdf_ctx_rccl_ranks(const vdf_ctx *ctx);
 void vdf_ctx_destroy(vdf_ctx *ctx);
 const char *vdf_last_error(const vdf_ctx *ctx); /* ctx may be NULL: last ctx_create failure */
 const char *vdf_version(void);

@@ -1,0 +1,130 @@
+"""bench.py's reporting code executed on the CPU: a NameError or a key that moved must fail HERE, not 400 tests into a metered GPU call
+(round 4 lost one to a leftover name).  Nothing below touches a GPU: the engine's per-step statistics are synthetic tuples."""
+import builtins
+import json
+import os
+import symtable
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+# (kernel_ms, n_launches, pairs, pairs_computed, n_hits, pairs_early_exit, early_exit_bits): the 1 M headline's figures
+STEP = (106.1, 1, 499_999_500_000, 500_300_000_000, 3778, 500_200_000_000, 832)
+
+
+def test_no_undefined_names_in_bench():
+    """Every name a function of bench.py reads resolves to a local, an enclosing scope, a module-level name or a builtin."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    top = symtable.symtable(src, "bench.py", "exec")
+    module_names = {s.get_name() for s in top.get_symbols() if s.is_assigned() or s.is_imported() or s.is_namespace()}
+    known = module_names | set(dir(builtins)) | {"__file__", "__name__"}
+    missing = []
+
+    def walk(t):
+        for s in t.get_symbols():
+            if t.get_type() == "module":
+                if s.is_referenced() and s.get_name() not in known:
+                    missing.append((t.get_name(), s.get_name()))
+            elif s.is_referenced() and s.is_global() and s.get_name() not in known:
+                missing.append((t.get_name(), s.get_name()))
+        for c in t.get_children():
+            walk(c)
+
+    walk(top)
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("backend", ["mfma", "valu"])
+def test_search_roofline_and_headline_assemble(backend, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "TRAFFIC_PATH", str(tmp_path / "none.json"))
+    roofline, extra, dtype = bench.search_roofline(backend, [STEP, STEP])
+    assert roofline["kernel"] == ("hamming_mfma2_kernel" if backend == "mfma" else "hamming_tile_kernel")
+    assert roofline["traffic"] is None and "missing" in roofline["traffic_source"]
+    assert abs(roofline["achieved"] / roofline["peak"] - roofline["frac"]) < 1e-12 and 0 < roofline["frac"]
+    if backend == "mfma":
+        # 8.1e14 executed FLOP in 106.1 ms of a 10 PF peak: the round-4 fraction
+        assert 0.75 < roofline["frac"] < 0.82 and roofline["algorithmic_frac"] > roofline["frac"]
+        assert extra["hbm_operand_stream_model"]["x_of_hbm_model"] > 50
+    else:
+        assert extra["valu"]["frac"] > 0
+    out = bench.headline(4.7e12, 20, 5, 106.9, 1, dtype, 1_000_000, 1_000_000, 499_999_500_000, 350, "single GPU", roofline)
+    assert list(out)[:13] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                              "vs_baseline", "dtype", "data", "config"]
+    assert out["vs_baseline"] is None and out["config"]["workload"].startswith("BASELINE configs[1]")
+    out["cpu_baseline"] = {"value": 3.6e8, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": "x"}
+    out["c4_10m_sharded"] = bench.c4_summary(10_000_000, 8, 1400.0)
+    out["hash"] = {"value": 1.5e9, "unit": "frames/s", "clips_per_gpu": 100_000, "n_gpus": 1, "ms_per_step": 1.04,
+                   "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": 6300.0, "peak": 8000.0,
+                                "unit": "GB/s", "frac": 0.7875, "traffic": None, "traffic_source": "x"},
+                   "full_hd": {"blah": "x" * 3000}, "cpu_baseline": {"value": 6e5, "unit": "frames/s", "cores": 256, "kind": "port", "sample": "y"}}
+    line = bench.finish_line(out)
+    d = json.loads(line)
+    assert list(d)[-1] == "hash_summary" and '"hash_summary"' in line[-1500:]  # a reader of the line's TAIL gets the second half of the metric
+    hs = d["hash_summary"]
+    assert hs["value"] == 1.5e9 and hs["roofline"]["frac"] == 0.7875 and hs["cpu_baseline"]["cores"] == 256 and hs["unit"] == "frames/s"
+    c4 = d["c4_10m_sharded"]
+    assert c4["scaling"] == "strong" and abs(c4["speedup_vs_n1_model"] - bench.C4_N1_REFERENCE_MS / 8 / 1400.0) < 1e-12
+
+
+def test_executed_pairs_and_medians():
+    st = {"pairs_computed": 1000.0, "pairs_early_exit": 800.0, "early_exit_bits": 832}
+    assert abs(bench.executed_pairs(st) - (1000.0 - 800.0 * (1 - 832 / 1024))) < 1e-9
+    st["early_exit_bits"] = 0
+    assert bench.executed_pairs(st) == 1000.0
+    assert bench.med_min([16.3, 13.2, 13.3]) == (13.3, 13.2)  # one slow step moves the mean, not the median
+
+
+def test_traffic_is_only_reported_for_the_library_it_was_measured_on(tmp_path, monkeypatch):
+    lib = tmp_path / "libvdf_hip.so"
+    lib.write_bytes(b"not really a library")
+    monkeypatch.setattr(bench, "LIB_PATH", str(lib))
+    monkeypatch.setattr(bench, "TRAFFIC_PATH", str(tmp_path / "pmc_traffic.json"))
+    bench._lib_sha.clear()
+    sha = bench.lib_sha256()
+    assert sha and len(sha) == 64
+    rec = {"lib_sha256": sha, "hamming_mfma2_kernel": {"hbm_bytes_per_launch": 8.2e10}}
+    (tmp_path / "pmc_traffic.json").write_text(json.dumps(rec))
+    v, src = bench.read_traffic("hamming_mfma2_kernel")
+    assert v == 8.2e10 and sha[:12] in src
+    assert bench.read_traffic("hamming_mfma2_kernel", 0.5)[0] == 4.1e10
+    v, src = bench.read_traffic("no_such_kernel")
+    assert v is None and "no entry" in src
+    rec["lib_sha256"] = "0" * 64  # a profile of another build
+    (tmp_path / "pmc_traffic.json").write_text(json.dumps(rec))
+    v, src = bench.read_traffic("hamming_mfma2_kernel")
+    assert v is None and "another libvdf_hip.so" in src
+    del rec["lib_sha256"]  # a file from before the sha was recorded
+    (tmp_path / "pmc_traffic.json").write_text(json.dumps(rec))
+    assert bench.read_traffic("hamming_mfma2_kernel")[0] is None
+    bench._lib_sha.clear()
+
+
+def test_committed_traffic_file_names_live_kernels_only():
+    """profiles/pmc_traffic.json: keyed to a library sha, no entry for a kernel that no longer exists."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    t = json.load(open(p))
+    assert isinstance(t.get("lib_sha256"), str) and len(t["lib_sha256"]) == 64
+    src = "".join(open(os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc", f)).read() for f in ("hamming.hip", "dct_hash.hip"))
+    for k in t:
+        if k in ("lib_sha256", "profiled_with"):
+            continue
+        assert k.split("@")[0] + "(" in src or k.split("@")[0] + "<" in src or ("void " + k.split("@")[0]) in src, k
+
+
+def test_synthetic_cache_generator_round_trips():
+    """bench.synth_cache (the cache_ingest leg's input): the app's wire format, decodable, paths plain and distinct."""
+    import numpy as np
+
+    from vid_dup_finder_lib_amd import cache as vc
+
+    data, hashes, dur, blob, offs, planted = bench.synth_cache(5000, plant_every=100)
+    c = vc.decode_cache(data, 1)
+    assert c["n_entries"] == 5000 and c["n_err"] == 0 and c["n_key_differs"] == 0
+    assert np.array_equal(c["hashes"], hashes) and np.array_equal(c["durations"], dur) and planted == 50
+    assert c["paths"][0].startswith("/srv/media/lib_") and len(set(c["paths"])) == 5000
+    assert all(int(np.unpackbits((hashes[i] ^ hashes[i + 1]).view(np.uint8)).sum()) <= 350 for i in range(0, 4900, 100))

@@ -15,7 +15,7 @@ def test_bench_emits_the_contract_line(backend):
     env = dict(os.environ, VDF_SEARCH_BACKEND=backend)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
                           "--n-hashes", "30000", "--hash-clips", "3000", "--hash-hd-clips", "20", "--ten-million", "200000",
-                          "--c5-cands", "4000", "--c5-refs", "400", "--dup-heavy", "40000"], capture_output=True, text=True, timeout=600, env=env)
+                          "--c5-cands", "4000", "--c5-refs", "400", "--dup-heavy", "40000", "--cache-entries", "30000"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # exactly ONE JSON line on stdout
@@ -43,9 +43,17 @@ def test_bench_emits_the_contract_line(backend):
     assert d["windowed"]["waste_ratio"] >= 1.0
     rf = d["refs_c5_shape"]
     assert rf["hits"] == 50000 and 1.0 <= rf["waste_ratio"] < 1.5 and rf["kernel_ms"] > 0
-    t = d["ten_million"]  # the north_star's target leg (here at a test size)
+    t = d["c4_10m_sharded"]  # BASELINE configs[3]; at one GPU the north_star's target leg (here at a test size)
     assert t["n_hashes"] == 200000 and t["pairs"] == 200000 * 199999 // 2 and t["match_groups"] >= t["planted_pairs"] - 1
-    assert d["c4_10m_sharded"]["ms_per_step"] == t["ms_per_step"] and d["c4_10m_sharded"]["scaling"] == "strong"
+    assert d["ten_million"]["ms_per_step"] == t["ms_per_step"] and t["scaling"] == "strong" and d["ten_million"]["same_as"] == "c4_10m_sharded"
+    keys = list(d)
+    assert keys[-1] == "hash_summary" and keys.index("c4_10m_sharded") < keys.index("c5_end_to_end") < keys.index("hash")
+    hs = d["hash_summary"]  # the second half of BASELINE's metric, where a reader of the line's tail finds it
+    assert hs["value"] == d["hash"]["value"] and hs["roofline"]["frac"] == d["hash"]["roofline"]["frac"] and hs["cpu_baseline"]["cores"] >= 1
+    assert '"hash_summary"' in lines[0][-1800:] and len(lines[0]) < 12000
+    ci = d["cache_ingest"]  # cache bytes -> groups, phase by phase
+    assert ci["entries"] == 30000 and ci["match_groups"] >= ci["planted_pairs"] - 1 and ci["decode_ms"] > 0 and ci["host_ms"] > 0
+    assert set(ci["search_cache_entries"]) >= {"rank_ms", "upload_ms", "sort_ms", "search_ms", "map_ms", "total_ms"}
     c5 = d["c5_end_to_end"]  # BASELINE configs[4] end to end (here at a test size)
     assert c5["groups"] == c5["planted_references"] == 200 and c5["members"] == 200 and c5["clips_per_s"] > 0
     assert set(c5["phases_ms"]) == {"hash_ms", "all_gather_ms", "sort_ms", "search_ms", "group_ms"}
@@ -53,6 +61,9 @@ def test_bench_emits_the_contract_line(backend):
     assert dh["n_hits"] >= dh["pairs_inside_clusters"] > 0 and dh["match_groups"] == dh["clusters"]
     assert dh["grouped_hashes"] == 4000 and dh["n_launches"] >= 1 and dh["timing"]["total_ms"] > 0
     assert dh["sparse_same_windows"]["n_hits"] < dh["n_hits"] and 0 <= dh["suspect_queue_fill"] <= 1.0
+    two = dh["two_slots"]  # the same database sharded over two slots: same groups; the slots' filter (when the list is long enough) agrees
+    assert two["match_groups"] == dh["match_groups"] and two["n_hits"] == dh["n_hits"] and 0 < two["downloaded_fraction"] <= 1.0
+    assert c5["ms_min"] <= c5["ms_per_step"] and d["windowed"]["ms_min"] <= d["windowed"]["ms"]
     assert d["n_launches"] == 1 and d["suspects"] >= 0
     assert d["cpu_baseline"]["all_cores"]["in_reference"] is False and d["cpu_baseline"]["all_cores"]["cores"] >= 1
     if backend == "mfma":

@@ -241,7 +241,7 @@ def _bench(extra, timeout=1500):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VDF_DIST_BACKEND"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--hash-clips", "2000",
-                          "--hash-hd-clips", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs"] + extra,
+                          "--hash-hd-clips", "0", "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs", "--cache-entries", "0"] + extra,
                          capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -257,9 +257,11 @@ def test_bench_on_distinct_devices_runs_both_forms_and_the_named_legs():
     assert d["n_gpus"] == 2 and d["match_groups"] > 0
     c4 = d["c4_10m_sharded"]
     assert c4["n_hashes"] == 120000 and c4["scaling"] == "strong" and c4["match_groups"] >= c4["planted_pairs"] - 1
+    assert d["rccl_ranks_seen"] == 2 and c4["rccl_ranks_seen"] == 2  # torch.distributed "nccl": one RCCL rank per GPU took part
     c5 = d["c5_end_to_end"]
     assert c5["n_candidates"] == 6000 and c5["n_references"] == 600 and c5["groups"] == c5["planted_references"]
     sp = d["single_process"]
     assert sp["rccl"] == "ok", sp
     assert sp["match_groups"] == d["match_groups"] and len(sp["per_device_kernel_ms"]) == 2 and sp["value"] > 0
     assert sp["c4_10m_sharded"]["match_groups"] == c4["match_groups"]
+    assert sp["rccl_ranks_seen"] == 2 and sp["c4_10m_sharded"]["rccl_ranks_seen"] == 2  # the library's own ncclCommInitAll over both devices

@@ -22,7 +22,7 @@ def _bench(extra, env_extra=None):
     env = dict(os.environ, **(env_extra or {}))
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--hash-clips", "2000",
-                          "--hash-hd-clips", "0", "--c4-hashes", "60000", "--c5-cands", "3000", "--c5-refs", "300", "--dup-heavy", "0",
+                          "--hash-hd-clips", "0", "--c4-hashes", "60000", "--c5-cands", "3000", "--c5-refs", "300", "--dup-heavy", "0", "--cache-entries", "0",
                           "--no-cpu-baseline", "--no-windowed", "--no-valu", "--no-refs"] + extra,
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -41,7 +41,10 @@ def test_bench_launches_its_own_ranks():
     assert abs(two["config"]["hashes_per_gpu_shard"] * 2 - n2) <= 1
     assert two["match_groups"] == one["match_groups"] > 0
     assert two["config"]["pairs"] == one["config"]["pairs"] == n2 * (n2 - 1) // 2
-    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0
+    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0 and two["hash_summary"]["n_gpus"] == 2
+    assert two["rccl_ranks_seen"] == 0 and two["dist_backend"] == "gloo"  # (two ranks on one GPU cannot use RCCL: this run says so)
+    keys = list(two)
+    assert keys.index("c4_10m_sharded") == min(keys.index(k) for k in keys if isinstance(two[k], dict) and k not in ("config", "roofline", "hbm_operand_stream_model"))
     # the named legs: BASELINE configs[3] sharded over the ranks (strong scaling) and configs[4] end to end
     for d in (one, two):
         c4 = d["c4_10m_sharded"]

@@ -6,10 +6,11 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
+sha256sum $R/vid_dup_finder_lib_amd/libvdf_hip.so > $O/lib_sha256.txt   # which binary these counters belong to (bench.py: read_traffic)
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --c4-hashes 0 --c5-cands 0 --no-valu --no-refs"  # headline + dup_heavy + hash legs
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --c4-hashes 0 --c5-cands 0 --cache-entries 0 --no-valu --no-refs"  # headline + dup_heavy + hash legs
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/bench_under_profiler.json 2> /dev/null
-B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --c4-hashes 0 --c5-cands 0 --dup-heavy 0 --no-valu --no-refs"
+B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --c4-hashes 0 --c5-cands 0 --dup-heavy 0 --cache-entries 0 --no-valu --no-refs"
 H1="python3 $R/tools/bench_hash.py --steps 1"
 H2="python3 $R/tools/bench_hash.py --steps 1 --clips 1000 --w 1920 --h 1080"   # the bench's full_hd leg (linear-stream kernel)
 H3="python3 $R/tools/bench_hash.py --steps 1 --clips 4000 --w 480 --h 270"     # the bench's pitch_480x270 leg

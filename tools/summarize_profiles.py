@@ -65,9 +65,10 @@ for k in summary.get("fetch_search", {}):
         t["hamming_mfma2_kernel"] = traffic("fetch_search", "write_search", k, 2,
                                             "candidate tiles stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction")
 for k in summary.get("fetch_hash", {}):
-    if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):
+    if k.startswith("resize_dct_hash_persistent_kernel") or k.startswith("resize_dct_hash_fused_kernel"):  # keyed by the kernel's real name
         t[k.split("<")[0].split("(")[0]] = traffic("fetch_hash", "write_hash", k, 2,
-                                                    "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction")
+                                                    "16 B/lane streaming reads: FETCH_SIZE doubled per the gfx950 correction; "
+                                                    "launch = tools/bench_hash.py, 100 000 clips of 16 x 64 x 64")
 for tag_, fd, wd in (("resize_mfma_frame_wavestream_kernel@1920x1080", "fetch_hd", "write_hd"),
                      ("resize_mfma_frame_stream_kernel@480x270", "fetch_sd", "write_sd"),
                      ("resize_mfma_frame_ksplit_kernel@3840x2160", "fetch_uhd", "write_uhd")):
@@ -75,12 +76,19 @@ for tag_, fd, wd in (("resize_mfma_frame_wavestream_kernel@1920x1080", "fetch_hd
         if k.startswith(tag_.split("@")[0]):
             t[tag_] = traffic(fd, wd, k, 2, "frames stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction; "
                                             "launch = tools/bench_hash.py at the bench leg's shape")
-old = {}
-try:
-    old = json.load(open(os.path.join(out, "pmc_traffic.json")))
-except Exception:
-    pass
-old.update({k: v for k, v in t.items() if v})
-t = old
+# The file is rebuilt from THIS profile run only (entries of kernels that no longer exist must not linger) and records which binary
+# it belongs to: bench.py reports a traffic figure only when the library it loads has this sha256 (tools/profile_round.sh writes the
+# sha of the .so it profiled next to the counters; the in-tree file is the fallback - the same file, gpurun ships it).
+import hashlib
+
+sha = None
+sha_file = os.path.join(src, "lib_sha256.txt")
+if os.path.exists(sha_file):
+    sha = open(sha_file).read().split()[0]
+else:
+    sha = hashlib.sha256(open(os.path.join(root, "vid_dup_finder_lib_amd", "libvdf_hip.so"), "rb").read()).hexdigest()
+t = {k: v for k, v in t.items() if v}
+t["lib_sha256"] = sha
+t["profiled_with"] = f"tools/profile_round.sh -> {os.path.basename(os.path.normpath(src))} -> tools/summarize_profiles.py {tag}"
 json.dump(t, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(t, indent=1))

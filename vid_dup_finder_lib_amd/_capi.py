@@ -108,6 +108,7 @@ SIGNATURES = {
     "vdf_ctx_device_at": (C.c_int, [_ctx, C.c_int]),
     "vdf_ctx_device_search_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(VdfSearchStats)]),
     "vdf_ctx_device_search_timing": (C.c_int, [_ctx, C.c_int, C.POINTER(VdfSearchTiming)]),
+    "vdf_ctx_rccl_ranks": (C.c_int, [_ctx]),
     "vdf_ctx_destroy": (None, [_ctx]),
     "vdf_last_error": (C.c_char_p, [_ctx]),
     "vdf_version": (C.c_char_p, []),

@@ -393,6 +393,14 @@ int vdf_ctx_device_search_stats(const vdf_ctx *ctx, int k, vdf_search_stats *out
     return VDF_OK;
 }
 
+int vdf_ctx_rccl_ranks(const vdf_ctx *ctx)
+{
+    if (!ctx || !ctx->rccl) return 0;
+    int n = 0;
+    for (ncclComm_t c : ctx->rccl->comms) n += c != nullptr;
+    return n;
+}
+
 int vdf_ctx_device_search_timing(const vdf_ctx *ctx, int k, vdf_search_timing *out)
 {
     if (!ctx || !out || k < 0 || k >= device_count(ctx)) return VDF_E_INVAL;

@@ -114,6 +114,10 @@ class Engine:
         self._check(self.lib.vdf_ctx_device_search_stats(self.ctx, int(slot), C.byref(s)))
         return {k: getattr(s, k) for k, _ in VdfSearchStats._fields_}
 
+    def rccl_ranks(self) -> int:
+        """RCCL communicators (one per GPU) this context has initialised (0: every replication so far was plain device copies)."""
+        return int(self.lib.vdf_ctx_rccl_ranks(self.ctx))
+
     def device_timing(self, slot: int) -> dict:
         t = VdfSearchTiming()
         self._check(self.lib.vdf_ctx_device_search_timing(self.ctx, int(slot), C.byref(t)))
