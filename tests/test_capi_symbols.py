@@ -30,6 +30,88 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_capi.SIGNATURES) == names, "ctypes binding and header disagree"
 
 
+# ---- the Rust side of the boundary: rust/vdf-sys/src/lib.rs must say what include/vdf.h says ------------------------------------------
+_C_CLASS = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "size_t": "usize",
+            "double": "f64", "float": "f32", "long long": "i64", "unsigned long long": "u64", "char": "i8", "void": "void"}
+_RS_CLASS = {"c_int": "i32", "i32": "i32", "u32": "u32", "u64": "u64", "i64": "i64", "u8": "u8", "usize": "usize", "f64": "f64", "f32": "f32",
+             "c_longlong": "i64", "c_ulonglong": "u64", "c_char": "i8", "c_void": "void"}
+
+
+def _c_shape(ctype):
+    """('ptr' depth, scalar class or struct name) of a C type without its parameter name."""
+    depth = ctype.count("*")
+    base = " ".join(t for t in ctype.replace("*", " ").split() if t != "const")
+    return depth, _C_CLASS.get(base, base)
+
+
+def _rs_shape(rtype):
+    depth = rtype.count("*const") + rtype.count("*mut")
+    base = re.sub(r"\*(const|mut)\s*", "", rtype).strip()
+    return depth, _RS_CLASS.get(base, base)
+
+
+def _header_protos():
+    text = re.sub(r"//.*", "", re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vdf.h")).read(), flags=re.S))
+    out = {}
+    for ret, name, args in re.findall(r"^([A-Za-z_][\w\s\*]*?)\b(vdf_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.M | re.S):
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [_c_shape(re.match(r"(.*?)(\w+)$", a.strip()).group(1)) for a in args.split(",")]
+        out[name] = (params, _c_shape(ret.strip()))
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for line in m.group(2).split(";"):
+            line = " ".join(line.split())
+            if not line:
+                continue
+            if "(*" in line:
+                fields.append((re.search(r"\(\s*\*\s*(\w+)", line).group(1), "fnptr"))
+            else:
+                mm = re.match(r"(.*?)(\w+)$", line)
+                fields.append((mm.group(2), _c_shape(mm.group(1).strip())))
+        structs[m.group(3)] = fields
+    return out, structs
+
+
+def _rust_protos():
+    text = re.sub(r"//.*", "", open(os.path.join(ROOT, "rust", "vdf-sys", "src", "lib.rs")).read())
+    out = {}
+    for name, args, ret in re.findall(r"pub fn (vdf_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", text, flags=re.S):
+        args = " ".join(args.split()).rstrip(",")
+        params = [] if not args else [_rs_shape(a.split(":", 1)[1].strip()) for a in args.split(", ")]
+        out[name] = (params, _rs_shape(ret.strip()) if ret else (0, "void"))
+    structs = {}
+    for name, body in re.findall(r"#\[repr\(C\)\][^{]*?pub struct (\w+)\s*\{(.*?)\n\}", text, flags=re.S):
+        fields = []
+        for line in body.split("\n"):
+            line = line.strip().rstrip(",")
+            if not line.startswith("pub "):
+                continue
+            f, ty = line[4:].split(":", 1)
+            fields.append((f.strip(), "fnptr" if "extern" in ty else _rs_shape(ty.strip())))
+        structs[name] = fields
+    return out, structs
+
+
+def test_rust_sys_crate_declares_the_whole_header():
+    """rust/vdf-sys/src/lib.rs (what a maintainer's Rust build links against; no rustc in this image) against include/vdf.h: the same
+    functions, the same number of parameters, every parameter and return value the same scalar width / pointer depth / struct, every
+    #[repr(C)] struct field for field - and the committed file is what tools/gen_vdf_sys.py makes of the header."""
+    import subprocess
+    import sys
+
+    c_fns, c_structs = _header_protos()
+    r_fns, r_structs = _rust_protos()
+    assert sorted(c_fns) == sorted(r_fns) == _declared()
+    assert len(c_fns) >= 64
+    for name in c_fns:
+        assert c_fns[name] == r_fns[name], (name, c_fns[name], r_fns[name])
+    for name, fields in c_structs.items():
+        assert r_structs.get(name) == fields, (name, fields, r_structs.get(name))
+    assert {"vdf_cache_soa", "vdf_cache_metadata", "vdf_cache_search_timing", "vdf_search_timing", "vdf_shard_exchange"} <= set(r_structs)
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_vdf_sys.py"), "--check"]).returncode == 0
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
 

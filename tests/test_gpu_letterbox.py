@@ -334,6 +334,54 @@ def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, mo
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("chunks", ["0", "1", "5"])
+def test_large_batches_detect_in_chunks_under_the_resize(monkeypatch, chunks):
+    """A large batch of large frames is cut into chunks: every chunk's detect pass is queued on an auxiliary stream at once and the resize
+    of chunk c starts as soon as its boxes are on the host, the later chunks' walkers running under it (csrc/api.cpp:
+    letterbox_hash_device_locked; VDF_LB_CHUNKS: 0 = by batch size - four chunks here -, 1 = one detect pass in front of everything,
+    n = n chunks).  Boxes and hashes of every clip equal the oracle's whatever the cut: bars of every kind in every chunk, a black probe
+    frame, a chunk without any bar (it takes the uncropped kernels), the caller's own non-default stream, two calls in a row."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_LB_CHUNKS", chunks)
+    rng = np.random.default_rng(97)
+    h, w, n = 416, 640, 203  # 266 240 px per frame (>= 2^18) and >= 128 clips: the automatic cut applies; 203 = 4 x 51 - 1: a short last chunk
+    frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
+    for c in range(n):
+        kind = c % 5 if c < 153 else 0  # clips 153 .. 202 (the last chunk of four) have no bars at all
+        if kind == 1:
+            frames[c, :, :30 + c % 7] = 16
+            frames[c, :, h - 28:] = 17
+        elif kind == 2:
+            frames[c, :, :, :80 + 4 * (c % 3)] = 16
+            frames[c, :, :, w - 80:] = 16
+        elif kind == 3:
+            frames[c, :, :20] = 15
+            frames[c, :, :, :64] = 15
+        elif kind == 4 and c % 20 == 4:
+            frames[c, 0] = 16  # a fade-in: the probe frame is black, frame 8 decides
+    res = [orc.hash_clip_letterbox(f) for f in frames]
+    want = np.stack([r[1] for r in res])
+    want_crops = np.array([r[3] for r in res], np.uint32)
+    assert len({tuple(c) for c in want_crops}) > 10
+    eng = vdf.Engine(0)
+    try:
+        d = torch.from_numpy(frames).cuda()
+        out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            with torch.cuda.stream(side):
+                out.zero_()
+                crops = eng.hash_frames_letterbox_device(d.data_ptr(), n, 16, w, h, out.data_ptr(), stream=side.cuda_stream)
+            side.synchronize()
+            assert np.array_equal(crops, want_crops)
+            got = out.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0].tolist()
+    finally:
+        eng.close()
+
+
 def test_contexts_give_their_device_memory_back():
     """Every device buffer a context grows (the crop split's descriptor arrays, the detect work list, tables, staging, hit lists) is released
     with the context: create - hash letterboxed, pillarboxed and mixed batches - search - close, and the library's own count of live

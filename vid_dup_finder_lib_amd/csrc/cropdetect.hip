@@ -330,7 +330,10 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 // then 64 x cap entries {frame index (clip * n_probe + probe), top, bottom, left | right << 1 first-strip flags}; frame i appends to sub-list
 // i % 64, so cap = ceil(frames / 64) entries always suffice.
 constexpr uint32_t kWorkLists = 64;
-__global__ __launch_bounds__(256, 8) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
+#ifndef VDF_LB_WAVES
+#define VDF_LB_WAVES 5
+#endif
+__global__ __launch_bounds__(256, VDF_LB_WAVES) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
                                                         size_t frame_stride, size_t clip_stride, uint32_t n_probe,
                                                         uint32_t tol, uint32_t *__restrict__ crops, uint32_t *__restrict__ work)
 {
