@@ -24,8 +24,6 @@ KNOBS = [
     ({"VDF_HASH_WGS_PER_CU": "2"}, "mfma"),
     ({"VDF_HASH_WGS_PER_CU": "4"}, "mfma"),
     ({"VDF_LB_NC16": "1"}, "mfma"),
-    ({"VDF_LB_CHUNKS": "1"}, "mfma"),
-    ({"VDF_LB_CHUNKS": "3"}, "mfma"),
     ({"VDF_MFMA_CHUNK_COLS": "4096"}, "mfma"),
     ({"VDF_MFMA_CHUNK_COLS": "512"}, "mfma"),
     ({"VDF_MFMA_GROUP": "3"}, "mfma"),

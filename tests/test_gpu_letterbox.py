@@ -334,21 +334,17 @@ def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, mo
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("chunks", ["0", "1", "5"])
-def test_large_batches_detect_in_chunks_under_the_resize(monkeypatch, chunks):
-    """A large batch of large frames is cut into chunks: every chunk's detect pass is queued on an auxiliary stream at once and the resize
-    of chunk c starts as soon as its boxes are on the host, the later chunks' walkers running under it (csrc/api.cpp:
-    letterbox_hash_device_locked; VDF_LB_CHUNKS: 0 = by batch size - four chunks here -, 1 = one detect pass in front of everything,
-    n = n chunks).  Boxes and hashes of every clip equal the oracle's whatever the cut: bars of every kind in every chunk, a black probe
-    frame, a chunk without any bar (it takes the uncropped kernels), the caller's own non-default stream, two calls in a row."""
+def test_a_large_mixed_batch_of_large_frames():
+    """203 clips of 640 x 416 with bars of every kind - top / bottom, sides, a corner, none - and black probe frames (a fade-in: every strip
+    of every edge is letterbox until two walkers meet; frame 8 decides), through the two-pass detect (first strips of all four edges; then
+    four walkers per frame with bars) and the crop split, on the caller's own non-default stream, twice: boxes and hashes equal the oracle's."""
     import vid_dup_finder_lib_amd as vdf
 
-    monkeypatch.setenv("VDF_LB_CHUNKS", chunks)
     rng = np.random.default_rng(97)
-    h, w, n = 416, 640, 203  # 266 240 px per frame (>= 2^18) and >= 128 clips: the automatic cut applies; 203 = 4 x 51 - 1: a short last chunk
+    h, w, n = 416, 640, 203
     frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
     for c in range(n):
-        kind = c % 5 if c < 153 else 0  # clips 153 .. 202 (the last chunk of four) have no bars at all
+        kind = c % 5 if c < 153 else 0
         if kind == 1:
             frames[c, :, :30 + c % 7] = 16
             frames[c, :, h - 28:] = 17
@@ -359,7 +355,7 @@ def test_large_batches_detect_in_chunks_under_the_resize(monkeypatch, chunks):
             frames[c, :, :20] = 15
             frames[c, :, :, :64] = 15
         elif kind == 4 and c % 20 == 4:
-            frames[c, 0] = 16  # a fade-in: the probe frame is black, frame 8 decides
+            frames[c, 0] = 16
     res = [orc.hash_clip_letterbox(f) for f in frames]
     want = np.stack([r[1] for r in res])
     want_crops = np.array([r[3] for r in res], np.uint32)

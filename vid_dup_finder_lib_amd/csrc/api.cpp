@@ -40,10 +40,6 @@ vdf_ctx::~vdf_ctx()
     for (PinBuf &b : pin_out) b.release();
     pin_small.release();
     pin_ctrl.release();
-    pin_crops.release();
-    for (hipEvent_t e : lb_events) if (e) (void)hipEventDestroy(e);
-    if (lb_ev_in) (void)hipEventDestroy(lb_ev_in);
-    if (aux_stream) (void)hipStreamDestroy(aux_stream);
     host_hits.buf.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -916,61 +912,20 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
         return VDF_OK;
     }
     VDF_HIP(ctx, hipSetDevice(ctx->device));
-    // The detect pass reads a few per cent of the bytes but is a chain of dependent strips (a 240-column side bar: 1.1 ms per 1000 1080p
-    // clips, run ALONE in front of a 4 ms resize; one all-black probe frame: 0.3 ms of two walkers crossing a whole frame).  A large batch is
-    // therefore cut into chunks: every chunk's detect is queued on an auxiliary stream at once, and the resize of chunk c starts on the
-    // caller's stream as soon as ITS boxes are on the host - under it the later chunks' walkers run on the CUs' idle slots.
-    size_t K = 1;
-    if (ctx->lb_chunks > 1) K = std::min<size_t>((size_t)ctx->lb_chunks, n_clips);
-    else if (ctx->lb_chunks == 0 && (size_t)w * h >= (1u << 18) && n_clips >= 128) K = 4;
+    // (Cutting a large batch into chunks whose detect passes run on a second stream under the resize of the chunks before them was
+    // built and measured in round 5 - profiles/r05_letterbox_ab.txt: the resize kernels fill every CU's LDS, so the walkers only got in
+    // between the chunks, and three chunk boundaries cost more than the hidden detect time saved: 1000 pillarboxed 1080p clips 5.45 ms
+    // against 5.32.  The detect pass was made faster instead: csrc/cropdetect.hip.)
     VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
-    const size_t per_chunk = (n_clips + K - 1) / K;
-    const size_t work_bytes = (vdf::letterbox_work_bytes(per_chunk, frames_per_clip) + 255) / 256 * 256;
-    VDF_HIP(ctx, ctx->crop_work.reserve(work_bytes * K));
-    if (K == 1) {
-        VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
-                                           ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream, ctx->lb_side_strips));
-        std::vector<uint32_t> crops(n_clips * 4);
-        VDF_HIP(ctx, hipMemcpyAsync(crops.data(), ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
-        VDF_HIP(ctx, hipStreamSynchronize(stream));
-        if (out_crops) std::memcpy(out_crops, crops.data(), n_clips * 16);
-        return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops.data(),
-                                   d_out, d_dc, stream);
-    }
-    if (!ctx->aux_stream) VDF_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    if (!ctx->lb_ev_in) VDF_HIP(ctx, hipEventCreateWithFlags(&ctx->lb_ev_in, hipEventDisableTiming));
-    while (ctx->lb_events.size() < K) {
-        hipEvent_t e = nullptr;
-        VDF_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->lb_events.push_back(e);
-    }
-    if (!ctx->pin_crops.reserve(n_clips * 16)) return fail(ctx, VDF_E_OOM, "pinned staging");
-    uint32_t *h_crops = ctx->pin_crops.as<uint32_t>();
-    hipStream_t aux = ctx->aux_stream;
-    VDF_HIP(ctx, hipEventRecord(ctx->lb_ev_in, stream));  // whatever produced the frames was queued on the caller's stream
-    VDF_HIP(ctx, hipStreamWaitEvent(aux, ctx->lb_ev_in, 0));
-    auto drain = [&](int rc) { (void)hipStreamSynchronize(aux); return rc; };  // an early return must not leave walkers writing into scratch
-    for (size_t c = 0; c < K; c++) {
-        const size_t lo = std::min(c * per_chunk, n_clips), cnt = std::min(per_chunk, n_clips - lo);
-        if (cnt == 0) break;
-        uint32_t *d_c = ctx->crops.as<uint32_t>() + 4 * lo;
-        hipError_t e = vdf::launch_letterbox(d_frames + lo * clip_stride, cnt, frames_per_clip, w, h, frame_stride, clip_stride, d_c,
-                                             reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->crop_work.p) + c * work_bytes), aux, ctx->lb_side_strips);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_crops + 4 * lo, d_c, cnt * 16, hipMemcpyDeviceToHost, aux);
-        if (e == hipSuccess) e = hipEventRecord(ctx->lb_events[c], aux);
-        if (e != hipSuccess) return drain(fail_hip(ctx, e, "letterbox detect"));
-    }
-    for (size_t c = 0; c < K; c++) {
-        const size_t lo = std::min(c * per_chunk, n_clips), cnt = std::min(per_chunk, n_clips - lo);
-        if (cnt == 0) break;
-        const hipError_t e = hipEventSynchronize(ctx->lb_events[c]);
-        if (e != hipSuccess) return drain(fail_hip(ctx, e, "letterbox detect"));
-        if (out_crops) std::memcpy(out_crops + 4 * lo, h_crops + 4 * lo, cnt * 16);
-        const int rc = hash_cropped_locked(ctx, d_frames + lo * clip_stride, cnt, frames_per_clip, w, h, frame_stride, clip_stride,
-                                           h_crops + 4 * lo, d_out + lo * VDF_HASH_WORDS, d_dc ? d_dc + lo : nullptr, stream);
-        if (rc) return drain(rc);
-    }
-    return VDF_OK;
+    VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(n_clips, frames_per_clip)));
+    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
+                                       ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream, ctx->lb_side_strips));
+    std::vector<uint32_t> crops(n_clips * 4);
+    VDF_HIP(ctx, hipMemcpyAsync(crops.data(), ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    if (out_crops) std::memcpy(out_crops, crops.data(), n_clips * 16);
+    return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops.data(),
+                               d_out, d_dc, stream);
 }
 
 
@@ -1071,7 +1026,6 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     ctx->rowcrop_all = std::getenv("VDF_ROWCROP_ALL") != nullptr;
     ctx->no_boxstream = std::getenv("VDF_NO_BOXSTREAM") != nullptr;
     if (std::getenv("VDF_LB_NC16")) ctx->lb_side_strips = 16;
-    if (const char *s = std::getenv("VDF_LB_CHUNKS")) { const int v = std::atoi(s); if (v >= 0 && v <= 64) ctx->lb_chunks = v; }
     if (const char *s = std::getenv("VDF_COPY_THREADS")) { const int v = std::atoi(s); if (v >= 1 && v <= 64) ctx->copy_threads = v; }
     if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) { const long v = std::atol(s); if (v >= 1 && v <= 1024) ctx->host_chunk_bytes = (size_t)v << 20; }
     if (const char *s = std::getenv("VDF_HOST_DIRECT")) ctx->host_direct = std::atoi(s) != 0;

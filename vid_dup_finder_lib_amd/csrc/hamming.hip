@@ -550,17 +550,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     constexpr uint32_t kColStep = 32 * kSub;
     constexpr int NBLK = 2 * (int)kSub;                   // blocks per stage and wave: (sub-tile, row tile)
     constexpr int NM = NBLK * K;                          // MFMAs per stage and wave
-#ifndef VDF_M2_P
-#define VDF_M2_P 4
-#endif
-    constexpr int P = (K == 16 && WAVES >= 8) ? 2 : VDF_M2_P, NB = P + 1;  // LDS fragments in flight / fragment buffers (the full-length stream of the
+    constexpr int P = (K == 16 && WAVES >= 8) ? 2 : 4, NB = P + 1;  // LDS fragments in flight / fragment buffers (the full-length stream of the
                                                                            // 512-row workgroup - 128 registers of targets, four thresholds - has room for two)
     constexpr uint32_t kTileRows = 64 * WAVES;
     constexpr int kDmaPerWave = (int)(kColStep * 32 / (64 * WAVES));  // 1 KB LDS-DMA pieces per wave and stage
-#ifndef VDF_M2_DMA_EVERY
-#define VDF_M2_DMA_EVERY (NM / kDmaPerWave)
-#endif
-    constexpr int kDmaEvery = VDF_M2_DMA_EVERY < NM / kDmaPerWave ? VDF_M2_DMA_EVERY : NM / kDmaPerWave;  // slots between DMA pieces
+    constexpr int kDmaEvery = NM / kDmaPerWave;  // slots between DMA pieces: spread evenly over the stage
     static_assert(kDmaEvery >= 2, "stage too short for its DMA pieces");
     constexpr int kTestAt = 2;                            // the previous block's test issues under MFMAs kTestAt .. kTestAt + 3 of a block
     static_assert(K >= kTestAt + 4, "block too short to hide the previous block's test");
@@ -677,8 +671,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
     v16f acc[2] = {v16f{}, v16f{}};
     if constexpr (kRowcLds) acc[0] = rowc[0];  // the stream's first block starts from its row term (the later ones fetch theirs from LDS)
     uint32_t n_early = 0;  // blocks that stopped after K steps
-    const bool hi_half = wave >= WAVES / 2;
-    (void)hi_half;
     float thr[kSub], thr_next[kSub];
 
     // A flagged block names its suspect pairs (rare path, ~0.3 % of the blocks): per lane the mask of accumulator registers
@@ -753,16 +745,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             // scale operands 0 / 0: the compiler selects the unscaled opcode (same values as scales 2^0, probed)
             if constexpr (s == 0 && !kRowcLds) acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, rowc[rt], 4, 4, 0, 0, 0, 0);
             else acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ar, b, acc[rt], 4, 4, 0, 0, 0, 0);  // (kRowcLds: acc holds the row term at s == 0)
-#ifndef VDF_M2_ABL_NOLDS  // ablation: no LDS fragment reads in the stream (the first P fragments are reused)
             if constexpr (i + P < NM) fq[(i + P) % NB] = frag(i + P);
-#endif
-#ifdef VDF_M2_ABL_NODMA  // ablation: no LDS-DMA in the stream (every stage multiplies the first stage's image)
-#elif defined(VDF_M2_DMA_STAGGER)  // experiment: the two waves of a SIMD (w and w + WAVES / 2) issue their DMA pieces half a period apart
-            if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) { if (!hi_half) load_piece(rs_next, nxt, i / kDmaEvery); }
-            if constexpr ((i % kDmaEvery) == 1 + kDmaEvery / 2 && (i / kDmaEvery) < kDmaPerWave) { if (hi_half) load_piece(rs_next, nxt, i / kDmaEvery); }
-#else
             if constexpr ((i % kDmaEvery) == 1 && (i / kDmaEvery) < kDmaPerWave) load_piece(rs_next, nxt, i / kDmaEvery);
-#endif
             // the block that finished kTestAt MFMAs ago sits in the other accumulator set: max over its 16 registers as a
             // tree, two or three v_max3 per slot
             if constexpr (blk >= 1) {
@@ -776,9 +760,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
                 } else if constexpr (s == kTestAt + 3) {
                     if (__builtin_amdgcn_ballot_w64(fmaxf(m5, m3) >= thr[(blk - 1) >> 1]) != 0ull) {
                         flags |= 1u << (blk - 1);
-#ifndef VDF_MFMA2_NO_CLEANUP  // timing experiment only: suspects are dropped (no hits reported)
                         emit(c, thr[(blk - 1) >> 1], live[rt ^ 1], row0 + 32u * (uint32_t)(rt ^ 1), cb + 32u * (uint32_t)((blk - 1) >> 1));
-#endif
                     }
                 }
             }
@@ -798,9 +780,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             const float pm = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), c[15]));
             if (__builtin_amdgcn_ballot_w64(pm >= thr[kSub - 1]) != 0ull) {
                 flags |= 1u << (NBLK - 1);
-#ifndef VDF_MFMA2_NO_CLEANUP
                 emit(c, thr[kSub - 1], live[(NBLK - 1) & 1], row0 + 32u * (uint32_t)((NBLK - 1) & 1), cb + 32u * (kSub - 1));
-#endif
             }
         }
         // blocks of sub-tiles at or beyond the end of the chunk hold nothing
@@ -810,10 +790,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
             if (cb + 32u * sub < c_end) valid |= 3u << (2 * sub);
         flags &= valid;
         n_early += (uint32_t)__builtin_popcount(valid & ~flags);
-#ifndef VDF_M2_ABL_NOBARRIER  // ablation (with NODMA): no barrier between stages
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
         __syncthreads();  // the DMA and the threshold load have landed (every wave waited for its own) and every wave is done with `cur`
-#endif
 #pragma unroll
         for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     };
@@ -827,9 +805,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void hamming_mfma2_kernel(
         for (int s = 0; s < K; s++) asm volatile("" ::"v"(a[rt][s]));  // retire the target loads before the loop (vmcnt bookkeeping)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: the fence's vmcnt wait is the compiler's to drop (it did, in a resize kernel: DESIGN 4.3)
     __syncthreads();
-#ifdef VDF_M2_SETPRIO  // experiment: static priority for the second-dispatched half of the workgroup (waves w and w + 4 share a SIMD)
-    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(VDF_M2_SETPRIO);
-#endif
 #pragma unroll
     for (uint32_t sub = 0; sub < kSub; sub++) thr[sub] = 0.5f * (thr_next[sub] - tol_f);
     for (uint32_t cb = cb0; cb < c_end; cb += 2 * kColStep) {

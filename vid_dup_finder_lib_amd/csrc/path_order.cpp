@@ -307,7 +307,10 @@ static int path_ranks_impl(const char *paths, const uint64_t *path_offsets, size
     if (!paths || !path_offsets || !out_rank || n >= 0xFFFFFFFFull) return VDF_E_INVAL;
     for (size_t i = 0; i < n; i++)
         if (path_offsets[i + 1] < path_offsets[i]) return VDF_E_INVAL;
-    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::thread::hardware_concurrency();
+    // automatic thread count: at most 32 - measured on the 256-thread host of the GPU box at 10 M paths (profiles/r05_cache_ingest.txt):
+    // 8 threads 463 ms, 16 281, 32 209, 64 277, 256 396: beyond 32 the serial steps between the phases (sample sort, the scan over
+    // buckets x slices) and the memory system take back what the parallel phases gain
+    unsigned nt = n_threads > 0 ? (unsigned)n_threads : std::min(32u, std::thread::hardware_concurrency());
     nt = std::max(1u, std::min(nt, 256u));
     if (n < 4096) nt = 1;
     Blob B{paths, path_offsets};
@@ -347,7 +350,14 @@ static int path_ranks_impl(const char *paths, const uint64_t *path_offsets, size
         const size_t n_samples = std::min(n, n_buckets * 8);
         std::vector<uint32_t> samples(n_samples);
         for (size_t s = 0; s < n_samples; s++) samples[s] = (uint32_t)((s * n) / n_samples);
-        std::sort(samples.begin(), samples.end(), [&](uint32_t x, uint32_t y) { const int c = B.cmp(x, y); return c ? c < 0 : x < y; });
+        if (B.plain) {  // (64 k samples: a comparison sort of them on one thread was 30 ms of the call)
+            std::vector<KeyIdx> ks(n_samples);
+            for (size_t q = 0; q < n_samples; q++) ks[q] = KeyIdx{0, samples[q]};
+            keyed_sort(B, ks.data(), ks.size(), B.shared);
+            for (size_t q = 0; q < n_samples; q++) samples[q] = ks[q].idx;
+        } else {
+            std::sort(samples.begin(), samples.end(), [&](uint32_t x, uint32_t y) { const int c = B.cmp(x, y); return c ? c < 0 : x < y; });
+        }
         std::vector<uint32_t> split(n_buckets - 1);
         for (size_t k = 1; k < n_buckets; k++) split[k - 1] = samples[k * n_samples / n_buckets];
         // bucket(i) = number of splitters <= path i in (path, index) order: equal paths may straddle a splitter only by index,

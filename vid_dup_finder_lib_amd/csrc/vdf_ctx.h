@@ -162,11 +162,6 @@ struct vdf_ctx {
     int wavestream_knob = 0;       // resize_dispatch.h: -1 = VDF_NO_WAVESTREAM, n > 0 = VDF_WAVESTREAM_NW=n
     bool no_rowcrop = false, rowcrop_all = false, no_boxstream = false;  // VDF_NO_ROWCROP / VDF_ROWCROP_ALL / VDF_NO_BOXSTREAM
     int lb_side_strips = 0;        // VDF_LB_NC16: 16 = the side walk never takes the 32-strip form
-    int lb_chunks = 0;             // VDF_LB_CHUNKS: 0 = by batch size, 1 = detect the whole batch before the first resize, n = n chunks
-    hipStream_t aux_stream = nullptr;     // letterbox detect of the later chunks of a batch, under the resize of the earlier ones (made on first use)
-    std::vector<hipEvent_t> lb_events;    // "crops of chunk c are on the host"
-    hipEvent_t lb_ev_in = nullptr;        // the caller's work on its stream, which the aux stream must not overtake
-    PinBuf pin_crops;                     // detected crop boxes of a batch (downloaded chunk by chunk)
     int copy_threads = 0;          // VDF_COPY_THREADS (0: half the hardware threads, at most 8)
     size_t host_chunk_bytes = 32u << 20;  // VDF_HOST_CHUNK_MB: pinned staging chunk (x 2) of the host-frame path
     bool host_direct = true;       // VDF_HOST_DIRECT=0: packed input goes through the library's staging too
