@@ -334,6 +334,75 @@ def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, mo
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("h,w", [(1080, 1920), (300, 1001), (96, 250), (64, 64)])
+def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(engine, h, w):
+    """Round 5: a batch of strips that is ONE value per strip from end to end (what a bar is, as a rule) is accepted without a histogram -
+    the column walk remembers the first row group's bytes and counts rows while every group repeats them; four constant rows pass on their
+    loads alone.  Everything around that shortcut against the oracle: clean bars of one value, of one value PER STRIP (a gradient across
+    the bar), bars with a single blemish in the first / a middle / the last row group or in the tail bytes of a row, blemishes that add up to
+    just under and just over 10 % of a strip, noisy bars inside +-16, a bar whose rows are constant but differ from each other."""
+    rng = np.random.default_rng(h * 7 + w)
+    bar_w, bar_h = max(w // 8, 3), max(h // 9, 3)
+    cases = []
+
+    def clip(edit):
+        f = rng.integers(60, 200, size=(16, h, w), dtype=np.uint8)
+        edit(f)
+        cases.append(f)
+
+    def sides(f, v=16):
+        f[:, :, :bar_w] = v
+        f[:, :, w - bar_w:] = v
+
+    def rows(f, v=16):
+        f[:, :bar_h] = v
+        f[:, h - bar_h:] = v
+
+    clip(lambda f: sides(f))
+    clip(lambda f: rows(f))
+    clip(lambda f: (sides(f), rows(f)))
+    clip(lambda f: f.__setitem__((slice(None), slice(None), slice(0, bar_w)), np.arange(bar_w, dtype=np.uint8)[None, None, :] * 3 + 5))  # one value per column
+    clip(lambda f: f.__setitem__((slice(None), slice(0, bar_h)), (np.arange(bar_h, dtype=np.uint8) * 5 + 3)[None, :, None]))  # one value per row
+    for at in (0, h // 2, h - 1):  # a single blemish somewhere in an otherwise constant side bar: still > 90 %
+        def e(f, at=at):
+            sides(f)
+            f[:, at, bar_w // 2] = 250
+            f[:, at, w - 1] = 251
+        clip(e)
+    for at in (0, w // 2, w - 1):  # and in a top / bottom bar, incl. the last (tail) bytes of a row
+        def e(f, at=at):
+            rows(f)
+            f[:, 1, at] = 250
+            f[:, h - 1, at] = 3
+        clip(e)
+    for frac in (0.099, 0.101):  # blemishes that add up to just under / just over 10 % of the second column and of the second row
+        def e(f, frac=frac):
+            sides(f)
+            rows(f)
+            k_col = int(np.floor(h * frac)) if frac < 0.1 else int(np.ceil(h * frac))
+            k_row = int(np.floor(w * frac)) if frac < 0.1 else int(np.ceil(w * frac))
+            f[:, bar_h:bar_h + k_col, 1] = 255   # column 1: k_col pixels far from the mode
+            f[:, 1, bar_w:bar_w + k_row] = 255   # row 1
+        clip(e)
+    def noisy(f):
+        f[:, :, :bar_w] = rng.integers(8, 25, size=(16, h, bar_w), dtype=np.uint8)   # inside +-16 of any mode it can have
+        f[:, :bar_h] = rng.integers(100, 117, size=(16, bar_h, w), dtype=np.uint8)
+    clip(noisy)
+    def striped(f):  # rows constant, each with its own value: the column walk leaves the shortcut at the second row group
+        f[:, :, :bar_w] = (np.arange(h, dtype=np.uint8) % 7 + 10)[None, :, None]
+    clip(striped)
+    frames = np.stack(cases)
+    d = torch.from_numpy(frames).cuda()
+    crops = torch.zeros((len(frames), 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    engine.cropdetect_letterbox_device(d.data_ptr(), len(frames), 16, w, h, crops.data_ptr())
+    torch.cuda.synchronize()
+    got = crops.cpu().numpy().astype(np.uint32)
+    want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
+    assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    assert tuple(want[0]) == (bar_w, bar_w, 0, 0) and tuple(want[1]) == (0, 0, bar_h, bar_h)
+
+
 def test_a_large_mixed_batch_of_large_frames():
     """203 clips of 640 x 416 with bars of every kind - top / bottom, sides, a corner, none - and black probe frames (a fade-in: every strip
     of every edge is letterbox until two walkers meet; frame 8 decides), through the two-pass detect (first strips of all four edges; then

@@ -53,11 +53,11 @@ def test_no_stream_kernel_spills(isa):
     assert all(v == (0, 0, 0) for v in search.values()), {k: v for k, v in search.items() if v != (0, 0, 0)}
     resize = {k: v for k, v in sp.items() if re.search(r"resize_|dct_hash", k)}
     assert len(resize) >= 50 and all(v[0] == 0 and v[2] == 0 for v in resize.values()), {k: v for k, v in resize.items() if v[0] or v[2]}
-    # the letterbox detect: its first pass (one strip per edge, eight waves per SIMD) used to carry the four-row walk and parked 4 of its
-    # values in scratch until round 5 moved every walker into the second pass
-    detect = {k: v for k, v in sp.items() if "letterbox_" in k}
-    assert len(detect) == 4 and all(v[0] == 0 and v[2] == 0 for v in detect.values()), detect  # (SGPRs parked in VGPR lanes are not scratch traffic)
     other = {k: v for k, v in sp.items() if (v[0] or v[2]) and k not in search and k not in resize}
+    # the letterbox detect: letterbox_kernel (eight waves per SIMD, 64 registers) parked 4 values of its four-row walk in scratch until round 5
+    # made its wave index wave-uniform for the compiler (readfirstlane): the per-wave LDS addresses moved to SGPRs
+    detect = {k: v for k, v in sp.items() if "letterbox_" in k}
+    assert len(detect) == 4 and all(v[0] == 0 and v[2] == 0 for v in detect.values()), detect
     assert not other, other
 
 

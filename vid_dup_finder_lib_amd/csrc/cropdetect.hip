@@ -153,11 +153,57 @@ template <class RowAt>
 __device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_t tol, uint32_t *hist4)
 {
     const uint32_t lane = threadIdx.x & 63, n16 = len >> 4;
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
+    // A bar is, as a rule, rows of one value each.  Four such rows are letterbox by any tolerance and are accepted from their loads alone:
+    // no histogram is cleared, counted into or scanned (that chain, not the loads, was a pass's time).  Anything else - the batch where the
+    // picture begins, noisy bars - takes the general path below and reads its rows once more (from L2).
+    {
+        bool uni = true;
+        uint32_t want[4] = {0u, 0u, 0u, 0u};  // each row's first pixel in every byte, taken from the first load itself (a separate
+                                              // load of it would put one more round trip in front of every pass)
+        for (uint32_t i0 = 0; i0 < n16 && uni; i0 += 128) {
+            U4 v[4][2];  // all eight loads of the pass in flight together: one round trip to HBM
 #pragma unroll
-    for (int k = 0; k < 16; k++) hist4[lane + 64 * k] = 0u;
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t i = i0 + 64u * k + lane;
+                    v[r][k] = i < n16 ? *reinterpret_cast<const U4 *>(row(r) + 16 * (size_t)i) : U4{0, 0, 0, 0};
+                }
+            if (i0 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) want[r] = ((uint32_t)__builtin_amdgcn_readfirstlane((int)v[r][0].x) & 255u) * 0x01010101u;  // lane 0 is active: n16 >= 1 here
+            }
+            bool good = true;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const bool active = i0 + 64u * k + lane < n16;
+                    const U4 &q = v[r][k];
+                    good = good && (!active || (q.x == want[r] && q.y == want[r] && q.z == want[r] && q.w == want[r]));
+                }
+            uni = __builtin_amdgcn_ballot_w64(good) == ~0ull;
+        }
+        uni = uni && n16 != 0;  // (rows shorter than 16 pixels: the general path)
+        if (uni && (len & 15u) != 0) {  // the last len % 16 pixels of each row
+            bool good = true;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                for (uint32_t i = 16 * n16 + lane; i < len; i += 64) good = good && row(r)[i] == (uint8_t)(want[r] & 255u);
+            uni = __builtin_amdgcn_ballot_w64(good) == ~0ull;
+        }
+        if (uni) return 4;
+    }
+    {   // (the clear's addresses are made from a lane number the compiler cannot see through: hoisted out of the caller's walk loop they
+        // stayed live across it and were the one value pass 1's 64 registers had no room for)
+        uint32_t l2 = lane;
+        asm volatile("" : "+v"(l2));
+#pragma unroll
+        for (int k = 0; k < 16; k++) hist4[l2 + 64 * k] = 0u;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
     for (uint32_t i0 = 0; i0 < n16; i0 += 128) {  // two 16-byte loads per lane and row in flight, four rows
         U4 v[4][2];
 #pragma unroll
@@ -240,18 +286,24 @@ __device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_
 // the NC bytes of its row that hold columns x0 .. x0 + NC - 1 and the wave keeps NC histograms (u16 counters, two columns per LDS word:
 // H < 65536); the strips are then judged in walking order - exactly the reference's take_while, evaluated speculatively.
 // from_right: strip k of the batch is column x0 + NC - 1 - k.  Returns how many leading strips of the batch are letterbox (0 .. NC).
-// histn: NC / 2 x 256 words of this wave.  All 64 lanes must call.
+// histn: NC / 2 x kHistPitch words of this wave (the callers give NC / 2 x 256 + 64).  All 64 lanes must call.
+constexpr uint32_t kHistPitch = 257;
 template <int NC>
 __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f, uint32_t W, uint32_t H, uint32_t x0, bool from_right,
                                                   uint32_t tol, uint32_t *histn)
 {
     constexpr uint32_t HALF = NC / 2, ND = NC / 4;  // columns per counter half, dwords per row
     const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (uint32_t k = 0; k < HALF * 4; k++) histn[lane + 64 * k] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     struct __attribute__((packed, aligned(1))) UN { uint32_t d[ND]; };
+    // A bar is, as a rule, the same NC bytes in every row.  While that holds nothing is counted at all: `ref` remembers the bytes and
+    // `uniform_rows` how many rows carried them; if it holds to the last row every column is a constant - letterbox by any tolerance - and the
+    // batch is accepted without the LDS having been touched (clearing, counting into and scanning NC histograms was most of a bar batch's
+    // time).  The first row group that differs clears the histograms, credits the rows seen so far and goes on counting.
+    bool uniform = true;
+    uint32_t uniform_rows = 0;
+    UN ref;
+#pragma unroll
+    for (uint32_t j = 0; j < ND; j++) ref.d[j] = 0u;
     auto byte_of = [](const UN &v, uint32_t c) {  // (64-bit shifts and selects, not an indexed load: a lane-dependent index would put v in scratch)
         uint64_t w = (uint64_t)v.d[0] | ((uint64_t)v.d[1] << 32);
 #pragma unroll
@@ -261,9 +313,13 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
         }
         return (uint32_t)(w >> (8 * (c & 7))) & 255u;
     };
-    auto slot = [&](uint32_t c, uint32_t value) { return &histn[(c % HALF) * 256u + value]; };
-    // rows per lane in flight: 64 / 32 / 8 dwords of loads - the walk kernel has the registers (the LDS histograms set its occupancy) and a
-    // pass of a 1080-row frame is 17 rows per lane: two at a time made it nine dependent round trips to HBM
+    // A column's 256 bins are kHistPitch = 257 words apart: at 256, bin v of every column sat in ONE bank - the bars' single value made the
+    // wave's atomics 16-way conflicts and the scan below (lanes = columns) 16-way on every read: 90 % of the kernel's LDS cycles were
+    // conflict cycles (rocprofv3, round 5: SQ_LDS_BANK_CONFLICT 64.7 M of SQ_LDS_IDX_ACTIVE 71.4 M per launch on 1000 pillarboxed 1080p clips).
+    auto slot = [&](uint32_t c, uint32_t value) { return &histn[(c % HALF) * kHistPitch + value]; };
+    // rows per lane in flight: 64 / 32 / 8 dwords of loads.  The side walk is latency-bound at two waves per SIMD (62 % of the wave cycles
+    // wait; 1.1 GB per launch is only 2.3 TB/s): a pass of a 1080-row frame is 17 rows per lane, and two at a time made it nine dependent
+    // round trips to HBM.  The kernel's occupancy is set by its LDS, so the registers are there.
     constexpr int INFL = NC >= 16 ? 8 : 4;
     for (uint32_t i0 = 0; i0 < H; i0 += 64u * INFL) {
         UN v[INFL];
@@ -287,8 +343,26 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
                 first.d[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k].d[j]);
                 same = same && v[k].d[j] == first.d[j];
             }
-            if (__builtin_amdgcn_ballot_w64(active && same) == act) {
-                // every active row holds the same NC bytes (bars): lane c adds the row count to column c's bin
+            const bool all_same = __builtin_amdgcn_ballot_w64(active && same) == act;  // every active row of the group holds the same NC bytes
+            if (uniform) {
+                bool as_before = all_same;
+                if (uniform_rows != 0)
+#pragma unroll
+                    for (uint32_t j = 0; j < ND; j++) as_before = as_before && first.d[j] == ref.d[j];
+                if (as_before) {  // wave-uniform: `first` and `ref` are scalars
+                    if (uniform_rows == 0) ref = first;
+                    uniform_rows += (uint32_t)__builtin_popcountll(act);
+                    continue;
+                }
+                uniform = false;
+#pragma unroll
+                for (uint32_t q = 0; q < HALF * 4 + 1; q++) histn[lane + 64 * q] = 0u;  // HALF x kHistPitch words (+ slack inside the wave's array)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (uniform_rows != 0 && lane < (uint32_t)NC) atomicAdd(slot(lane, byte_of(ref, lane)), uniform_rows << (16 * (lane / HALF)));
+            }
+            if (all_same) {
+                // (bars with a blemish further up: lane c adds the row count to column c's bin)
                 if (lane < (uint32_t)NC) atomicAdd(slot(lane, byte_of(first, lane)), (uint32_t)__builtin_popcountll(act) << (16 * (lane / HALF)));
             } else if (active) {
 #pragma unroll 4
@@ -296,12 +370,13 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
             }
         }
     }
+    if (uniform) return (uint32_t)NC;  // every column of the batch is one value from top to bottom
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // lane = NC q + c: share q of column c's histogram (256 / (64 / NC) bins)
     constexpr uint32_t SHARES = 64 / NC, BINS = 256 / SHARES;
     const uint32_t c = lane % NC, q = lane / NC, sh = 16 * (c / HALF);
-    const uint32_t *hc = histn + (c % HALF) * 256u + BINS * q;
+    const uint32_t *hc = histn + (c % HALF) * kHistPitch + BINS * q;
     uint32_t key = 0;
 #pragma unroll 8
     for (uint32_t b = 0; b < BINS; b++) key = max(key, (((hc[b] >> sh) & 0xFFFFu) << 8) | (BINS * q + b));  // max count, ties -> the larger value
@@ -325,100 +400,56 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 }
 
 
-// Pass 1: one workgroup per probed frame, one wave per edge, ONE strip each: the first column from the left / right, the first row from the
-// top / bottom.  Most frames have no bars and are finished here - 4 KB of LDS and 64 registers, eight workgroups per SIMD row: the launch
-// rate of 40 000 small workgroups is what matters at 64 x 64.  A frame with a letterbox strip on any edge goes on the work list of pass 2.
+// Pass 1: one workgroup per probed frame.  Waves 2 / 3 walk in from the top / bottom; waves 0 / 1 judge only the FIRST column strip of their
+// side.  Most frames have no side bars and are finished here (4 KB of LDS, the launch rate of 40 000 small workgroups matters at 64 x 64).
+// A frame whose left or right first strip IS letterbox goes on the work list of pass 2 with its top / bottom result.
 // work: 64 sub-lists (one shared counter took 40 000 same-address atomics 0.6 ms when every 64 x 64 clip of a batch had side bars): counts[64],
-// then 64 x cap entries {frame index (clip * n_probe + probe), first-strip flags left | right << 1 | top << 2 | bottom << 3}; frame i appends
-// to sub-list i % 64, so cap = ceil(frames / 64) entries always suffice.
+// then 64 x cap entries {frame index (clip * n_probe + probe), top, bottom, left | right << 1 first-strip flags}; frame i appends to sub-list
+// i % 64, so cap = ceil(frames / 64) entries always suffice.
 constexpr uint32_t kWorkLists = 64;
 __global__ __launch_bounds__(256, 8) void letterbox_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
                                                         size_t frame_stride, size_t clip_stride, uint32_t n_probe,
                                                         uint32_t tol, uint32_t *__restrict__ crops, uint32_t *__restrict__ work)
 {
     __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_hist4[2][4 * 256];  // the row walkers' four-strip batches
     __shared__ uint32_t s_edge[4];
+    __shared__ uint32_t s_prog[4];  // strips each walker has confirmed so far
     const size_t clip = blockIdx.x / n_probe;
     const uint32_t probe = blockIdx.x % n_probe;  // frame 8 * probe
     const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * probe) * frame_stride;
-    const uint32_t wave = threadIdx.x >> 6;
+    // (readfirstlane: the wave index is uniform, and saying so keeps every per-wave LDS address - histograms, s_prog, s_edge - in SGPRs; as a
+    // per-lane value they cost the 64-register budget of eight waves per SIMD four VGPRs it did not have: 4 spills to scratch until round 5)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = s_hist[wave];
-    bool first;
-    if (wave == 0) first = strip_is_letterbox(f, W, H, tol, hist);
-    else if (wave == 1) first = strip_is_letterbox(f + (W - 1), W, H, tol, hist);
-    else if (wave == 2) first = strip_is_letterbox(f, 1, W, tol, hist);
-    else first = strip_is_letterbox(f + (size_t)(H - 1) * W, 1, W, tol, hist);
-    if ((threadIdx.x & 63) == 0) s_edge[wave] = first ? 1u : 0u;
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t flags = s_edge[0] | (s_edge[1] << 1) | (s_edge[2] << 2) | (s_edge[3] << 3);
-    if (flags) {
-        if (threadIdx.x == 0) {
-            const uint32_t k = blockIdx.x % kWorkLists, cap = (gridDim.x + kWorkLists - 1) / kWorkLists;
-            const uint32_t at = atomicAdd(&work[k], 1u);
-            uint32_t *e = work + kWorkLists + 2 * ((size_t)k * cap + at);
-            e[0] = blockIdx.x; e[1] = flags;
-        }
-    } else if (threadIdx.x < 4) {
-        atomicMin(&crops[clip * 4 + threadIdx.x], 0u);  // no bar on any edge of this frame: union = per-edge minimum (crop.rs:53-68)
-    }
-}
-
-// Pass 2: the frames with bars.  Persistent workgroups of four waves - the left / right / top / bottom walker of one frame at a time - take
-// entries off the work list.  Side walkers judge kColumnBatch column strips per pass, top / bottom walkers four rows; every walker stops at
-// the first strip that is not letterbox (the reference's take_while), or when the frame is decided without it: opposite walkers that meet
-// (a fade-in: uniformly black, every strip of every edge is letterbox) mean "no crop" whatever the other edges find
-// (video_frames_gray.rs:119-127), and each walker alone would go through the whole frame first - 1.5 ms for ONE such 1080p frame in a batch
-// whose other thousand clips take 0.1 ms.  The walkers publish their progress; the counts only grow, so a partial sum that reaches the
-// extent implies the final one does.  Registers are not scarce here (the LDS histograms set the occupancy), so a pass keeps all its loads
-// in flight.
-template <int kColumnBatch>
-__global__ __launch_bounds__(256) void letterbox_walk_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
-                                                             size_t frame_stride, size_t clip_stride, uint32_t n_probe,
-                                                             uint32_t tol, uint32_t *__restrict__ crops, const uint32_t *__restrict__ work,
-                                                             uint32_t n_frames)
-{
-    __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256];  // the side walkers' batches of strips
-    __shared__ uint32_t s_hist4[2][4 * 256];                 // the row walkers' four-strip batches
-    __shared__ uint32_t s_hist[4][256];                      // single strips
-    __shared__ uint32_t s_edge[4];
-    __shared__ uint32_t s_prog[4];  // strips each walker has confirmed so far
-    // workgroup b serves sub-list b % 64 from entry b / 64 in steps of gridDim.x / 64 (the grid is a multiple of 64)
-    const uint32_t wave = threadIdx.x >> 6, list = blockIdx.x % kWorkLists, cap = (n_frames + kWorkLists - 1) / kWorkLists;
-    const uint32_t n_work = work[list];
-    uint32_t *hist = s_hist[wave];
-    for (uint32_t at = blockIdx.x / kWorkLists; at < n_work; at += gridDim.x / kWorkLists) {
-        const uint32_t *e = work + kWorkLists + 2 * ((size_t)list * cap + at);
-        const uint32_t frame = e[0], first = (e[1] >> wave) & 1u;
-        const size_t clip = frame / n_probe;
-        const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * (frame % n_probe)) * frame_stride;
-        if (threadIdx.x < 4) s_prog[threadIdx.x] = (e[1] >> threadIdx.x) & 1u;
-        __syncthreads();
-        auto publish = [&](uint32_t n) {
-            if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
-        };
-        auto decided = [&]() {  // one pair of opposite walkers has met: "no crop", nothing left to find out
-            const uint32_t l = __atomic_load_n(&s_prog[0], __ATOMIC_RELAXED), r = __atomic_load_n(&s_prog[1], __ATOMIC_RELAXED);
-            const uint32_t t = __atomic_load_n(&s_prog[2], __ATOMIC_RELAXED), b = __atomic_load_n(&s_prog[3], __ATOMIC_RELAXED);
-            return __builtin_amdgcn_readfirstlane((int)((uint64_t)l + r >= W || (uint64_t)t + b >= H)) != 0;
-        };
-        uint32_t n = first;
-        if (first && wave < 2) {
-            const bool right = wave == 1;
+    // A frame whose opposite walkers meet (a fade-in: uniformly black, every strip of every edge is letterbox) means "no crop" whatever the
+    // other edges find (video_frames_gray.rs:119-127), and each walker alone would go through the whole frame first - 1.5 ms for ONE
+    // such 1080p frame in a batch whose other thousand clips take 0.1 ms.  The walkers publish their progress; once top + bottom
+    // reach H the result is fixed and they stop.  (The counts only grow, so a partial sum that reaches the extent implies the final one does.)
+    auto publish = [&](uint32_t n) {
+        if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
+    };
+    auto converged = [&]() {
+        const uint32_t t = __atomic_load_n(&s_prog[2], __ATOMIC_RELAXED), b = __atomic_load_n(&s_prog[3], __ATOMIC_RELAXED);
+        return __builtin_amdgcn_readfirstlane((int)((uint64_t)t + b >= H)) != 0;
+    };
+    uint32_t n = 0;
+    if (wave == 0) {
+        n = strip_is_letterbox(f, W, H, tol, hist) ? 1u : 0u;
+    } else if (wave == 1) {
+        n = strip_is_letterbox(f + (W - 1), W, H, tol, hist) ? 1u : 0u;
+    } else {
+        // top (wave 2) / bottom (wave 3): strip k is row k / H - 1 - k.  The first strip alone (most frames have no bar and stop here), then
+        // four at a time while a whole batch is inside the frame
+        const bool bottom = wave == 3;
+        auto strip = [&](uint32_t k) { return f + (size_t)(bottom ? H - 1 - k : k) * W; };
+        if (strip_is_letterbox(strip(0), 1, W, tol, hist)) {
+            n = 1;
+            publish(n);
             bool walking = true;
-            while (walking && n + kColumnBatch <= W && H < 65536u && !decided()) {
-                const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
-                n += got;
-                publish(n);
-                walking = got == (uint32_t)kColumnBatch;
-            }
-            if (walking)
-                while (n < W && !decided() && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) publish(++n);
-        } else if (first) {
-            // top (wave 2) / bottom (wave 3): strip k is row k / H - 1 - k, four at a time while a whole batch is inside the frame
-            const bool bottom = wave == 3;
-            auto strip = [&](uint32_t k) { return f + (size_t)(bottom ? H - 1 - k : k) * W; };
-            bool walking = true;
-            while (walking && n + 4 <= H && !decided()) {
+            while (walking && n + 4 <= H && !converged()) {
                 const uint32_t n0 = n;
                 const uint32_t got = row_strips4([&](uint32_t k) { return strip(n0 + k); }, W, tol, s_hist4[wave - 2]);
                 n += got;
@@ -426,15 +457,77 @@ __global__ __launch_bounds__(256) void letterbox_walk_kernel(const uint8_t *__re
                 walking = got == 4;
             }
             if (walking)
-                while (n < H && !decided() && strip_is_letterbox(strip(n), 1, W, tol, hist)) publish(++n);
+                while (n < H && !converged() && strip_is_letterbox(strip(n), 1, W, tol, hist)) publish(++n);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
+    __syncthreads();
+    const uint32_t l = s_edge[0], r = s_edge[1], t = s_edge[2], b = s_edge[3];
+    // side bars to walk (and the frame is not already decided: top + bottom met, or a frame of one or two columns that the first strips cover)
+    const bool deferred = (l | r) != 0 && (uint64_t)t + b < H && (uint64_t)l + r < W;
+    if (deferred) {
+        if (threadIdx.x == 0) {
+            const uint32_t k = blockIdx.x % kWorkLists, cap = (gridDim.x + kWorkLists - 1) / kWorkLists;
+            const uint32_t at = atomicAdd(&work[k], 1u);
+            uint32_t *e = work + kWorkLists + 4 * ((size_t)k * cap + at);
+            e[0] = blockIdx.x; e[1] = t; e[2] = b; e[3] = l | (r << 1);
+        }
+    } else if (threadIdx.x < 4) {
+        // video_frames_gray.rs:119-127: converging edges (e.g. a uniform frame) mean "no crop"
+        const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
+        atomicMin(&crops[clip * 4 + threadIdx.x], ok ? s_edge[threadIdx.x] : 0u);  // union = per-edge minimum
+    }
+}
+
+// Pass 2: the frames with side bars.  Persistent workgroups of two waves (left / right walker) take entries off the work list and walk
+// kColumnBatch column strips per pass; the walkers of a frame stop when left + right reach W.  Then the frame's four edges are final.
+template <int kColumnBatch>
+__global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__restrict__ frames, uint32_t W, uint32_t H,
+                                                              size_t frame_stride, size_t clip_stride, uint32_t n_probe,
+                                                              uint32_t tol, uint32_t *__restrict__ crops, const uint32_t *__restrict__ work,
+                                                              uint32_t n_frames)
+{
+    __shared__ uint32_t s_histn[2][kColumnBatch / 2 * 256 + 64];  // batches of strips (pitch kHistPitch), or one strip in the first KB
+    __shared__ uint32_t s_edge[2];
+    __shared__ uint32_t s_prog[2];
+    // workgroup b serves sub-list b % 64 from entry b / 64 in steps of gridDim.x / 64 (the grid is a multiple of 64)
+    const uint32_t wave = threadIdx.x >> 6, list = blockIdx.x % kWorkLists, cap = (n_frames + kWorkLists - 1) / kWorkLists;
+    const uint32_t n_work = work[list];
+    const bool right = wave == 1;
+    uint32_t *hist = s_histn[wave];
+    for (uint32_t at = blockIdx.x / kWorkLists; at < n_work; at += gridDim.x / kWorkLists) {
+        const uint32_t *e = work + kWorkLists + 4 * ((size_t)list * cap + at);
+        const uint32_t frame = e[0], t = e[1], b = e[2], first = (e[3] >> wave) & 1u;
+        const size_t clip = frame / n_probe;
+        const uint8_t *f = frames + clip * clip_stride + (size_t)(8 * (frame % n_probe)) * frame_stride;
+        if (threadIdx.x < 2) s_prog[threadIdx.x] = (e[3] >> threadIdx.x) & 1u;
+        __syncthreads();
+        auto publish = [&](uint32_t n) {
+            if ((threadIdx.x & 63) == 0) __atomic_store_n(&s_prog[wave], n, __ATOMIC_RELAXED);
+        };
+        auto converged = [&]() {
+            const uint32_t l = __atomic_load_n(&s_prog[0], __ATOMIC_RELAXED), r = __atomic_load_n(&s_prog[1], __ATOMIC_RELAXED);
+            return __builtin_amdgcn_readfirstlane((int)((uint64_t)l + r >= W)) != 0;
+        };
+        uint32_t n = first;
+        if (first) {
+            bool walking = true;
+            while (walking && n + kColumnBatch <= W && H < 65536u && !converged()) {
+                const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
+                n += got;
+                publish(n);
+                walking = got == (uint32_t)kColumnBatch;
+            }
+            if (walking)
+                while (n < W && !converged() && strip_is_letterbox(right ? f + (W - n - 1) : f + n, W, H, tol, hist)) publish(++n);
         }
         if ((threadIdx.x & 63) == 0) s_edge[wave] = n;
         __syncthreads();
         if (threadIdx.x < 4) {
-            // video_frames_gray.rs:119-127: converging edges (e.g. a uniform frame) mean "no crop"
-            const uint32_t l = s_edge[0], r = s_edge[1], t = s_edge[2], b = s_edge[3];
+            const uint32_t l = s_edge[0], r = s_edge[1];
+            const uint32_t edge[4] = {l, r, t, b};
             const bool ok = (long long)W - l - r >= 1 && (long long)H - t - b >= 1;
-            atomicMin(&crops[clip * 4 + threadIdx.x], ok ? s_edge[threadIdx.x] : 0u);  // union = per-edge minimum
+            atomicMin(&crops[clip * 4 + threadIdx.x], ok ? edge[threadIdx.x] : 0u);
         }
         __syncthreads();  // s_edge / s_prog are rewritten for the next entry
     }
@@ -444,7 +537,7 @@ size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip)
 {
     const uint32_t nf = frames_per_clip < VDF_DCT_SIZE ? frames_per_clip : VDF_DCT_SIZE;
     const size_t frames = n_clips * ((nf + 7) / 8), cap = (frames + kWorkLists - 1) / kWorkLists;
-    return (kWorkLists + 2 * kWorkLists * cap) * sizeof(uint32_t);
+    return (kWorkLists + 4 * kWorkLists * cap) * sizeof(uint32_t);
 }
 
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
@@ -462,22 +555,22 @@ hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t fram
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // Column strips per pass: 32 for tall frames (44 KB of LDS per workgroup: three per CU), 16 from 256 rows; small frames, where a strip
-    // is a handful of loads and the fixed work per pass (clearing and scanning the histograms) dominates, take eight (those two: four
-    // workgroups per CU by registers).  An empty work list costs one pass of trivial workgroups.
+    // Sixteen strips per pass (16 KB of LDS per workgroup, nine per CU); small frames, where a strip is a handful of loads and the
+    // fixed work per pass (clearing and scanning the histograms) dominates, take eight (twice the workgroups per CU: 64 x 64 x 20 000 clips
+    // with side bars 0.86 -> 0.45 ms).  An empty work list costs one pass of trivial workgroups.
     const uint32_t n_frames = (uint32_t)(n_clips * n_probe);
     auto grid_for = [&](uint32_t per_cu) {  // a multiple of 64 (the sub-lists), no more than the frames can fill
         const size_t want = std::min<size_t>(n_frames, (size_t)cus * per_cu);
         return (uint32_t)((want + kWorkLists - 1) / kWorkLists * kWorkLists);
     };
     if (h >= 512 && side_strips != 16)
-        hipLaunchKernelGGL(letterbox_walk_kernel<32>, dim3(grid_for(3)), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+        hipLaunchKernelGGL(letterbox_sides_kernel<32>, dim3(grid_for(4)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
                            work, n_frames);
     else if (h >= 256)
-        hipLaunchKernelGGL(letterbox_walk_kernel<16>, dim3(grid_for(4)), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+        hipLaunchKernelGGL(letterbox_sides_kernel<16>, dim3(grid_for(9)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
                            work, n_frames);
     else
-        hipLaunchKernelGGL(letterbox_walk_kernel<8>, dim3(grid_for(4)), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
+        hipLaunchKernelGGL(letterbox_sides_kernel<8>, dim3(grid_for(16)), dim3(128), 0, stream, frames, w, h, frame_stride, clip_stride, n_probe, 16u, crops,
                            work, n_frames);
     return hipGetLastError();
 }
