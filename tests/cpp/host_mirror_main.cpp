@@ -2,6 +2,8 @@
 //   selftest                      no GPU: Path ordering, MatchGroup contract, Hamming axioms
 //   search <file> <tolerance>     GPU: prints one group per line (duplicate paths, tab separated)
 //   refs <file> <n_ref> <tol>     GPU: first n_ref entries are the references
+//   cache <cache.bin> <tol> <cand prefix> <ref prefix | ->   GPU: the app's search_disk on a cache FILE (bincode bytes): entries whose path starts
+//                                 with the prefixes are the candidates / references; prints "key<TAB>reference or -<TAB>duplicates..."
 // File format: u64 n, then n x {16 x u64 hash, u32 duration, u32 path_len, path bytes}.
 #include <cassert>
 #include <cstdio>
@@ -65,6 +67,27 @@ static int selftest()
     threw = false;
     try { vdf::VideoHash::from_frames({}, 16, 16, "p", 1); } catch (const vdf::Error &err) { threw = err.kind == vdf::Error::NotEnoughFrames; }
     assert(threw);
+    // the sidecar (cache_metadata.rs; video_hash_filesystem_cache.rs:76-139): host only
+    auto md = vdf::CacheMetadata::make(VDF_CROPDETECT_LETTERBOX, 15.0);
+    assert(md.to_disk_fmt() == "Unix,FfmpegBackend,Letterbox,15,1");
+    vdf::CacheMetadata::try_parse(md.to_disk_fmt()).validate(VDF_CROPDETECT_LETTERBOX, 15.0);
+    std::string msg;
+    try { vdf::CacheMetadata::try_parse("Unix,FfmpegBackend,None,15,1").validate(VDF_CROPDETECT_LETTERBOX, 15.0); } catch (const vdf::MetadataError &err) { msg = err.what(); }
+    assert(msg == "crop mismatch: Act: None, Exp: Letterbox");
+    msg.clear();
+    try { vdf::CacheMetadata::try_parse("Unix,FfmpegBackend,letterbox,15,1"); } catch (const vdf::MetadataError &err) { msg = err.what(); }
+    assert(msg.find("Could not parse crop") == 0);
+    assert(*vdf::metadata_path("/home/u/.cache/vdf/cache.bin") == "/home/u/.cache/vdf/cache.metadata.txt" && *vdf::metadata_path("d//c.tar.gz") == "d/c.tar.metadata.txt");
+    assert(!vdf::metadata_path("..") && !vdf::metadata_path("/"));
+    // a cache file's bytes -> arrays (host only): count 1, key "a/b", mtime (7 s, 9 ns), Ok, 16 words, src_path "a/b", duration 42
+    std::string bytes("\x01\x03" "a/b" "\x07\x09\x00", 8);
+    for (int i = 0; i < 16; i++) bytes += (char)(i + 1);
+    bytes += std::string("\x03" "a/b" "\x2a", 5);
+    auto cache = vdf::Cache::from_bytes(bytes.data(), bytes.size());
+    assert(cache.len() == 1 && cache.path(0) == "a/b" && cache.duration(0) == 42 && cache.soa().hashes[15] == 16 && cache.soa().mtime_secs[0] == 7);
+    threw = false;
+    try { vdf::Cache::from_bytes(bytes.data(), bytes.size() - 1); } catch (const vdf::Error &) { threw = true; }
+    assert(threw);
     std::puts("selftest ok");
     return 0;
 }
@@ -83,6 +106,22 @@ int main(int argc, char **argv)
         print_groups(vdf::search_with_references(refs, news, std::atof(argv[4])));
         return 0;
     }
-    std::fprintf(stderr, "usage: selftest | search <file> <tol> | refs <file> <n_ref> <tol>\n");
+    if (argc >= 6 && !std::strcmp(argv[1], "cache")) {
+        std::ifstream f(argv[2], std::ios::binary);
+        const std::string bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const auto cache = vdf::Cache::from_bytes(bytes.data(), bytes.size());
+        const std::string cp = argv[4], rp = argv[5];
+        std::vector<uint32_t> keys;
+        const auto groups = vdf::search_cache(
+            cache, std::atof(argv[3]), [&](const std::string &p) { return p.rfind(cp, 0) == 0; },
+            [&](const std::string &p) { return rp != "-" && p.rfind(rp, 0) == 0; }, &keys);
+        for (size_t g = 0; g < groups.size(); g++) {
+            std::cout << keys[g] << '\t' << (groups[g].reference() ? *groups[g].reference() : std::string("-"));
+            for (const auto &p : groups[g].duplicates()) std::cout << '\t' << p;
+            std::cout << '\n';
+        }
+        return 0;
+    }
+    std::fprintf(stderr, "usage: selftest | search <file> <tol> | refs <file> <n_ref> <tol> | cache <cache.bin> <tol> <cand prefix> <ref prefix | ->\n");
     return 2;
 }

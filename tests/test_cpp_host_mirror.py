@@ -66,3 +66,43 @@ def test_cpp_search_matches_oracle(tmp_path, devices, monkeypatch):
     assert out.returncode == 0, out.stderr
     want = orc.search_with_references(words[:60], dur[:60], paths[:60], words[60:], dur[60:], paths[60:], 0.2)
     assert [(g[0], g[1:]) for g in _parse(out.stdout)] == [(r, m) for r, m in want]
+
+
+@pytest.mark.gpu
+def test_cpp_search_disk_on_a_cache_file(tmp_path):
+    """The app's side from compiled C++ (host/vdf.hpp: Cache, search_cache - what rust/vdf-app/src/search_disk.rs is in Rust): the bytes of a
+    cache FILE -> SoA -> filename filters as index lists -> vdf_search_cache_entries -> MatchGroups of paths, with SearchOutput::sort's
+    Sorting::Distance key per group from the same call (app_fns.rs:428-482, search_output.rs:43-60).  Find-all and with-refs, against the oracle
+    on the selected entries and a brute-force key."""
+    from vid_dup_finder_lib_amd import cache as vc
+
+    exe = _build()
+    rng = np.random.default_rng(7)
+    words, dur = hg.planted_set(rng, 1200, n_clusters=40, durations="windowed")
+    paths = [("/lib/new/" if i % 3 else "/lib/ref/") + f"d{int(rng.integers(0, 4))}/v{i}.mkv" for i in range(len(dur))]
+    perm = rng.permutation(len(dur))  # a cache file holds its entries in HashMap order
+    words, dur, paths = words[perm], dur[perm], [paths[i] for i in perm]
+    f = tmp_path / "cache.bin"
+    f.write_bytes(vc.encode_cache(words, dur, paths))
+    where = {p: i for i, p in enumerate(paths)}
+
+    def key(group_paths):
+        idx = [where[p] for p in group_paths]
+        return max(orc.hamming(words[a], words[b]) for k, a in enumerate(idx) for b in idx[k + 1:])
+
+    # find-all over everything under /lib
+    out = subprocess.run([exe, "cache", str(f), "0.35", "/lib/", "-"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = _parse(out.stdout)
+    want = orc.search(words, dur, paths, 0.35)
+    assert [r[2:] for r in rows] == want and len(want) > 10 and all(r[1] == "-" for r in rows)
+    assert [int(r[0]) for r in rows] == [key(g) for g in want]
+    # with-refs: /lib/ref/ entries are the references, /lib/new/ the candidates
+    out = subprocess.run([exe, "cache", str(f), "0.3", "/lib/new/", "/lib/ref/"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = _parse(out.stdout)
+    ri = [i for i, p in enumerate(paths) if p.startswith("/lib/ref/")]
+    ci = [i for i, p in enumerate(paths) if p.startswith("/lib/new/")]
+    want = orc.search_with_references(words[ri], dur[ri], [paths[i] for i in ri], words[ci], dur[ci], [paths[i] for i in ci], 0.3)
+    assert [(r[1], r[2:]) for r in rows] == [(r, m) for r, m in want] and len(want) > 5
+    assert [int(r[0]) for r in rows] == [key(m + [r]) for r, m in want]

@@ -266,4 +266,111 @@ inline std::vector<MatchGroup> search_with_references(const std::vector<VideoHas
     return out;
 }
 
+// ---- the app's side of the path: its hash cache, the sidecar, search_disk, the distance key -------------------
+// vid_dup_finder_app/src/video_hash_filesystem_cache/generic_filesystem_cache/base_fs_cache.rs:167-223 (load), cache_metadata.rs:45-168,
+// video_hash_filesystem_cache.rs:76-139 (sidecar), app/app_fns.rs:428-482 (search_disk), app/search_output.rs:43-60 (Sorting::Distance).
+
+// The loaded cache as arrays: no object per entry.  Entries that held Err(..) are counted (n_err) and absent.
+class Cache {
+public:
+    // load_cache_from_disk (bincode backend): malformed bytes are the original's Deserialization error
+    static Cache from_bytes(const void *data, size_t len)
+    {
+        Cache c;
+        if (vdf_cache_decode(static_cast<const uint8_t *>(data), len, &c.soa_) != VDF_OK) throw Error(Error::VidProc, "cache file does not deserialize");
+        return c;
+    }
+    Cache(Cache &&o) noexcept : soa_(o.soa_) { o.soa_ = vdf_cache_soa{}; }
+    Cache &operator=(Cache &&o) noexcept { if (this != &o) { vdf_cache_free(&soa_); soa_ = o.soa_; o.soa_ = vdf_cache_soa{}; } return *this; }
+    Cache(const Cache &) = delete;
+    Cache &operator=(const Cache &) = delete;
+    ~Cache() { vdf_cache_free(&soa_); }
+    size_t len() const { return (size_t)soa_.n_ok; }
+    uint64_t n_err() const { return soa_.n_err; }
+    std::string path(size_t i) const { return std::string(soa_.paths + soa_.path_offsets[i], (size_t)(soa_.path_offsets[i + 1] - soa_.path_offsets[i])); }
+    uint32_t duration(size_t i) const { return soa_.durations[i]; }
+    const vdf_cache_soa &soa() const { return soa_; }
+
+private:
+    Cache() = default;
+    vdf_cache_soa soa_{};
+};
+
+// search_disk's middle: `includes_cand` / `includes_ref` are the --files / --with-refs filename filters; no reference passes its filter =>
+// find-all search (app_fns.rs:474-478).  One library call: PathBuf ranks, upload, Search::sort on the device, the search, map back.
+// keys (optional): SearchOutput::sort's Sorting::Distance key of every group, from the same call's groups (vdf_groups_max_distance).
+template <class FC, class FR>
+inline std::vector<MatchGroup> search_cache(const Cache &cache, double tolerance, FC includes_cand, FR includes_ref,
+                                            std::vector<uint32_t> *keys = nullptr, Context &ctx = Context::default_context())
+{
+    std::vector<uint64_t> cand, refs;
+    for (size_t i = 0; i < cache.len(); i++) {
+        const std::string p = cache.path(i);
+        if (includes_cand(p)) cand.push_back(i);
+        if (includes_ref(p)) refs.push_back(i);
+    }
+    std::vector<MatchGroup> out;
+    if (cand.empty()) return out;  // "No files were found at the paths given by --files"
+    const vdf_cache_soa &a = cache.soa();
+    detail::Groups gr;
+    if (vdf_search_cache_entries(ctx.get(), a.hashes, a.durations, a.path_offsets, a.paths, cache.len(), cand.data(), cand.size(),
+                                 refs.empty() ? nullptr : refs.data(), refs.size(), vdf_tolerance_int(tolerance), &gr.g, nullptr) != VDF_OK)
+        throw Error(Error::Device, vdf_last_error(ctx.get()));
+    std::vector<uint32_t> all_keys((size_t)gr.g.n_groups, 0u);
+    if (keys && gr.g.n_groups &&
+        vdf_groups_max_distance(ctx.get(), a.hashes, cache.len(), a.hashes, cache.len(), &gr.g, all_keys.data()) != VDF_OK)
+        throw Error(Error::Device, vdf_last_error(ctx.get()));
+    if (keys) keys->clear();
+    for (uint64_t g = 0; g < gr.g.n_groups; g++) {
+        std::vector<std::string> paths;
+        for (uint64_t k = gr.g.offsets[g]; k < gr.g.offsets[g + 1]; k++) paths.push_back(cache.path((size_t)gr.g.members[k]));
+        if (gr.g.ref_index[g] >= 0) out.push_back(MatchGroup::make_with_reference(cache.path((size_t)gr.g.ref_index[g]), std::move(paths)));
+        else if (paths.size() >= 2) out.push_back(MatchGroup::make(std::move(paths)));
+        else continue;
+        if (keys) keys->push_back(all_keys[(size_t)g]);
+    }
+    return out;
+}
+
+// VdfCacheMetadata (cache_metadata.rs:45-51) and the sidecar's name; MetadataError carries the app's own message
+struct MetadataError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct CacheMetadata {
+    vdf_cache_metadata m{};
+    static CacheMetadata make(int32_t crop, double skip_forward_amount)  // VdfCacheMetadata::new: Unix, FfmpegBackend, version 1
+    {
+        CacheMetadata x;
+        if (vdf_cache_metadata_new(crop, skip_forward_amount, &x.m) != VDF_OK) throw MetadataError("bad cropdetect");
+        return x;
+    }
+    std::string to_disk_fmt() const
+    {
+        char buf[512];
+        size_t n = 0;
+        if (vdf_cache_metadata_format(&m, buf, sizeof buf, &n) != VDF_OK) throw MetadataError("metadata fields out of range");
+        return std::string(buf, n);
+    }
+    static CacheMetadata try_parse(const std::string &text)
+    {
+        CacheMetadata x;
+        char err[1024] = {0};
+        if (vdf_cache_metadata_parse(text.data(), text.size(), &x.m, err, sizeof err) != VDF_OK) throw MetadataError(err);
+        return x;
+    }
+    void validate(int32_t exp_crop, double exp_skip_forward_amount) const
+    {
+        char err[1024] = {0};
+        if (vdf_cache_metadata_validate(&m, exp_crop, exp_skip_forward_amount, err, sizeof err) != VDF_OK) throw MetadataError(err);
+    }
+};
+inline std::optional<std::string> metadata_path(const std::string &cache_path)  // file_stem + with_file_name; nullopt = no file name (EINVAL in the app)
+{
+    std::string buf(cache_path.size() + 32, '\0');
+    size_t n = 0;
+    if (vdf_cache_metadata_path(cache_path.data(), cache_path.size(), buf.data(), buf.size(), &n) != VDF_OK) return std::nullopt;
+    buf.resize(n);
+    return buf;
+}
+
 }  // namespace vdf
