@@ -161,14 +161,16 @@ __device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_
         bool uni = true;
         uint32_t want[4] = {0u, 0u, 0u, 0u};  // each row's first pixel in every byte, taken from the first load itself (a separate
                                               // load of it would put one more round trip in front of every pass)
-        for (uint32_t i0 = 0; i0 < n16 && uni; i0 += 128) {
+        for (uint32_t i0 = 0; i0 < n16 && uni; i0 += 128) {  // (n16 >= 1 inside)
             U4 v[4][2];  // all eight loads of the pass in flight together: one round trip to HBM
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const uint32_t i = i0 + 64u * k + lane;
-                    v[r][k] = i < n16 ? *reinterpret_cast<const U4 *>(row(r) + 16 * (size_t)i) : U4{0, 0, 0, 0};
+                    // (UNCONDITIONAL loads at a clamped index: a `valid ? load : 0` here became a branch around every load with a full
+                    // vmcnt(0) wait behind it - eight serial round trips per pass, and the black-frame walk half as fast as without the check)
+                    const uint32_t i = min(i0 + 64u * k + lane, n16 - 1);
+                    v[r][k] = *reinterpret_cast<const U4 *>(row(r) + 16 * (size_t)i);
                 }
             if (i0 == 0) {
 #pragma unroll
@@ -179,9 +181,8 @@ __device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const bool active = i0 + 64u * k + lane < n16;
-                    const U4 &q = v[r][k];
-                    good = good && (!active || (q.x == want[r] && q.y == want[r] && q.z == want[r] && q.w == want[r]));
+                    const U4 &q = v[r][k];  // (a clamped lane re-checks the row's last 16 pixels: harmless)
+                    good = good & ((((q.x ^ want[r]) | (q.y ^ want[r])) | ((q.z ^ want[r]) | (q.w ^ want[r]))) == 0u);  // (no short circuit: no branches between the loads)
                 }
             uni = __builtin_amdgcn_ballot_w64(good) == ~0ull;
         }
