@@ -15,6 +15,9 @@ H1="python3 $R/tools/bench_hash.py --steps 1"
 H2="python3 $R/tools/bench_hash.py --steps 1 --clips 1000 --w 1920 --h 1080"   # the bench's full_hd leg (linear-stream kernel)
 H3="python3 $R/tools/bench_hash.py --steps 1 --clips 4000 --w 480 --h 270"     # the bench's pitch_480x270 leg
 H4="python3 $R/tools/bench_hash.py --steps 1 --clips 250 --w 3840 --h 2160"    # the bench's uhd_3840x2160 leg (K-split kernel)
+# the headline alone (3 timed + 2 warm-up launches of ONE kernel shape): its rocprofv3 average is the figure bench.py's roofline.kernel_ms must agree with
+B3="python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --hash-clips 0 --no-windowed --c4-hashes 0 --c5-cands 0 --dup-heavy 0 --cache-entries 0 --no-valu --no-refs"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_headline -- $B3 > $O/bench_headline_under_profiler.json 2> /dev/null
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_search -- $B1 > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_hash -- $H1 > /dev/null 2>&1

@@ -22,6 +22,15 @@ if stats:
     keep = [rows[0]] + [r for r in rows[1:] if "vdf::" in r[0]]
     with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f).writerows(keep)
+stats_h = glob.glob(os.path.join(src, "kt_headline", "*", "*_kernel_stats.csv"))
+if stats_h:  # the headline's kernels alone: one launch shape per kernel, so AverageNs is the per-launch time
+    rows = list(csv.reader(open(stats_h[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if "vdf::" in r[0]]
+    with open(os.path.join(out, f"{tag}_kernel_stats_headline.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
+bh = os.path.join(src, "bench_headline_under_profiler.json")
+if os.path.exists(bh) and os.path.getsize(bh):
+    open(os.path.join(out, f"{tag}_bench_headline_under_profiler.json"), "w").write(open(bh).read())
 bj = os.path.join(src, "bench_under_profiler.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     open(os.path.join(out, f"{tag}_bench_under_profiler.json"), "w").write(open(bj).read())
