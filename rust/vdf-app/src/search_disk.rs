@@ -1,7 +1,7 @@
 //! Seam in `vid_dup_finder_app/src/app/app_fns.rs:428-482` (`search_disk`): from the loaded hash cache to MatchGroups in ONE library
 //! call.  Uncompiled in the engine repository (no Rust toolchain there); the C side of every call below is exercised by
 //! tests/test_cache_ingest.py through ctypes and measured by bench.py's `cache_ingest` leg (profiles/r05_cache_ingest.txt:
-//! 10 M entries - decode 35 ms, PathBuf ranks 0.37 s, upload + device sort 33 ms, then the search itself).
+//! 10 M entries - decode 31-35 ms, PathBuf ranks 0.26-0.29 s, upload + device sort 34 ms, then the search itself).
 //!
 //! What the original does per search: `all_cached_paths()` -> two filename filters -> `cache.fetch(p)` (a clone of one `VideoHash`
 //! per selected path) -> `search()` / `search_with_references()`, whose `Search::new` sorts by `(duration, src_path.to_owned())`
