@@ -361,6 +361,16 @@ def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(e
     clip(lambda f: sides(f))
     clip(lambda f: rows(f))
     clip(lambda f: (sides(f), rows(f)))
+    def very_wide(f):  # bars of 0.4 w: several wide probes (columns_uniform) in a row, then counted batches, then single strips
+        bw = int(w * 0.4)
+        f[:, :, :bw] = 17
+        f[:, :, w - bw + 3:] = 17
+    clip(very_wide)
+    def wide_with_a_late_blemish(f):  # clean for the first probe, one odd pixel inside the second: the walk must go on counting from there
+        bw = int(w * 0.4)
+        f[:, :, :bw] = 17
+        f[:, h - 1, min(bw - 2, 5 * (w // 32) + 3)] = 200
+    clip(wide_with_a_late_blemish)
     clip(lambda f: f.__setitem__((slice(None), slice(None), slice(0, bar_w)), np.arange(bar_w, dtype=np.uint8)[None, None, :] * 3 + 5))  # one value per column
     clip(lambda f: f.__setitem__((slice(None), slice(0, bar_h)), (np.arange(bar_h, dtype=np.uint8) * 5 + 3)[None, :, None]))  # one value per row
     for at in (0, h // 2, h - 1):  # a single blemish somewhere in an otherwise constant side bar: still > 90 %
