@@ -413,6 +413,50 @@ def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(e
     assert tuple(want[0]) == (bar_w, bar_w, 0, 0) and tuple(want[1]) == (0, 0, bar_h, bar_h)
 
 
+@pytest.mark.parametrize("h,w,offset", [(512, 640, 0), (540, 1920, 0), (512, 640, 64), (512, 576, 0), (520, 704, 32)])
+def test_clean_side_bars_are_probed_in_aligned_windows(engine, h, w, offset):
+    """Round 5: the side walk of frames from 512 rows on probes clean bars in ALIGNED windows of 128, then 64 bytes (columns_uniform: whole
+    cache lines / sectors, read once) before it falls back to the counted 32-column batches - the walk is bound by HBM transactions.  Bar
+    widths on both sides of every window boundary, different left and right, a bar that is clean only up to a boundary, a gradient bar
+    (constant columns of different values), a noisy bar (every probe fails at once), a frame whose rows are all equal (every column constant:
+    left and right meet, "no crop"), frame widths that are multiples of 128, of 64 only and of neither, and a buffer whose frames start off
+    a line boundary: boxes equal the oracle's."""
+    rng = np.random.default_rng(h + w + offset)
+    widths = [1, 2, 31, 33, 63, 64, 65, 96, 127, 128, 129, 160, 191, 192, 193, 255, 256, 257]
+    cases = []
+    for k, bw in enumerate(widths):
+        f = rng.integers(60, 200, size=(16, h, w), dtype=np.uint8)
+        f[:, :, :bw] = 16
+        f[:, :, w - widths[(k * 7 + 3) % len(widths)]:] = 18
+        cases.append(f)
+    f = rng.integers(60, 200, size=(16, h, w), dtype=np.uint8)  # clean up to column 128, then a bar with one odd pixel per column block
+    f[:, :, :200] = 16
+    f[:, 7, 130] = 99
+    f[:, h - 3, 170] = 99
+    cases.append(f)
+    f = rng.integers(60, 200, size=(16, h, w), dtype=np.uint8)  # gradient bar
+    f[:, :, :150] = (np.arange(150, dtype=np.uint8) + 3)[None, None, :]
+    cases.append(f)
+    f = rng.integers(60, 200, size=(16, h, w), dtype=np.uint8)  # noisy bars inside +-16
+    f[:, :, :140] = rng.integers(10, 24, size=(16, h, 140), dtype=np.uint8)
+    f[:, :, w - 70:] = rng.integers(10, 24, size=(16, h, 70), dtype=np.uint8)
+    cases.append(f)
+    row = rng.integers(60, 200, size=(1, 1, w), dtype=np.uint8)  # all rows equal: every column is constant
+    cases.append(np.broadcast_to(row, (16, h, w)).copy())
+    frames = np.stack(cases)
+    n = len(frames)
+    buf = torch.zeros(n * 16 * h * w + 256, dtype=torch.uint8, device="cuda")
+    buf[offset:offset + frames.size] = torch.from_numpy(frames).cuda().reshape(-1)
+    crops = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    engine.cropdetect_letterbox_device(buf.data_ptr() + offset, n, 16, w, h, crops.data_ptr())
+    torch.cuda.synchronize()
+    got = crops.cpu().numpy().astype(np.uint32)
+    want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
+    assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    assert tuple(want[widths.index(128)][:1]) == (128,) and tuple(want[-1]) == (0, 0, 0, 0)
+
+
 def test_a_large_mixed_batch_of_large_frames():
     """203 clips of 640 x 416 with bars of every kind - top / bottom, sides, a corner, none - and black probe frames (a fade-in: every strip
     of every edge is letterbox until two walkers meet; frame 8 decides), through the two-pass detect (first strips of all four edges; then

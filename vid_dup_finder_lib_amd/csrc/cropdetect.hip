@@ -401,6 +401,50 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 }
 
 
+// True iff every row of the frame holds the same WB bytes at columns x0 .. x0 + WB - 1: each of those columns is one value from top to bottom,
+// i.e. WB letterbox strips by any tolerance (a clean bar).  No LDS, no counting - registers only.  What it is for is BYTES: the side walk
+// is bound by HBM transactions, not by its round trips (rocprofv3, round 5: 43 M L2 misses of 64 B per launch on 1000 pillarboxed 1080p
+// clips = 2.8 GB at 3.5 TB/s of scattered 64-byte reads, for 1.1 GB of columns: a 32-byte batch fetches a 64-byte sector, and the batch
+// next to it fetches the same sector again later).  A probe at a 128- or 64-byte ALIGNED window reads whole lines / sectors once.
+// All 64 lanes must call.
+template <int WB>
+__device__ __forceinline__ bool columns_uniform(const uint8_t *__restrict__ f, uint32_t W, uint32_t H, uint32_t x0)
+{
+    constexpr uint32_t ND = WB / 4;
+    const uint32_t lane = threadIdx.x & 63;
+    constexpr int INFL = WB >= 128 ? 4 : 8;  // rows per lane in flight (128 dwords of loads either way)
+    uint32_t ref[ND];                        // row 0's bytes (scalars)
+#pragma unroll
+    for (uint32_t j = 0; j < ND; j++) ref[j] = 0u;
+    for (uint32_t i0 = 0; i0 < H; i0 += 64u * INFL) {
+        uint4 v[INFL][ND / 4];
+#pragma unroll
+        for (int k = 0; k < INFL; k++) {  // unconditional, aligned 16-byte loads at a clamped row (a clamped lane re-checks the last row)
+            const uint32_t row = min(i0 + 64u * k + lane, H - 1);
+            const uint4 *src = reinterpret_cast<const uint4 *>(f + (size_t)row * W + x0);
+#pragma unroll
+            for (uint32_t j = 0; j < ND / 4; j++) v[k][j] = src[j];
+        }
+        if (i0 == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < ND / 4; j++) {  // lane 0, k = 0: row 0
+                ref[4 * j + 0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].x);
+                ref[4 * j + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].y);
+                ref[4 * j + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].z);
+                ref[4 * j + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].w);
+            }
+        }
+        uint32_t diff = 0;
+#pragma unroll
+        for (int k = 0; k < INFL; k++)
+#pragma unroll
+            for (uint32_t j = 0; j < ND / 4; j++)
+                diff |= (v[k][j].x ^ ref[4 * j]) | (v[k][j].y ^ ref[4 * j + 1]) | (v[k][j].z ^ ref[4 * j + 2]) | (v[k][j].w ^ ref[4 * j + 3]);
+        if (__builtin_amdgcn_ballot_w64(diff == 0u) != ~0ull) return false;  // wave-uniform
+    }
+    return true;
+}
+
 // Pass 1: one workgroup per probed frame.  Waves 2 / 3 walk in from the top / bottom; waves 0 / 1 judge only the FIRST column strip of their
 // side.  Most frames have no side bars and are finished here (4 KB of LDS, the launch rate of 40 000 small workgroups matters at 64 x 64).
 // A frame whose left or right first strip IS letterbox goes on the work list of pass 2 with its top / bottom result.
@@ -513,7 +557,24 @@ __global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__r
         uint32_t n = first;
         if (first) {
             bool walking = true;
+            // Aligned probes for clean bars (columns_uniform), where rows and frame are line-aligned: a window of 128 bytes, after its first
+            // failure 64, after that the counted 32-column batches for good.  The window that holds strip n starts at or before it: the strips
+            // in front of n inside it were accepted already, and if they are not constant columns (a noisy bar) the probe just fails.
+            const uint32_t align = (uint32_t)(reinterpret_cast<uintptr_t>(f) | W);  // rows start where the frame does, W bytes apart
+            uint32_t probe = kColumnBatch != 32 ? 0u : (align & 127u) == 0 ? 128u : (align & 63u) == 0 ? 64u : 0u;
             while (walking && n + kColumnBatch <= W && H < 65536u && !converged()) {
+                if (probe) {
+                    const uint32_t edge = right ? W - n : n;                                              // first column not yet accepted (left) / one past it (right)
+                    const uint32_t a = right ? (edge + probe - 1) / probe * probe - probe : edge / probe * probe;  // the aligned window that holds it
+                    const bool clean = probe == 128u ? columns_uniform<128>(f, W, H, a) : columns_uniform<64>(f, W, H, a);
+                    if (clean) {
+                        n = right ? W - a : a + probe;
+                        publish(n);
+                        continue;
+                    }
+                    probe = probe == 128u ? 64u : 0u;
+                    continue;
+                }
                 const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
                 n += got;
                 publish(n);
