@@ -336,11 +336,11 @@ def test_boxes_that_share_their_column_range_take_the_per_wave_kernel(engine, mo
 
 @pytest.mark.parametrize("h,w", [(1080, 1920), (300, 1001), (96, 250), (64, 64)])
 def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(engine, h, w):
-    """Round 5: a batch of strips that is ONE value per strip from end to end (what a bar is, as a rule) is accepted without a histogram -
-    the column walk remembers the first row group's bytes and counts rows while every group repeats them; four constant rows pass on their
-    loads alone.  Everything around that shortcut against the oracle: clean bars of one value, of one value PER STRIP (a gradient across
-    the bar), bars with a single blemish in the first / a middle / the last row group or in the tail bytes of a row, blemishes that add up to
-    just under and just over 10 % of a strip, noisy bars inside +-16, a bar whose rows are constant but differ from each other."""
+    """Round 5: a batch of strips whose pixels stay inside a window of `tolerance` (a bar: one value per strip, as a rule) is accepted without
+    a histogram - rows by their exact min / max, columns by staying within tolerance / 2 of row 0's pixel.  Everything around that shortcut
+    against the oracle: clean bars of one value, of one value PER STRIP (a gradient across the bar), bars with a single blemish in the first / a
+    middle / the last row group or in the tail bytes of a row, blemishes that add up to just under and just over 10 % of a strip, noisy bars
+    inside +-16, a bar whose rows are constant but differ from each other."""
     rng = np.random.default_rng(h * 7 + w)
     bar_w, bar_h = max(w // 8, 3), max(h // 9, 3)
     cases = []
@@ -361,7 +361,7 @@ def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(e
     clip(lambda f: sides(f))
     clip(lambda f: rows(f))
     clip(lambda f: (sides(f), rows(f)))
-    def very_wide(f):  # bars of 0.4 w: several wide probes (columns_uniform) in a row, then counted batches, then single strips
+    def very_wide(f):  # bars of 0.4 w: several wide probes (columns_narrow) in a row, then counted batches, then single strips
         bw = int(w * 0.4)
         f[:, :, :bw] = 17
         f[:, :, w - bw + 3:] = 17
@@ -415,7 +415,7 @@ def test_uniform_bars_are_accepted_from_their_loads_and_blemished_ones_are_not(e
 
 @pytest.mark.parametrize("h,w,offset", [(512, 640, 0), (540, 1920, 0), (512, 640, 64), (512, 576, 0), (520, 704, 32)])
 def test_clean_side_bars_are_probed_in_aligned_windows(engine, h, w, offset):
-    """Round 5: the side walk of frames from 512 rows on probes clean bars in ALIGNED windows of 128, then 64 bytes (columns_uniform: whole
+    """Round 5: the side walk of frames from 512 rows on probes clean bars in ALIGNED windows of 128, then 64 bytes (columns_narrow: whole
     cache lines / sectors, read once) before it falls back to the counted 32-column batches - the walk is bound by HBM transactions.  Bar
     widths on both sides of every window boundary, different left and right, a bar that is clean only up to a boundary, a gradient bar
     (constant columns of different values), a noisy bar (every probe fails at once), a frame whose rows are all equal (every column constant:
@@ -455,6 +455,84 @@ def test_clean_side_bars_are_probed_in_aligned_windows(engine, h, w, offset):
     want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
     assert np.array_equal(got, want), (got.tolist(), want.tolist())
     assert tuple(want[widths.index(128)][:1]) == (128,) and tuple(want[-1]) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("h,w", [(1080, 1920), (540, 1024), (300, 1001), (96, 250)])
+def test_noisy_bars_are_accepted_by_their_range_and_wide_ranges_are_counted(engine, h, w):
+    """Round 5: strips whose pixels all lie inside a window of `tolerance` are letterbox whatever their mode is, so a bar a lossy codec has
+    left as 16 + {0..3} is accepted from its loads alone (rows: exact min / max over four rows; columns: every row within tolerance / 2 of row
+    0's pixel) instead of through a histogram whose few bins are all LDS conflicts.  The edges of that rule against the oracle: ranges of
+    exactly 16 and of 17 (the 17th value rare: still letterbox by the count; common: not), a first row that is the outlier (the anchor of
+    the column check), values 8 and 9 away from the anchor on both sides, bars at 0 and at 255 (no wrap in the 16-bit lanes), one noisy
+    strip among clean ones, noise in one frame of the clip only."""
+    rng = np.random.default_rng(h * 3 + w)
+    bw, bh = max(w // 7, 5), max(h // 8, 5)
+    cases = []
+
+    def clip(edit):
+        f = rng.integers(70, 190, size=(16, h, w), dtype=np.uint8)
+        edit(f)
+        cases.append(f)
+
+    def side_bars(f, lo, hi, p=None):
+        vals = np.arange(lo, hi + 1)
+        f[:, :, :bw] = rng.choice(vals, size=(16, h, bw), p=p).astype(np.uint8)
+        f[:, :, w - bw:] = rng.choice(vals, size=(16, h, bw), p=p).astype(np.uint8)
+
+    def row_bars(f, lo, hi, p=None):
+        vals = np.arange(lo, hi + 1)
+        f[:, :bh] = rng.choice(vals, size=(16, bh, w), p=p).astype(np.uint8)
+        f[:, h - bh:] = rng.choice(vals, size=(16, bh, w), p=p).astype(np.uint8)
+
+    for lo, hi in ((16, 19), (0, 3), (252, 255), (0, 16), (239, 255), (100, 116)):  # ranges of at most 16: letterbox for certain
+        clip(lambda f, lo=lo, hi=hi: side_bars(f, lo, hi))
+        clip(lambda f, lo=lo, hi=hi: row_bars(f, lo, hi))
+    rare = np.array([0.97 / 17] * 17 + [0.03])   # 18 values, range 17: the last one rare -> > 90 % near any mode
+    rare /= rare.sum()
+    clip(lambda f: side_bars(f, 20, 37, rare))
+    clip(lambda f: row_bars(f, 20, 37, rare))
+    ends = np.array([0.45] + [0.1 / 16] * 16 + [0.45])  # range 17, both ends common: the mode's window leaves out 45 %
+    ends /= ends.sum()
+    clip(lambda f: side_bars(f, 20, 37, ends))
+    clip(lambda f: row_bars(f, 20, 37, ends))
+    for d in (8, 9, -8, -9):  # a constant bar of 50 whose first row / first column is d away and a few more pixels 8 the other way
+        def e(f, d=d):
+            f[:, :, :bw] = 50
+            f[:, 0, :bw] = 50 + d
+            f[:, 1 + h // 2, :bw] = 50 - (8 if d > 0 else -8)
+        clip(e)
+        def e2(f, d=d):
+            f[:, :bh] = 50
+            f[:, :bh, 0] = 50 + d
+            f[:, :bh, w // 2] = 50 - (8 if d > 0 else -8)
+        clip(e2)
+    def first_row_outlier(f):  # the anchor row is far off: the window check fails at once, the count accepts (one row in h)
+        f[:, :, :bw] = 16
+        f[:, 0, :bw] = 200
+    clip(first_row_outlier)
+    def one_noisy_strip(f):
+        f[:, :, :bw] = 16
+        f[:, :, bw // 2] = rng.integers(0, 256, size=(16, h), dtype=np.uint8)   # a strip of picture inside the bar: the walk stops there
+        f[:, :bh] = 16
+        f[:, bh // 2] = rng.integers(0, 256, size=(16, w), dtype=np.uint8)
+    clip(one_noisy_strip)
+    def one_frame_only(f):  # frame 0 has clean bars, frame 8 noisy wider ones: per-frame boxes differ, the union takes the smaller
+        f[0, :, :bw] = 16
+        f[8, :, :bw + 9] = rng.integers(14, 20, size=(h, bw + 9), dtype=np.uint8)
+        f[0, :bh + 4] = rng.integers(14, 20, size=(bh + 4, w), dtype=np.uint8)
+        f[8, :bh] = 16
+    clip(one_frame_only)
+    frames = np.stack(cases)
+    d = torch.from_numpy(frames).cuda()
+    crops = torch.zeros((len(frames), 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    engine.cropdetect_letterbox_device(d.data_ptr(), len(frames), 16, w, h, crops.data_ptr())
+    torch.cuda.synchronize()
+    got = crops.cpu().numpy().astype(np.uint32)
+    want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
+    assert np.array_equal(got, want), [(i, g, x) for i, (g, x) in enumerate(zip(got.tolist(), want.tolist())) if g != x]
+    assert tuple(want[0]) == (bw, bw, 0, 0) and tuple(want[1]) == (0, 0, bh, bh)
+    assert tuple(want[14]) == (0, 0, 0, 0) and tuple(want[15]) == (0, 0, 0, 0)  # the "both ends common" bars are picture
 
 
 def test_a_large_mixed_batch_of_large_frames():

@@ -13,6 +13,7 @@ ap.add_argument("--bars", type=float, default=0.12, help="letterbox bar height a
 ap.add_argument("--side", type=float, default=0.0, help="pillarbox bar width as a fraction of W (0 = none)")
 ap.add_argument("--black", type=float, default=0.0, help="fraction of clips whose frame 0 is uniformly black (a fade-in: every strip of every edge is letterbox)")
 ap.add_argument("--mix", action="store_true", help="a mixed batch: 70 %% of the clips without bars, 20 %% with --bars top / bottom, 10 %% with --side bars")
+ap.add_argument("--noise", type=int, default=0, help="bars are 16 + U{0..noise} per pixel instead of one value (what a lossy codec leaves of a black bar)")
 ap.add_argument("--steps", type=int, default=3)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -32,6 +33,10 @@ if bar:
 if side:
     frames[sd, :, :, :side] = 16
     frames[sd, :, :, a.w - side:] = 16
+if a.noise > 0:
+    nz = torch.randint(0, a.noise + 1, (a.clips, 16, a.h, a.w), dtype=torch.uint8, device=dev, generator=g)
+    frames = torch.where(frames == 16, 16 + nz, frames)
+    del nz
 if a.black > 0:
     frames[:: max(1, int(round(1 / a.black))), 0] = 16
 out = torch.zeros((a.clips, 16), dtype=torch.int64, device=dev)

@@ -41,6 +41,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
                max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, row_ror<8>(v));
+    v = min(v, row_ror<4>(v));
+    v = min(v, row_ror<2>(v));
+    v = min(v, row_ror<1>(v));
+    return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
+// Bytes of a dword as two packed 16-bit pairs (even bytes, odd bytes): running minima / maxima over pixels then cost one packed
+// instruction per pair (v_pk_min_u16 / v_pk_max_u16).
+typedef unsigned short vdf_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void minmax_bytes(uint32_t d, vdf_u16x2 &mn, vdf_u16x2 &mx)
+{
+    const vdf_u16x2 e = __builtin_bit_cast(vdf_u16x2, d & 0x00FF00FFu), o = __builtin_bit_cast(vdf_u16x2, (d >> 8) & 0x00FF00FFu);
+    mn = __builtin_elementwise_min(__builtin_elementwise_min(mn, e), o);
+    mx = __builtin_elementwise_max(__builtin_elementwise_max(mx, e), o);
+}
+
 // The reference's test is  count as f64 / len as f64 > 0.9  (video_frames_gray.rs:65,96-99).  For integers below 2^32 that is exactly
 // 10 count > 9 len: a quotient other than 9/10 itself is at least 1 / (10 len) > 2^-36 away from 0.9, far more than the 2^-54 by which
 // the double 0.9 and the rounding of the division can move it; and 9/10 exactly divides to the double 0.9, which is not greater than
@@ -154,47 +174,49 @@ __device__ __forceinline__ uint32_t row_strips4(RowAt row, uint32_t len, uint32_
 {
     const uint32_t lane = threadIdx.x & 63, n16 = len >> 4;
     struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
-    // A bar is, as a rule, rows of one value each.  Four such rows are letterbox by any tolerance and are accepted from their loads alone:
-    // no histogram is cleared, counted into or scanned (that chain, not the loads, was a pass's time).  Anything else - the batch where the
-    // picture begins, noisy bars - takes the general path below and reads its rows once more (from L2).
-    {
-        bool uni = true;
-        uint32_t want[4] = {0u, 0u, 0u, 0u};  // each row's first pixel in every byte, taken from the first load itself (a separate
-                                              // load of it would put one more round trip in front of every pass)
-        for (uint32_t i0 = 0; i0 < n16 && uni; i0 += 128) {  // (n16 >= 1 inside)
+    // A strip whose pixels all lie within `tol` of each other (max - min <= tol) is letterbox whatever its mode is: the mode is one of its
+    // values, so every pixel is within tol of it and the count is the whole strip.  That is what a bar is - one value, or a few neighbouring
+    // ones once a lossy codec has been over it - and it needs no histogram: four such rows are accepted from their loads alone, with packed
+    // min / max per lane and two wave reductions per row.  (The histogram of a NOISY bar is the worst case the LDS has: a handful of bins,
+    // every atomic a 16-way conflict - 1000 1080p clips with 129-row bars of 16 .. 19 took 1.24 ms to probe against 0.27 ms for bars of
+    // exactly 16.)  Anything else - the batch where the picture begins - takes the general path below and reads its rows once more (from L2).
+    if (n16 != 0) {
+        vdf_u16x2 mn[4], mx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { mn[r] = vdf_u16x2{0xFFFFu, 0xFFFFu}; mx[r] = vdf_u16x2{0u, 0u}; }
+        for (uint32_t i0 = 0; i0 < n16; i0 += 128) {
             U4 v[4][2];  // all eight loads of the pass in flight together: one round trip to HBM
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    // (UNCONDITIONAL loads at a clamped index: a `valid ? load : 0` here became a branch around every load with a full
-                    // vmcnt(0) wait behind it - eight serial round trips per pass, and the black-frame walk half as fast as without the check)
+                    // (UNCONDITIONAL loads at a clamped index - a clamped lane looks at the row's last 16 pixels again, harmless: a
+                    // `valid ? load : 0` here became a branch around every load with a full vmcnt(0) wait behind it, eight serial round trips)
                     const uint32_t i = min(i0 + 64u * k + lane, n16 - 1);
                     v[r][k] = *reinterpret_cast<const U4 *>(row(r) + 16 * (size_t)i);
                 }
-            if (i0 == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) want[r] = ((uint32_t)__builtin_amdgcn_readfirstlane((int)v[r][0].x) & 255u) * 0x01010101u;  // lane 0 is active: n16 >= 1 here
-            }
-            bool good = true;
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const U4 &q = v[r][k];  // (a clamped lane re-checks the row's last 16 pixels: harmless)
-                    good = good & ((((q.x ^ want[r]) | (q.y ^ want[r])) | ((q.z ^ want[r]) | (q.w ^ want[r]))) == 0u);  // (no short circuit: no branches between the loads)
+                    minmax_bytes(v[r][k].x, mn[r], mx[r]);
+                    minmax_bytes(v[r][k].y, mn[r], mx[r]);
+                    minmax_bytes(v[r][k].z, mn[r], mx[r]);
+                    minmax_bytes(v[r][k].w, mn[r], mx[r]);
                 }
-            uni = __builtin_amdgcn_ballot_w64(good) == ~0ull;
         }
-        uni = uni && n16 != 0;  // (rows shorter than 16 pixels: the general path)
-        if (uni && (len & 15u) != 0) {  // the last len % 16 pixels of each row
-            bool good = true;
+        bool narrow = true;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                for (uint32_t i = 16 * n16 + lane; i < len; i += 64) good = good && row(r)[i] == (uint8_t)(want[r] & 255u);
-            uni = __builtin_amdgcn_ballot_w64(good) == ~0ull;
+        for (int r = 0; r < 4; r++) {
+            uint32_t lo = min((uint32_t)mn[r].x, (uint32_t)mn[r].y), hi = max((uint32_t)mx[r].x, (uint32_t)mx[r].y);
+            for (uint32_t i = 16 * n16 + lane; i < len; i += 64) {  // the last len % 16 pixels of the row
+                const uint32_t p = row(r)[i];
+                lo = min(lo, p);
+                hi = max(hi, p);
+            }
+            narrow = narrow & (wave_max_u32(hi) - wave_min_u32(lo) <= tol);
         }
-        if (uni) return 4;
+        if (narrow) return 4;
     }
     {   // (the clear's addresses are made from a lane number the compiler cannot see through: hoisted out of the caller's walk loop they
         // stayed live across it and were the one value pass 1's 64 registers had no room for)
@@ -296,15 +318,10 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
     constexpr uint32_t HALF = NC / 2, ND = NC / 4;  // columns per counter half, dwords per row
     const uint32_t lane = threadIdx.x & 63;
     struct __attribute__((packed, aligned(1))) UN { uint32_t d[ND]; };
-    // A bar is, as a rule, the same NC bytes in every row.  While that holds nothing is counted at all: `ref` remembers the bytes and
-    // `uniform_rows` how many rows carried them; if it holds to the last row every column is a constant - letterbox by any tolerance - and the
-    // batch is accepted without the LDS having been touched (clearing, counting into and scanning NC histograms was most of a bar batch's
-    // time).  The first row group that differs clears the histograms, credits the rows seen so far and goes on counting.
-    bool uniform = true;
-    uint32_t uniform_rows = 0;
-    UN ref;
 #pragma unroll
-    for (uint32_t j = 0; j < ND; j++) ref.d[j] = 0u;
+    for (uint32_t k = 0; k < HALF * 4 + 1; k++) histn[lane + 64 * k] = 0u;  // HALF x kHistPitch words (+ slack inside the wave's array)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     auto byte_of = [](const UN &v, uint32_t c) {  // (64-bit shifts and selects, not an indexed load: a lane-dependent index would put v in scratch)
         uint64_t w = (uint64_t)v.d[0] | ((uint64_t)v.d[1] << 32);
 #pragma unroll
@@ -344,26 +361,8 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
                 first.d[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k].d[j]);
                 same = same && v[k].d[j] == first.d[j];
             }
-            const bool all_same = __builtin_amdgcn_ballot_w64(active && same) == act;  // every active row of the group holds the same NC bytes
-            if (uniform) {
-                bool as_before = all_same;
-                if (uniform_rows != 0)
-#pragma unroll
-                    for (uint32_t j = 0; j < ND; j++) as_before = as_before && first.d[j] == ref.d[j];
-                if (as_before) {  // wave-uniform: `first` and `ref` are scalars
-                    if (uniform_rows == 0) ref = first;
-                    uniform_rows += (uint32_t)__builtin_popcountll(act);
-                    continue;
-                }
-                uniform = false;
-#pragma unroll
-                for (uint32_t q = 0; q < HALF * 4 + 1; q++) histn[lane + 64 * q] = 0u;  // HALF x kHistPitch words (+ slack inside the wave's array)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (uniform_rows != 0 && lane < (uint32_t)NC) atomicAdd(slot(lane, byte_of(ref, lane)), uniform_rows << (16 * (lane / HALF)));
-            }
-            if (all_same) {
-                // (bars with a blemish further up: lane c adds the row count to column c's bin)
+            if (__builtin_amdgcn_ballot_w64(active && same) == act) {
+                // every active row holds the same NC bytes: lane c adds the row count to column c's bin
                 if (lane < (uint32_t)NC) atomicAdd(slot(lane, byte_of(first, lane)), (uint32_t)__builtin_popcountll(act) << (16 * (lane / HALF)));
             } else if (active) {
 #pragma unroll 4
@@ -371,7 +370,6 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
             }
         }
     }
-    if (uniform) return (uint32_t)NC;  // every column of the batch is one value from top to bottom
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // lane = NC q + c: share q of column c's histogram (256 / (64 / NC) bins)
@@ -401,46 +399,50 @@ __device__ __forceinline__ uint32_t column_strips(const uint8_t *__restrict__ f,
 }
 
 
-// True iff every row of the frame holds the same WB bytes at columns x0 .. x0 + WB - 1: each of those columns is one value from top to bottom,
-// i.e. WB letterbox strips by any tolerance (a clean bar).  No LDS, no counting - registers only.  What it is for is BYTES: the side walk
-// is bound by HBM transactions, not by its round trips (rocprofv3, round 5: 43 M L2 misses of 64 B per launch on 1000 pillarboxed 1080p
-// clips = 2.8 GB at 3.5 TB/s of scattered 64-byte reads, for 1.1 GB of columns: a 32-byte batch fetches a 64-byte sector, and the batch
-// next to it fetches the same sector again later).  A probe at a 128- or 64-byte ALIGNED window reads whole lines / sectors once.
+// True iff, in every one of the WB columns x0 .. x0 + WB - 1, all rows lie within tol / 2 of the column's pixel in row 0 - then each column's
+// pixels are within tol of each other, hence of its mode whatever that is, and all WB strips are letterbox (a bar: one value per column, or
+// a few neighbouring ones after a lossy codec).  False decides nothing.  No LDS, no counting: packed 16-bit adds against row 0 and one running
+// maximum.  What it is for is BYTES and LDS conflicts: the side walk is bound by HBM transactions, not by its round trips (rocprofv3,
+// round 5: 43 M L2 misses of 64 B per launch on 1000 pillarboxed 1080p clips = 2.8 GB at 3.5 TB/s of scattered 64-byte reads, for 1.1 GB
+// of columns: a 32-byte batch fetches a 64-byte sector, and the batch next to it fetches the same sector again later) - a probe at a
+// 128- or 64-byte ALIGNED window reads whole lines / sectors once; and a noisy bar's histogram is all 16-way bank conflicts.
 // All 64 lanes must call.
 template <int WB>
-__device__ __forceinline__ bool columns_uniform(const uint8_t *__restrict__ f, uint32_t W, uint32_t H, uint32_t x0)
+__device__ __forceinline__ bool columns_narrow(const uint8_t *__restrict__ f, uint32_t W, uint32_t H, uint32_t x0, uint32_t tol)
 {
     constexpr uint32_t ND = WB / 4;
+    struct __attribute__((packed, aligned(1))) UW { uint32_t d[ND]; };
     const uint32_t lane = threadIdx.x & 63;
-    constexpr int INFL = WB >= 128 ? 4 : 8;  // rows per lane in flight (128 dwords of loads either way)
-    uint32_t ref[ND];                        // row 0's bytes (scalars)
+    constexpr int INFL = WB >= 128 ? 4 : 8;  // rows per lane in flight (128 / 128 / 64 / 32 / 16 dwords of loads)
+    const uint32_t half = tol / 2;
+    vdf_u16x2 ce[ND], co[ND];                // half - (row 0's pixel), per even / odd byte of each dword (scalars)
 #pragma unroll
-    for (uint32_t j = 0; j < ND; j++) ref[j] = 0u;
+    for (uint32_t j = 0; j < ND; j++) ce[j] = co[j] = vdf_u16x2{0u, 0u};
+    vdf_u16x2 worst = {0u, 0u};              // max over everything seen of (pixel - row 0's pixel + half) mod 2^16: <= tol iff inside the window
     for (uint32_t i0 = 0; i0 < H; i0 += 64u * INFL) {
-        uint4 v[INFL][ND / 4];
+        UW v[INFL];
 #pragma unroll
-        for (int k = 0; k < INFL; k++) {  // unconditional, aligned 16-byte loads at a clamped row (a clamped lane re-checks the last row)
+        for (int k = 0; k < INFL; k++) {  // unconditional loads at a clamped row (a clamped lane looks at the last row again)
             const uint32_t row = min(i0 + 64u * k + lane, H - 1);
-            const uint4 *src = reinterpret_cast<const uint4 *>(f + (size_t)row * W + x0);
-#pragma unroll
-            for (uint32_t j = 0; j < ND / 4; j++) v[k][j] = src[j];
+            v[k] = *reinterpret_cast<const UW *>(f + (size_t)row * W + x0);
         }
         if (i0 == 0) {
 #pragma unroll
-            for (uint32_t j = 0; j < ND / 4; j++) {  // lane 0, k = 0: row 0
-                ref[4 * j + 0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].x);
-                ref[4 * j + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].y);
-                ref[4 * j + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].z);
-                ref[4 * j + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0][j].w);
+            for (uint32_t j = 0; j < ND; j++) {  // lane 0, k = 0: row 0
+                const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0].d[j]);
+                ce[j] = vdf_u16x2{(unsigned short)(half - (r0 & 255u)), (unsigned short)(half - ((r0 >> 16) & 255u))};
+                co[j] = vdf_u16x2{(unsigned short)(half - ((r0 >> 8) & 255u)), (unsigned short)(half - (r0 >> 24))};
             }
         }
-        uint32_t diff = 0;
 #pragma unroll
         for (int k = 0; k < INFL; k++)
 #pragma unroll
-            for (uint32_t j = 0; j < ND / 4; j++)
-                diff |= (v[k][j].x ^ ref[4 * j]) | (v[k][j].y ^ ref[4 * j + 1]) | (v[k][j].z ^ ref[4 * j + 2]) | (v[k][j].w ^ ref[4 * j + 3]);
-        if (__builtin_amdgcn_ballot_w64(diff == 0u) != ~0ull) return false;  // wave-uniform
+            for (uint32_t j = 0; j < ND; j++) {
+                const uint32_t d = v[k].d[j];
+                const vdf_u16x2 e = __builtin_bit_cast(vdf_u16x2, d & 0x00FF00FFu), o = __builtin_bit_cast(vdf_u16x2, (d >> 8) & 0x00FF00FFu);
+                worst = __builtin_elementwise_max(__builtin_elementwise_max(worst, e + ce[j]), o + co[j]);
+            }
+        if (__builtin_amdgcn_ballot_w64(max((uint32_t)worst.x, (uint32_t)worst.y) > tol) != 0ull) return false;  // wave-uniform
     }
     return true;
 }
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__r
         uint32_t n = first;
         if (first) {
             bool walking = true;
-            // Aligned probes for clean bars (columns_uniform), where rows and frame are line-aligned: a window of 128 bytes, after its first
+            // Aligned probes for bars (columns_narrow), where rows and frame are line-aligned: a window of 128 bytes, after its first
             // failure 64, after that the counted 32-column batches for good.  The window that holds strip n starts at or before it: the strips
             // in front of n inside it were accepted already, and if they are not constant columns (a noisy bar) the probe just fails.
             const uint32_t align = (uint32_t)(reinterpret_cast<uintptr_t>(f) | W);  // rows start where the frame does, W bytes apart
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__r
                 if (probe) {
                     const uint32_t edge = right ? W - n : n;                                              // first column not yet accepted (left) / one past it (right)
                     const uint32_t a = right ? (edge + probe - 1) / probe * probe - probe : edge / probe * probe;  // the aligned window that holds it
-                    const bool clean = probe == 128u ? columns_uniform<128>(f, W, H, a) : columns_uniform<64>(f, W, H, a);
+                    const bool clean = probe == 128u ? columns_narrow<128>(f, W, H, a, tol) : columns_narrow<64>(f, W, H, a, tol);
                     if (clean) {
                         n = right ? W - a : a + probe;
                         publish(n);
@@ -575,7 +577,11 @@ __global__ __launch_bounds__(128) void letterbox_sides_kernel(const uint8_t *__r
                     probe = probe == 128u ? 64u : 0u;
                     continue;
                 }
-                const uint32_t got = column_strips<kColumnBatch>(f, W, H, right ? W - n - kColumnBatch : n, right, tol, s_histn[wave]);
+                // a batch of narrow columns (a bar, clean or noisy) is accepted without a histogram; the batch where the picture begins fails
+                // this at its first row group and is counted
+                const uint32_t x0 = right ? W - n - kColumnBatch : n;
+                const uint32_t got = columns_narrow<kColumnBatch>(f, W, H, x0, tol) ? (uint32_t)kColumnBatch
+                                                                                   : column_strips<kColumnBatch>(f, W, H, x0, right, tol, s_histn[wave]);
                 n += got;
                 publish(n);
                 walking = got == (uint32_t)kColumnBatch;
