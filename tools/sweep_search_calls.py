@@ -52,3 +52,24 @@ for nr in (1, 10, 100, 1000, 10_000, 100_000, 1_000_000):
     for _ in range(3):
         t = time.perf_counter(); r = eng1.search_refs_device(cw.data_ptr(), cd.data_ptr(), n, rw.data_ptr(), rd.data_ptr(), nr, 350, capacity=cap); best = min(best, time.perf_counter() - t)
     print(f"n_ref={nr:8d}: {best*1e3:9.3f} ms  hits {r[1] if isinstance(r, tuple) else len(r)}")
+print("== the same with the candidate database pinned (vdf_ctx_pin_database): whole call, and its phases")
+eng1.pin_database(cw.data_ptr(), n)
+for nr in (1, 10, 100, 1000, 10_000, 100_000):
+    idx = rng.integers(0, n, nr); rw = torch.from_numpy(w[idx].view(np.int64)).to(dev); rd = torch.from_numpy(d[idx].view(np.int32)).to(dev)
+    cap = max(1 << 16, 4 * nr)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t = time.perf_counter(); r = eng1.search_refs_device(cw.data_ptr(), cd.data_ptr(), n, rw.data_ptr(), rd.data_ptr(), nr, 350, capacity=cap); dt = time.perf_counter() - t
+        if dt < best: best, tm = dt, eng1.last_timing()
+    print(f"n_ref={nr:8d}: {best*1e3:9.3f} ms  hits {r[1] if isinstance(r, tuple) else len(r)}  " + " ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in tm.items()))
+eng1.pin_database(0, 0)
+print("== few candidates against 1 M references (the incremental case the other way round)")
+for nc in (1, 10, 100, 1000):
+    idx = np.sort(rng.integers(0, n, nc)); cw2 = torch.from_numpy(w[idx].view(np.int64)).to(dev); cd2 = torch.from_numpy(d[idx].view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        t = time.perf_counter(); r = eng1.search_refs_device(cw2.data_ptr(), cd2.data_ptr(), nc, cw.data_ptr(), cd.data_ptr(), n, 350, capacity=1 << 22); dt = time.perf_counter() - t
+        if dt < best: best, tm = dt, eng1.last_timing()
+    print(f"n_cand={nc:7d}: {best*1e3:9.3f} ms  hits {r[1] if isinstance(r, tuple) else len(r)}  " + " ".join(f"{k} {v:.3f}" if isinstance(v, float) else f"{k} {v}" for k, v in tm.items()))
