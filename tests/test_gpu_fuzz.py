@@ -194,6 +194,89 @@ def test_cropped_hash_fuzz(seed):
         assert np.array_equal(got, want), (mode, h, w, np.nonzero((got != want).any(axis=1))[0].tolist(), crops.tolist())
 
 
+def _bar(rng, shape, axis_len_first):
+    """One bar of a random style: what a bar can look like after an encoder - and what only looks like one."""
+    style = int(rng.integers(0, 8))
+    base = int(rng.choice([0, 1, 16, 17, 128, 235, 250, 255])) if rng.random() < 0.5 else int(rng.integers(0, 256))
+    if style == 0:    # one value
+        return np.full(shape, base, np.uint8)
+    if style == 1:    # one value per strip (gradient along the walk) or per position inside the strips
+        ramp = (base + np.arange(shape[axis_len_first], dtype=np.int64) * int(rng.integers(1, 4))) % 256
+        idx = [None] * len(shape)
+        idx[axis_len_first] = slice(None)
+        return np.broadcast_to(ramp.astype(np.uint8)[tuple(idx)], shape).copy()
+    if style in (2, 3):  # noise inside a window of k levels: k <= 17 is the range rule's ground (16 accepted for sure, 17 by the count or not)
+        k = int(rng.choice([2, 4, 8, 16, 17, 18, 24, 40]))
+        lo = min(base, 256 - k)
+        return rng.integers(lo, lo + k, size=shape).astype(np.uint8)
+    if style in (4, 5):  # a clean or slightly noisy bar with outliers (logo pixels, subtitles): below / around / above the 10 % mark
+        k = int(rng.choice([1, 3]))
+        lo = min(base, 256 - k)
+        out = rng.integers(lo, lo + k, size=shape).astype(np.uint8)
+        p = float(rng.choice([0.001, 0.05, 0.095, 0.105, 0.2]))
+        mask = rng.random(shape) < p
+        out[mask] = ((out[mask].astype(np.int64) + 100) % 256).astype(np.uint8)
+        return out
+    if style == 6:    # two far-apart values: never a bar
+        return rng.choice(np.array([base, (base + 90) % 256], np.uint8), size=shape)
+    return rng.integers(0, 256, size=shape).astype(np.uint8)  # picture
+
+
+@pytest.mark.parametrize("seed", range(max(24, _SOAK // 2)))
+def test_letterbox_detect_fuzz(seed):
+    """vdf_cropdetect_letterbox_device against the oracle on random frames with random bars of random styles on all four edges (one value, a
+    ramp, noise inside windows of 2 ... 40 levels, outliers around the 10 % mark, two-valued, picture), dark / flat / busy pictures (a dark picture
+    continues a dark bar: the walk goes on into it), frames 0 and 8 differing, every alignment class of width and buffer base, all three
+    side-walk kernels (H < 256, < 512, >= 512: with the aligned probes) - the round-5 shortcuts (range rule, probes) decide nothing the count would not."""
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(70_000 + seed)
+    hk = seed % 3
+    h = int(rng.integers(17, 256)) if hk == 0 else int(rng.integers(256, 512)) if hk == 1 else int(rng.integers(512, 900))
+    w = int(rng.choice([64, 128, 192, 256, 320, 384, 512, 640, 704, 768, 896, 1024, 1280])) if seed % 2 else int(rng.integers(40, 1100))
+    n = 12 if h * w < 400_000 else 6
+    frames = np.empty((n, 16, h, w), np.uint8)
+    for c in range(n):
+        pic = int(rng.integers(0, 4))
+        if pic == 0:
+            f = rng.integers(0, 256, size=(16, h, w), dtype=np.uint8)
+        elif pic == 1:    # dark picture: within the tolerance of a black bar
+            f = rng.integers(0, 30, size=(16, h, w), dtype=np.uint8)
+        elif pic == 2:    # flat picture with a little texture
+            f = (int(rng.integers(0, 236)) + rng.integers(0, 20, size=(16, h, w))).astype(np.uint8)
+        else:             # smooth gradient both ways
+            f = ((np.arange(h)[:, None] * 255 // h + np.arange(w)[None, :] * 255 // w) // 2).astype(np.uint8)[None].repeat(16, 0)
+        for fr in (0, 8):
+            if fr == 8 and rng.random() < 0.5:
+                f[8] = f[0]   # the same bars in both probed frames (the usual case); else frame 8 gets its own below
+                continue
+            t, b = (int(rng.integers(0, h // 3)) if rng.random() < 0.6 else 0 for _ in range(2))
+            l, r = (int(rng.integers(0, w // 3)) if rng.random() < 0.6 else 0 for _ in range(2))
+            if l: f[fr, :, :l] = _bar(rng, (h, l), 1)
+            if r: f[fr, :, w - r:] = _bar(rng, (h, r), 1)
+            if t: f[fr, :t, :] = _bar(rng, (t, w), 0)
+            if b: f[fr, h - b:, :] = _bar(rng, (b, w), 0)
+        if rng.random() < 0.08:
+            f[0] = int(rng.integers(0, 256))  # a uniform probe frame: the walkers meet
+        frames[c] = f
+    offset = int(rng.choice([0, 0, 16, 64, 128, 1, 3]))
+    buf = torch.zeros(frames.size + 256, dtype=torch.uint8, device="cuda")
+    buf[offset:offset + frames.size] = torch.from_numpy(frames).cuda().reshape(-1)
+    crops = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    eng = vdf.Engine(0)
+    try:
+        torch.cuda.synchronize()
+        eng.cropdetect_letterbox_device(buf.data_ptr() + offset, n, 16, w, h, crops.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        eng.close()
+    got = crops.cpu().numpy().astype(np.uint32)
+    want = np.array([orc.cropdetect_letterbox(c) for c in frames], np.uint32)
+    assert np.array_equal(got, want), (h, w, offset, [(i, g, x) for i, (g, x) in enumerate(zip(got.tolist(), want.tolist())) if g != x])
+
+
 @pytest.mark.parametrize("seed", range(max(12, _SOAK // 10)))
 def test_hash_fuzz_wide_frames(seed):
     """The wide kernels numerically fuzzed: 1500..4200 columns, 129..2200 rows, through the device entry point with random
