@@ -153,6 +153,27 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 3, 5])
+@pytest.mark.parametrize("h,w,n", [(128, 256, 70), (126, 224, 70), (117, 208, 70), (112, 200, 70), (120, 160, 70), (108, 192, 70), (96, 320, 70),
+                                   (128, 480, 50), (120, 640, 50), (128, 854, 45), (128, 1280, 40), (128, 1920, 36), (64, 1920, 40), (100, 1366, 40),
+                                   (65, 300, 70), (80, 240, 70), (64, 528, 60), (127, 150, 70), (90, 160, 70), (64, 512, 70), (48, 1920, 40), (72, 1000, 40)])
+def test_short_wide_frames_stream_and_match_oracle(mode, h, w, n, monkeypatch):
+    """Round 5: frames of at most 128 rows used to fuse resize and DCT whatever their width; the wide ones (resize_short_prefers_stream:
+    more than 64 rows and 19 000 pixels, or wider than 512) now take the linear-stream kernels where they are eligible - frames of ONE or TWO
+    chunks, of 4 ... 8 blocks, more clips than resident workgroups.  Default dispatch, the fused kernel and the stream kernels by force
+    against the oracle; sizes on both sides of the rule."""
+    import vid_dup_finder_lib_amd as vdf
+
+    monkeypatch.setenv("VDF_RESIZE_MODE", str(mode))
+    eng = vdf.Engine(0)
+    try:
+        rng = np.random.default_rng(6000 + h * 7 + w)
+        frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+        _check(eng, frames)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("mode", [0, 6])
 @pytest.mark.parametrize("h,w,n", [(576, 1024, 2), (864, 1536, 1), (1152, 2048, 1), (1440, 2560, 1), (2160, 3840, 1), (300, 4096, 1),
                                    (333, 3008, 1), (130, 1040, 40), (720, 1280, 1), (1080, 1920, 1)])

@@ -535,6 +535,69 @@ def test_noisy_bars_are_accepted_by_their_range_and_wide_ranges_are_counted(engi
     assert tuple(want[14]) == (0, 0, 0, 0) and tuple(want[15]) == (0, 0, 0, 0)  # the "both ends common" bars are picture
 
 
+def test_frames_and_boxes_of_one_chunk_in_large_batches():
+    """Round 5: a frame (or crop box) that fits ONE chunk of the chunk-stream kernels ends in the step that began with wave 0 reading the previous
+    frame's partial sums, and nothing ordered that read before the other waves' next write - a wave without a block in a short chunk got
+    there at once: 1 - 2 clips in 30 000 came out wrong (found by a size sweep with the kernel forced onto 64 x 48 frames; in the product path only
+    letterbox boxes of at most 64 rows reach it).  Now an LDS barrier in that case.  Large batches of such boxes through the ROWCROP chunk
+    kernel and the cropped stream kernel against the general kernels (and the oracle on the first clips), and the forced form of the find."""
+    import os
+
+    import vid_dup_finder_lib_amd as vdf
+
+    def engine_with(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            return vdf.Engine(0)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    h, w, n = 144, 176, 12000
+    frames = torch.randint(0, 256, (n, 16, h, w), dtype=torch.uint8, device=dev, generator=g)
+    host8 = frames[:8].cpu().numpy()
+    for crop, general in (((0, 0, 50, 50), {"VDF_NO_ROWCROP": "1", "VDF_RESIZE_MODE": "4"}), ((8, 8, 50, 50), {"VDF_RESIZE_MODE": "4"}),
+                          ((0, 0, 100, 11), {"VDF_NO_ROWCROP": "1", "VDF_RESIZE_MODE": "4"})):   # boxes of 44, 44 and 33 rows: one chunk, waves without a block
+        crops = np.tile(np.array(crop, np.uint32), (n, 1))
+        l, r, t, b = crop
+        want8 = np.stack([orc.hash_clip(np.ascontiguousarray(host8[c][:, t:h - b, l:w - r]))[1] for c in range(8)])
+        ref_eng = engine_with(general)
+        ref = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+        ref_eng.hash_frames_cropped_device(frames.data_ptr(), n, 16, w, h, crops, ref.data_ptr())
+        torch.cuda.synchronize()
+        ref_eng.close()
+        assert np.array_equal(ref[:8].cpu().numpy().view(np.uint64), want8)
+        for rep in range(3):
+            eng = vdf.Engine(0)
+            out = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+            eng.hash_frames_cropped_device(frames.data_ptr(), n, 16, w, h, crops, out.data_ptr())
+            torch.cuda.synchronize()
+            eng.close()
+            bad = torch.nonzero((out != ref).any(dim=1)).flatten()
+            assert len(bad) == 0, (crop, rep, bad[:10].tolist())
+    del frames
+    for hh, ww, nn in ((48, 64, 30000), (32, 64, 30000), (40, 128, 20000)):  # the forced form: whole frames of one short chunk
+        frames = torch.randint(0, 256, (nn, 16, hh, ww), dtype=torch.uint8, device=dev, generator=g)
+        torch.cuda.synchronize()  # the library's own stream does not wait for torch's
+        ref_eng = vdf.Engine(0)
+        ref = torch.zeros((nn, 16), dtype=torch.int64, device=dev)
+        ref_eng.hash_frames_device(frames.data_ptr(), nn, 16, ww, hh, ref.data_ptr())
+        torch.cuda.synchronize()
+        ref_eng.close()
+        for rep in range(3):
+            eng = engine_with({"VDF_RESIZE_MODE": "5"})
+            out = torch.zeros((nn, 16), dtype=torch.int64, device=dev)
+            eng.hash_frames_device(frames.data_ptr(), nn, 16, ww, hh, out.data_ptr())
+            torch.cuda.synchronize()
+            eng.close()
+            bad = torch.nonzero((out != ref).any(dim=1)).flatten()
+            assert len(bad) == 0, (hh, ww, rep, bad[:10].tolist())
+
+
 def test_a_large_mixed_batch_of_large_frames():
     """203 clips of 640 x 416 with bars of every kind - top / bottom, sides, a corner, none - and black probe frames (a fade-in: every strip
     of every edge is letterbox until two walkers meet; frame 8 decides), through the two-pass detect (first strips of all four edges; then

@@ -19,7 +19,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--modes", default="0,4,6")
 ap.add_argument("--mb", type=int, default=1500, help="frame bytes per launch")
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--sizes", default="", help="WxH,WxH,... instead of the built-in list")
 args = ap.parse_args()
+if args.sizes:
+    SIZES = [tuple(int(v) for v in s.split("x")) for s in args.sizes.split(",")]
 modes = [int(m) for m in args.modes.split(",")]
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)

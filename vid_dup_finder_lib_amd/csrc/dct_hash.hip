@@ -964,6 +964,11 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
         }
         if (last) {  // frame complete: partial sums to LDS, the result is written after the next barrier
+            // A frame of ONE chunk ends in the step that began with wave 0 reading the PREVIOUS frame's partial sums (write_pending):
+            // nothing orders that read before the writes below - a wave without a block in a short chunk gets here at once (seen, round 5:
+            // 1 - 2 clips in 30 000 of 64 x 48 through this kernel by force; in the product path only a letterbox box of at most one chunk
+            // can get here).  Frames of two chunks and more have the next step's barrier in between.  LDS-only: the DMA stays in flight.
+            if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
@@ -1728,6 +1733,7 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
             acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
         }
         if (wraps) {  // frame complete
+            if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // a box of one chunk: see resize_mfma_frame_stream_kernel
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];

@@ -119,6 +119,19 @@ bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_
     return stream_class(w, &nb) == 1 || resize_wavestream_applies(w, knob);  // the chunk form (frames up to 512 wide) or one block stream per wave
 }
 
+bool resize_short_prefers_stream(uint32_t w, uint32_t h)
+{
+    // Frames of at most 128 rows fuse resize and DCT in one kernel, one workgroup per clip (a frame at a time: 4 - 16 KB in flight per
+    // workgroup).  That is the faster form for small frames only.  Measured against the linear-stream kernels + dct_hash_kernel, round 5
+    // (TB/s of frame bytes, fused -> stream; gpurun_out/r05u, r05w = profiles/r05_short_frames.txt): 176 x 99 4.1 -> 4.1, 192 x 108 4.7 -> 4.8,
+    // 160 x 120 4.4 -> 4.7, 200 x 112 3.7 -> 4.8, 208 x 117 3.6 -> 5.4, 224 x 126 3.9 -> 5.8, 256 x 128 4.8 -> 6.1, 320 x 96 4.5 -> 6.1,
+    // 480 x 128 4.1 -> 6.4, 640 x 120 3.9 -> 5.8, 854 x 128 2.5 -> 5.7, 1920 x 128 3.5 -> 6.0, 1920 x 64 4.7 -> 6.0; the other way:
+    // 128 x 128 4.8 -> 4.3, 160 x 90 4.2 -> 3.8, 192 x 80 4.3 -> 4.0, 128 x 96 4.6 -> 3.5, 512 x 64 4.8 -> 4.2 (one chunk per frame).
+    if (h > 128) return false;  // (not asked: such frames never fuse)
+    if (w > 512) return h >= 64;  // the per-wave form
+    return h > 64 && (uint64_t)w * h >= 19000;
+}
+
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
 {
     uint32_t p = w;  // w % 16 == 0
