@@ -567,6 +567,7 @@ def test_frames_and_boxes_of_one_chunk_in_large_batches():
         want8 = np.stack([orc.hash_clip(np.ascontiguousarray(host8[c][:, t:h - b, l:w - r]))[1] for c in range(8)])
         ref_eng = engine_with(general)
         ref = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()  # the library's own stream does not wait for torch's fill
         ref_eng.hash_frames_cropped_device(frames.data_ptr(), n, 16, w, h, crops, ref.data_ptr())
         torch.cuda.synchronize()
         ref_eng.close()
@@ -574,6 +575,7 @@ def test_frames_and_boxes_of_one_chunk_in_large_batches():
         for rep in range(3):
             eng = vdf.Engine(0)
             out = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
             eng.hash_frames_cropped_device(frames.data_ptr(), n, 16, w, h, crops, out.data_ptr())
             torch.cuda.synchronize()
             eng.close()
@@ -585,12 +587,14 @@ def test_frames_and_boxes_of_one_chunk_in_large_batches():
         torch.cuda.synchronize()  # the library's own stream does not wait for torch's
         ref_eng = vdf.Engine(0)
         ref = torch.zeros((nn, 16), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
         ref_eng.hash_frames_device(frames.data_ptr(), nn, 16, ww, hh, ref.data_ptr())
         torch.cuda.synchronize()
         ref_eng.close()
         for rep in range(3):
             eng = engine_with({"VDF_RESIZE_MODE": "5"})
             out = torch.zeros((nn, 16), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
             eng.hash_frames_device(frames.data_ptr(), nn, 16, ww, hh, out.data_ptr())
             torch.cuda.synchronize()
             eng.close()

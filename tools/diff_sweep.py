@@ -61,6 +61,7 @@ for case in range(a.cases):
     if kind == 0:
         def call(eng):
             out = torch.zeros(out_shape, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()  # the library's stream does not wait for torch's fill
             eng.hash_frames_device(frames.data_ptr(), n, 16, w, h, out.data_ptr())
             return out
         ref = run({"VDF_RESIZE_MODE": "4"}, call)
@@ -88,6 +89,7 @@ for case in range(a.cases):
             crops[:] = np.array(pool, np.uint32)[rng.integers(0, len(pool), n)]
         def call(eng):
             out = torch.zeros(out_shape, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()  # the library's stream does not wait for torch's fill
             eng.hash_frames_cropped_device(frames.data_ptr(), n, 16, w, h, crops, out.data_ptr())
             return out
         ref = run({"VDF_RESIZE_MODE": "4", "VDF_NO_ROWCROP": "1"}, call)
