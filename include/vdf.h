@@ -21,6 +21,8 @@
  *     context's GPU) and a hipStream_t passed as void* (NULL = the context's own non-blocking
  *     stream, NOT the legacy default stream) and need a single-device context; everything else
  *     takes host pointers (or, *_shards, one device pointer per GPU of a multi-GPU context).
+ *     Stream order is all the ordering there is: work the caller queued on ANOTHER stream - a fill of the output buffer, the
+ *     decoder's writes of the frames - is not waited for.  Pass the stream that work is on, or finish it first.
  *   - The search calls need their (candidate) arrays in sorted order and return VDF_E_INVAL when the
  *     durations are not ascending.
  *   - vdf_ctx_create() binds a context to one GPU.  vdf_ctx_create_multi() makes ONE context over several GPUs of
