@@ -61,6 +61,13 @@ for case in range(a.cases):
     order = np.argsort(dur, kind="stable")
     words, dur = np.ascontiguousarray(words[order]), np.ascontiguousarray(dur[order])
     ref = engines[1].search_self_sorted(words, dur, tol)
+    # search_with_references: references in the caller's order (unsorted durations), drawn from the database and from nowhere
+    nr = int(rng.integers(1, max(2, n // 10)))
+    ridx = rng.integers(0, n, nr)
+    rw, rd = words[ridx].copy(), dur[ridx].copy()
+    fresh = rng.random(nr) < 0.3
+    rw[fresh] = rng.integers(0, 2 ** 64, size=(int(fresh.sum()), 16), dtype=np.uint64)
+    ref_r = engines[1].search_refs_sorted(words, dur, rw, rd, tol)
     line = []
     for G in (2, 3, 4):
         got = engines[G].search_self_sorted(words, dur, tol)
@@ -76,7 +83,8 @@ for case in range(a.cases):
         got2 = engines[G].search_self_shards([t.data_ptr() for t in sw], [t.data_ptr() for t in sd], sizes, tol)
         ok2 = got2 == ref
         tm = engines[G].last_timing()
-        n_bad += (not ok) + (not ok2)
-        line.append(f"G={G}: host {'same' if ok else 'DIFFERENT'}, shards {'same' if ok2 else 'DIFFERENT'} (filtered {tm['hits_filtered']})")
-    print(f"[{case}] n={n} tol={tol} style {('sparse', 'clustered', 'dense')[style]}: groups {len(ref)} members {sum(len(g) for g in ref)}: " + "; ".join(line), flush=True)
+        ok3 = engines[G].search_refs_sorted(words, dur, rw, rd, tol) == ref_r
+        n_bad += (not ok) + (not ok2) + (not ok3)
+        line.append(f"G={G}: host {'same' if ok else 'DIFFERENT'}, shards {'same' if ok2 else 'DIFFERENT'} (filtered {tm['hits_filtered']}), refs {'same' if ok3 else 'DIFFERENT'}")
+    print(f"[{case}] n={n} tol={tol} style {('sparse', 'clustered', 'dense')[style]}: groups {len(ref)} members {sum(len(g) for g in ref)}, {nr} refs -> {len(ref_r)} groups: " + "; ".join(line), flush=True)
 print(f"== {a.cases} cases, {n_bad} differing")
