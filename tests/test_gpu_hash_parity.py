@@ -153,6 +153,42 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("h,w", [(48, 80), (64, 96), (80, 80), (96, 96), (112, 112), (72, 128), (96, 128), (128, 128), (128, 64), (96, 64), (100, 48),
+                                 (63, 112), (128, 32), (100, 16), (17, 128), (65, 64), (64, 80), (65, 80), (127, 127 - 15), (128, 16), (16, 128)])
+def test_tiled_persistent_kernel_matches_oracle_and_the_per_clip_kernel(h, w, monkeypatch):
+    """Round 5: frames of up to 128 x 128 whose width is a multiple of 16 (and that are not a single 64 x 64 tile) take
+    resize_dct_hash_tiled_kernel - persistent workgroups, units of eight 16-byte loads per lane in two register buffers, the next clip's first
+    unit in flight under the DCT.  All three shapes (2 x 1, 1 x 2, 2 x 2 tiles; the last one in row-group units), partial tiles in both
+    directions, more clips than resident workgroups (the persistent loop runs several times), the first clips against the oracle and every
+    clip against the one-workgroup-per-clip kernel (VDF_HASH_NO_PERSISTENT)."""
+    import torch
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(7000 + h * 7 + w)
+    n = 2000
+    frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+    d = torch.from_numpy(frames).cuda()
+    outs = {}
+    for name, env in (("tiled", {}), ("per_clip", {"VDF_HASH_NO_PERSISTENT": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = vdf.Engine(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        try:
+            if name == "tiled":
+                _check(eng, frames[:48])
+            out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.hash_frames_device(d.data_ptr(), n, 16, w, h, out.data_ptr())
+            torch.cuda.synchronize()
+            outs[name] = out
+        finally:
+            eng.close()
+    assert torch.equal(outs["tiled"], outs["per_clip"])
+
+
 @pytest.mark.parametrize("mode", [0, 3, 5])
 @pytest.mark.parametrize("h,w,n", [(128, 256, 70), (126, 224, 70), (117, 208, 70), (112, 200, 70), (120, 160, 70), (108, 192, 70), (96, 320, 70),
                                    (128, 480, 50), (120, 640, 50), (128, 854, 45), (128, 1280, 40), (128, 1920, 36), (64, 1920, 40), (100, 1366, 40),

@@ -621,6 +621,112 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
     }
 }
 
+// Persistent form for frames of up to 128 x 128 (NKT x NRG tiles of 64 x 64, W % 16 == 0; round 5).  The one-workgroup-per-clip kernel above keeps
+// ONE tile's loads in flight per wave (4 KB) and its frames' streams end at every DCT: 96 x 64 read at 4.2 TB/s, 64 x 128 at 4.6, 32 x 128 at 2.7.
+// Here a wave issues its loads in UNITS of eight 16-byte loads per lane (8 KB per wave: a whole frame of up to two tiles, or one 64-row group
+// of a 2 x 2-tile frame) into one of two register buffers: unit u + 1 goes out before the products of unit u run, and the next clip's first
+// unit before the DCT - as in the 64 x 64 kernel, nothing of the stream waits for the DCT.  Tables (8 fragments at most) stay in registers.
+// (Whole 2 x 2-tile frames as units - 16 loads, 241 registers, two workgroups per CU - measured no better than the per-clip kernel: 128 x 128
+// 4.66 against 4.77 TB/s; the unit of eight keeps all three shapes at three workgroups per CU.)
+// Plain loads: two instructions share a 128-byte line here (see load_pixels16).  Same products, exact integer sums: bit-identical.
+// (WAVES = the register bound, waves per SIMD: the 2 x 2 shape needs it - 168 registers keep it at three workgroups per CU; put on the
+// two-tile shapes, which fit anyway, it changed their schedule for the worse: 80 x 48 5.3 -> 4.1 TB/s, 32 x 128 5.7 -> 3.8)
+template <int NKT, int NRG, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
+    const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
+    MfmaResizeTables T, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
+    uint32_t *__restrict__ out_dontcare, uint32_t n_clips)
+{
+    constexpr bool SPLIT = NKT * NRG > 2;        // a unit is one row group of a frame, not the frame
+    constexpr int RGU = SPLIT ? 1 : NRG;         // row groups per unit
+    constexpr int NU = 4 * (SPLIT ? NRG : 1);    // units per wave and clip (four frames)
+    static_assert(NU % 2 == 0, "the two buffers alternate: the next clip's first unit lands in buffer 0");
+    __shared__ DctShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    if (tid < 32) sh.words[tid] = 0u;
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    v4i bh[NKT][2], av[NRG][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; kt++) { bh[kt][0] = T.bh[(kt * 2 + 0) * 64 + lane]; bh[kt][1] = T.bh[(kt * 2 + 1) * 64 + lane]; }
+    if constexpr (!SPLIT) {
+#pragma unroll
+        for (int rg = 0; rg < NRG; rg++) { av[rg][0] = T.av[(rg * 2 + 0) * 64 + lane]; av[rg][1] = T.av[(rg * 2 + 1) * 64 + lane]; }
+    }
+    const int32_t bias_h = T.bias_h[r16];
+    const uint32_t f0 = 4 * wave;  // this wave's frames: 4 wave .. 4 wave + 3
+    const size_t lane_off = (size_t)r16 * W + 16u * g;
+    typedef v4i UnitPx[RGU][NKT][4];
+    auto issue = [&](size_t clip, int u, UnitPx &px) __attribute__((always_inline)) {
+        const int q = SPLIT ? u / NRG : u, rg0 = SPLIT ? u % NRG : 0;
+        const uint8_t *base = frames + clip * clip_stride + (size_t)(f0 + q) * frame_stride + lane_off;
+#pragma unroll
+        for (int ri = 0; ri < RGU; ri++)
+#pragma unroll
+            for (int kt = 0; kt < NKT; kt++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t row0 = 64u * (rg0 + ri) + 16u * m;
+                    px[ri][kt][m] = (v4i){0, 0, 0, 0};
+                    if (row0 + r16 < H && 64u * kt + 16u * g < W) px[ri][kt][m] = load_pixels16<false>(base + (size_t)row0 * W + 64 * kt, nullptr);
+                }
+    };
+    v4i vh = {0, 0, 0, 0}, vl = bias_v;  // the frame's vertical sums, carried over its units
+    auto products = [&](int u, const UnitPx &px) __attribute__((always_inline)) {
+        const int q = SPLIT ? u / NRG : u, rg0 = SPLIT ? u % NRG : 0;
+        // (2 x 2 tiles: the vertical fragments are fetched per unit - L1 hits, consumed behind the unit's sixteen products - instead of
+        // living in 16 registers: that is what keeps this shape at three workgroups per CU without a spill)
+        v4i avh_u = av[rg0][0], avl_u = av[rg0][1];
+        if constexpr (SPLIT) {
+            avh_u = T.av[(rg0 * 2 + 0) * 64 + lane];
+            avl_u = T.av[(rg0 * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int ri = 0; ri < RGU; ri++) {
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
+#pragma unroll
+                for (int kt = 0; kt < NKT; kt++) {
+                    const v4i a = px[ri][kt][m] ^ x80;
+                    ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh[kt][0], ah, 0, 0, 0);
+                    al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh[kt][1], al, 0, 0, 0);
+                }
+                b[m] = (int)finalize4(ah, al, T.prec_h);
+            }
+            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(SPLIT ? avh_u : av[rg0 + ri][0], b, vh, 0, 0, 0);
+            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(SPLIT ? avl_u : av[rg0 + ri][1], b, vl, 0, 0, 0);
+        }
+        if (rg0 + RGU == NRG) {  // the frame's last unit
+            sh.cube[(f0 + q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+            vh = (v4i){0, 0, 0, 0};
+            vl = bias_v;
+        }
+    };
+    UnitPx pa, pb;
+    uint32_t clip = blockIdx.x;
+    if (clip < n_clips) issue(clip, 0, pa);
+    while (clip < n_clips) {
+        const uint32_t next = clip + gridDim.x;
+        __builtin_amdgcn_s_setprio(3);  // as in the 64 x 64 kernel: the resize releases the loads the stream lives on
+#pragma unroll
+        for (int u = 0; u < NU; u += 2) {
+            issue(clip, u + 1, pb);
+            products(u, pa);
+            if (u + 2 < NU) issue(clip, u + 2, pa);
+            else if (next < n_clips) issue(next, 0, pa);  // in flight during the whole DCT below
+            products(u + 1, pb);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
+        clip = next;
+    }
+}
+
 // ---- large frames, coalesced ------------------------------------------------------------------------------
 // Large frames, one workgroup per frame; the four waves' vertical partial sums (exact i32) are added through LDS and the 16 x 16
 // u8 frame goes to `small`.  The natural A-operand shape (lane = row, 16 bytes of one K tile: resize_row_blocks) makes every
@@ -1916,6 +2022,23 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
             hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<false>, dim3(grid), dim3(256), 0, stream, frames, w, h,
                                frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
                                (uint32_t)n_clips);
+    } else if (a.n_kt <= 2 && a.n_rg <= 2 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+        // up to 128 x 128: units of eight loads per lane in flight, persistent
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+#define VDF_TILED(KERNEL)                                                                                                       \
+    do {                                                                                                                         \
+        int per_cu = 3;                                                                                                          \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess || per_cu < 1) per_cu = 3;       \
+        const uint32_t grid = (uint32_t)std::min<size_t>(n_clips, (size_t)cus * (size_t)per_cu);                                 \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, make_tables(a),    \
+                           cos_table, out_hashes, out_dontcare, (uint32_t)n_clips);                                              \
+    } while (0)
+        if (a.n_kt == 2 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 2, 3>));
+        else if (a.n_kt == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 1, 1>));
+        else VDF_TILED((resize_dct_hash_tiled_kernel<1, 2, 1>));
+#undef VDF_TILED
     } else if (a.n_kt == 1 && a.n_rg == 1)
         hipLaunchKernelGGL(resize_dct_hash_fused_kernel<true>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w,
                            h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes, out_dontcare);
