@@ -419,30 +419,38 @@ __device__ __forceinline__ bool columns_narrow(const uint8_t *__restrict__ f, ui
 #pragma unroll
     for (uint32_t j = 0; j < ND; j++) ce[j] = co[j] = vdf_u16x2{0u, 0u};
     vdf_u16x2 worst = {0u, 0u};              // max over everything seen of (pixel - row 0's pixel + half) mod 2^16: <= tol iff inside the window
-    for (uint32_t i0 = 0; i0 < H; i0 += 64u * INFL) {
+    auto look = [&](const UW &v) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t j = 0; j < ND; j++) {
+            const uint32_t d = v.d[j];
+            const vdf_u16x2 e = __builtin_bit_cast(vdf_u16x2, d & 0x00FF00FFu), o = __builtin_bit_cast(vdf_u16x2, (d >> 8) & 0x00FF00FFu);
+            worst = __builtin_elementwise_max(__builtin_elementwise_max(worst, e + ce[j]), o + co[j]);
+        }
+    };
+    auto outside = [&]() __attribute__((always_inline)) {  // wave-uniform
+        const uint32_t wx = worst.x, wy = worst.y;
+        return __builtin_amdgcn_ballot_w64((wx > wy ? wx : wy) > tol) != 0ull;
+    };
+    {   // The first 64 rows on their own, one load per lane: the window where the picture begins - every walk ends in three or four of them -
+        // fails here for a quarter or an eighth of what a full first round reads (the side walk is bound by its HBM transactions).
+        // (unconditional loads at a clamped row: a clamped lane looks at the last row again)
+        const UW v = *reinterpret_cast<const UW *>(f + (size_t)min(lane, H - 1) * W + x0);
+#pragma unroll
+        for (uint32_t j = 0; j < ND; j++) {  // lane 0: row 0
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.d[j]);
+            ce[j] = vdf_u16x2{(unsigned short)(half - (r0 & 255u)), (unsigned short)(half - ((r0 >> 16) & 255u))};
+            co[j] = vdf_u16x2{(unsigned short)(half - ((r0 >> 8) & 255u)), (unsigned short)(half - (r0 >> 24))};
+        }
+        look(v);
+        if (outside()) return false;
+    }
+    for (uint32_t i0 = 64; i0 < H; i0 += 64u * INFL) {
         UW v[INFL];
 #pragma unroll
-        for (int k = 0; k < INFL; k++) {  // unconditional loads at a clamped row (a clamped lane looks at the last row again)
-            const uint32_t row = min(i0 + 64u * k + lane, H - 1);
-            v[k] = *reinterpret_cast<const UW *>(f + (size_t)row * W + x0);
-        }
-        if (i0 == 0) {
+        for (int k = 0; k < INFL; k++) v[k] = *reinterpret_cast<const UW *>(f + (size_t)min(i0 + 64u * k + lane, H - 1) * W + x0);
 #pragma unroll
-            for (uint32_t j = 0; j < ND; j++) {  // lane 0, k = 0: row 0
-                const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0].d[j]);
-                ce[j] = vdf_u16x2{(unsigned short)(half - (r0 & 255u)), (unsigned short)(half - ((r0 >> 16) & 255u))};
-                co[j] = vdf_u16x2{(unsigned short)(half - ((r0 >> 8) & 255u)), (unsigned short)(half - (r0 >> 24))};
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < INFL; k++)
-#pragma unroll
-            for (uint32_t j = 0; j < ND; j++) {
-                const uint32_t d = v[k].d[j];
-                const vdf_u16x2 e = __builtin_bit_cast(vdf_u16x2, d & 0x00FF00FFu), o = __builtin_bit_cast(vdf_u16x2, (d >> 8) & 0x00FF00FFu);
-                worst = __builtin_elementwise_max(__builtin_elementwise_max(worst, e + ce[j]), o + co[j]);
-            }
-        if (__builtin_amdgcn_ballot_w64(max((uint32_t)worst.x, (uint32_t)worst.y) > tol) != 0ull) return false;  // wave-uniform
+        for (int k = 0; k < INFL; k++) look(v[k]);
+        if (outside()) return false;
     }
     return true;
 }
