@@ -88,7 +88,8 @@ int main()
         CHECK(!resize_stream_eligible(aligned, w, 1080, (size_t)w * 1080, (size_t)w * 1080 * 16), "%u wide should not stream by default", w);
     // short frames (at most 128 rows: the fused kernel's range): the wide ones stream (round 5, measured)
     struct { uint32_t w, h; bool stream; } shorts[] = {{64, 64, false}, {128, 128, false}, {160, 90, false}, {128, 96, false}, {192, 80, false}, {512, 64, false},
-                                                       {160, 120, true}, {192, 108, true}, {224, 126, true}, {256, 128, true}, {320, 96, true}, {480, 128, true},
+                                                       {160, 120, false}, {192, 108, false}, {208, 112, false}, {208, 117, true}, {192, 128, true}, {200, 112, true}, {224, 126, true},
+                                                       {256, 128, true}, {320, 96, true}, {480, 128, true},
                                                        {640, 120, true}, {854, 128, true}, {1920, 128, true}, {1920, 64, true}, {1920, 48, false}, {1920, 129, false}};
     for (auto &q : shorts) CHECK(resize_short_prefers_stream(q.w, q.h) == q.stream, "short frame %u x %u: stream %d", q.w, q.h, (int)q.stream);
     // the per-wave block streams: every M-class width (from 462 columns) whose pitch is at most 1920, with as many waves as block buffers fit; the (whole-KB) block

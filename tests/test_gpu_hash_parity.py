@@ -154,13 +154,17 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
 
 
 @pytest.mark.parametrize("h,w", [(48, 80), (64, 96), (80, 80), (96, 96), (112, 112), (72, 128), (96, 128), (128, 128), (128, 64), (96, 64), (100, 48),
-                                 (63, 112), (128, 32), (100, 16), (17, 128), (65, 64), (64, 80), (65, 80), (127, 127 - 15), (128, 16), (16, 128)])
+                                 (63, 112), (128, 32), (100, 16), (17, 128), (65, 64), (64, 80), (65, 80), (127, 127 - 15), (128, 16), (16, 128),
+                                 (81, 144), (90, 160), (120, 160), (99, 176), (108, 192), (64, 192), (33, 176), (128, 144), (128, 192), (65, 160),
+                                 (117, 208), (126, 224), (64, 256), (96, 256), (128, 256), (100, 240), (17, 256), (48, 208)])
 def test_tiled_persistent_kernel_matches_oracle_and_the_per_clip_kernel(h, w, monkeypatch):
-    """Round 5: frames of up to 128 x 128 whose width is a multiple of 16 (and that are not a single 64 x 64 tile) take
-    resize_dct_hash_tiled_kernel - persistent workgroups, units of eight 16-byte loads per lane in two register buffers, the next clip's first
-    unit in flight under the DCT.  All three shapes (2 x 1, 1 x 2, 2 x 2 tiles; the last one in row-group units), partial tiles in both
+    """Round 5: frames of up to 256 x 128 whose width is a multiple of 16 (and that are not a single 64 x 64 tile) take
+    resize_dct_hash_tiled_kernel - persistent workgroups, units of (at most) eight 16-byte loads per lane in two register buffers, the next
+    clip's first unit in flight under the DCT.  All seven shapes (2 x 1, 1 x 2 tiles: a frame per unit; 2 x 2: a row group per unit; 3 and 4
+    K tiles x 1 and 2 row groups: half a row group per unit, the block results carried between the halves), partial tiles in both
     directions, more clips than resident workgroups (the persistent loop runs several times), the first clips against the oracle and every
-    clip against the one-workgroup-per-clip kernel (VDF_HASH_NO_PERSISTENT)."""
+    clip against the one-workgroup-per-clip kernel (VDF_HASH_NO_PERSISTENT) - through the fused family by force (VDF_RESIZE_MODE=3), since
+    the default dispatch hands the largest of these sizes to the stream kernels."""
     import torch
 
     import vid_dup_finder_lib_amd as vdf
@@ -170,7 +174,7 @@ def test_tiled_persistent_kernel_matches_oracle_and_the_per_clip_kernel(h, w, mo
     frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
     d = torch.from_numpy(frames).cuda()
     outs = {}
-    for name, env in (("tiled", {}), ("per_clip", {"VDF_HASH_NO_PERSISTENT": "1"})):
+    for name, env in (("tiled", {"VDF_RESIZE_MODE": "3"}), ("per_clip", {"VDF_RESIZE_MODE": "3", "VDF_HASH_NO_PERSISTENT": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = vdf.Engine(0)

@@ -9,7 +9,12 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 g = torch.Generator(device=dev); g.manual_seed(1)
 print("# w x h: clips | per-clip kernel | tiled persistent   (TB/s of frame bytes)")
-for w, h in [(80, 48), (96, 64), (80, 80), (96, 96), (112, 112), (128, 72), (128, 96), (128, 128), (64, 128), (64, 96), (48, 100), (128, 64), (112, 63), (160, 90), (32, 128), (16, 100), (128, 17)]:
+SIZES = [(80, 48), (96, 64), (80, 80), (96, 96), (112, 112), (128, 72), (128, 96), (128, 128), (64, 128), (64, 96), (48, 100), (128, 64), (112, 63), (32, 128), (16, 100), (128, 17),
+         (144, 81), (160, 90), (160, 120), (176, 99), (192, 108), (192, 64), (192, 80), (160, 64), (144, 128), (192, 128),
+         (208, 117), (224, 126), (256, 64), (256, 96), (256, 128), (240, 100), (208, 80)]
+if len(sys.argv) > 1:
+    SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1].split(",")]
+for w, h in SIZES:
     n = max(96, min(400_000, 1500 * 1_000_000 // (16 * w * h)))
     frames = torch.randint(0, 256, (n, 16, h, w), dtype=torch.uint8, device=dev, generator=g)
     torch.cuda.synchronize()

@@ -631,15 +631,19 @@ __global__ __launch_bounds__(256) void resize_dct_hash_persistent_kernel(
 // Plain loads: two instructions share a 128-byte line here (see load_pixels16).  Same products, exact integer sums: bit-identical.
 // (WAVES = the register bound, waves per SIMD: the 2 x 2 shape needs it - 168 registers keep it at three workgroups per CU; put on the
 // two-tile shapes, which fit anyway, it changed their schedule for the worse: 80 x 48 5.3 -> 4.1 TB/s, 32 x 128 5.7 -> 3.8)
+// Three or four K tiles (129 ... 256 columns): a unit is TWO of the four 16-row blocks of a row group (2 x NKT loads); the block results wait
+// in `b` for the row group's second unit, whose end is the vertical product.
 template <int NKT, int NRG, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
     MfmaResizeTables T, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
     uint32_t *__restrict__ out_dontcare, uint32_t n_clips)
 {
-    constexpr bool SPLIT = NKT * NRG > 2;        // a unit is one row group of a frame, not the frame
-    constexpr int RGU = SPLIT ? 1 : NRG;         // row groups per unit
-    constexpr int NU = 4 * (SPLIT ? NRG : 1);    // units per wave and clip (four frames)
+    constexpr int MU = NKT > 2 ? 2 : 4;                 // 16-row blocks per unit
+    constexpr int RGU = NKT * NRG <= 2 ? NRG : 1;       // row groups per unit (the whole frame where that is eight loads)
+    constexpr int UPF = (NRG / RGU) * (4 / MU);         // units per frame
+    constexpr int NU = 4 * UPF;                         // units per wave and clip (four frames)
+    constexpr bool FETCH_AV = UPF > 1;                  // vertical fragments fetched per unit instead of living in registers
     static_assert(NU % 2 == 0, "the two buffers alternate: the next clip's first unit lands in buffer 0");
     __shared__ DctShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
@@ -651,56 +655,60 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     v4i bh[NKT][2], av[NRG][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; kt++) { bh[kt][0] = T.bh[(kt * 2 + 0) * 64 + lane]; bh[kt][1] = T.bh[(kt * 2 + 1) * 64 + lane]; }
-    if constexpr (!SPLIT) {
+    if constexpr (!FETCH_AV) {
 #pragma unroll
         for (int rg = 0; rg < NRG; rg++) { av[rg][0] = T.av[(rg * 2 + 0) * 64 + lane]; av[rg][1] = T.av[(rg * 2 + 1) * 64 + lane]; }
     }
     const int32_t bias_h = T.bias_h[r16];
     const uint32_t f0 = 4 * wave;  // this wave's frames: 4 wave .. 4 wave + 3
     const size_t lane_off = (size_t)r16 * W + 16u * g;
-    typedef v4i UnitPx[RGU][NKT][4];
+    typedef v4i UnitPx[RGU][NKT][MU];
     auto issue = [&](size_t clip, int u, UnitPx &px) __attribute__((always_inline)) {
-        const int q = SPLIT ? u / NRG : u, rg0 = SPLIT ? u % NRG : 0;
+        const int q = u / UPF, r = u % UPF, rg0 = RGU > 1 ? 0 : r / (4 / MU), m0 = (r % (4 / MU)) * MU;
         const uint8_t *base = frames + clip * clip_stride + (size_t)(f0 + q) * frame_stride + lane_off;
 #pragma unroll
         for (int ri = 0; ri < RGU; ri++)
 #pragma unroll
             for (int kt = 0; kt < NKT; kt++)
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const uint32_t row0 = 64u * (rg0 + ri) + 16u * m;
-                    px[ri][kt][m] = (v4i){0, 0, 0, 0};
-                    if (row0 + r16 < H && 64u * kt + 16u * g < W) px[ri][kt][m] = load_pixels16<false>(base + (size_t)row0 * W + 64 * kt, nullptr);
+                for (int mi = 0; mi < MU; mi++) {
+                    const uint32_t row0 = 64u * (rg0 + ri) + 16u * (m0 + mi);
+                    px[ri][kt][mi] = (v4i){0, 0, 0, 0};
+                    if (row0 + r16 < H && 64u * kt + 16u * g < W) px[ri][kt][mi] = load_pixels16<false>(base + (size_t)row0 * W + 64 * kt, nullptr);
                 }
     };
     v4i vh = {0, 0, 0, 0}, vl = bias_v;  // the frame's vertical sums, carried over its units
+    v4i b = {0, 0, 0, 0};                // the row group's four block results, carried over its units (MU == 2)
     auto products = [&](int u, const UnitPx &px) __attribute__((always_inline)) {
-        const int q = SPLIT ? u / NRG : u, rg0 = SPLIT ? u % NRG : 0;
-        // (2 x 2 tiles: the vertical fragments are fetched per unit - L1 hits, consumed behind the unit's sixteen products - instead of
-        // living in 16 registers: that is what keeps this shape at three workgroups per CU without a spill)
+        const int q = u / UPF, r = u % UPF, rg0 = RGU > 1 ? 0 : r / (4 / MU), m0 = (r % (4 / MU)) * MU;
+        // (several units per frame: the vertical fragments are fetched per unit - L1 hits, consumed behind the unit's products - instead of
+        // living in 16 registers: that is what keeps the 2 x 2 shape at three workgroups per CU without a spill)
         v4i avh_u = av[rg0][0], avl_u = av[rg0][1];
-        if constexpr (SPLIT) {
-            avh_u = T.av[(rg0 * 2 + 0) * 64 + lane];
-            avl_u = T.av[(rg0 * 2 + 1) * 64 + lane];
+        if constexpr (FETCH_AV) {
+            if (m0 + MU == 4) {
+                avh_u = T.av[(rg0 * 2 + 0) * 64 + lane];
+                avl_u = T.av[(rg0 * 2 + 1) * 64 + lane];
+            }
         }
 #pragma unroll
         for (int ri = 0; ri < RGU; ri++) {
-            v4i b;
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
+            for (int mi = 0; mi < MU; mi++) {
                 v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
 #pragma unroll
                 for (int kt = 0; kt < NKT; kt++) {
-                    const v4i a = px[ri][kt][m] ^ x80;
+                    const v4i a = px[ri][kt][mi] ^ x80;
                     ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh[kt][0], ah, 0, 0, 0);
                     al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh[kt][1], al, 0, 0, 0);
                 }
-                b[m] = (int)finalize4(ah, al, T.prec_h);
+                b[m0 + mi] = (int)finalize4(ah, al, T.prec_h);
             }
-            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(SPLIT ? avh_u : av[rg0 + ri][0], b, vh, 0, 0, 0);
-            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(SPLIT ? avl_u : av[rg0 + ri][1], b, vl, 0, 0, 0);
+            if (m0 + MU == 4) {  // the row group's last unit
+                vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(FETCH_AV ? avh_u : av[rg0 + ri][0], b, vh, 0, 0, 0);
+                vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(FETCH_AV ? avl_u : av[rg0 + ri][1], b, vl, 0, 0, 0);
+            }
         }
-        if (rg0 + RGU == NRG) {  // the frame's last unit
+        if (rg0 + RGU == NRG && m0 + MU == 4) {  // the frame's last unit
             sh.cube[(f0 + q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
             vh = (v4i){0, 0, 0, 0};
             vl = bias_v;
@@ -2022,7 +2030,7 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
             hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<false>, dim3(grid), dim3(256), 0, stream, frames, w, h,
                                frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
                                (uint32_t)n_clips);
-    } else if (a.n_kt <= 2 && a.n_rg <= 2 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+    } else if (a.n_kt <= 4 && a.n_rg <= 2 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
         // up to 128 x 128: units of eight loads per lane in flight, persistent
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -2035,7 +2043,11 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
         hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, make_tables(a),    \
                            cos_table, out_hashes, out_dontcare, (uint32_t)n_clips);                                              \
     } while (0)
-        if (a.n_kt == 2 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 2, 3>));
+        if (a.n_kt == 4 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<4, 2, 2>));
+        else if (a.n_kt == 4) VDF_TILED((resize_dct_hash_tiled_kernel<4, 1, 2>));
+        else if (a.n_kt == 3 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<3, 2, 3>));
+        else if (a.n_kt == 3) VDF_TILED((resize_dct_hash_tiled_kernel<3, 1, 3>));
+        else if (a.n_kt == 2 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 2, 3>));
         else if (a.n_kt == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 1, 1>));
         else VDF_TILED((resize_dct_hash_tiled_kernel<1, 2, 1>));
 #undef VDF_TILED

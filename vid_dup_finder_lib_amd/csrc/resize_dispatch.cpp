@@ -127,8 +127,13 @@ bool resize_short_prefers_stream(uint32_t w, uint32_t h)
     // 160 x 120 4.4 -> 4.7, 200 x 112 3.7 -> 4.8, 208 x 117 3.6 -> 5.4, 224 x 126 3.9 -> 5.8, 256 x 128 4.8 -> 6.1, 320 x 96 4.5 -> 6.1,
     // 480 x 128 4.1 -> 6.4, 640 x 120 3.9 -> 5.8, 854 x 128 2.5 -> 5.7, 1920 x 128 3.5 -> 6.0, 1920 x 64 4.7 -> 6.0; the other way:
     // 128 x 128 4.8 -> 4.3, 160 x 90 4.2 -> 3.8, 192 x 80 4.3 -> 4.0, 128 x 96 4.6 -> 3.5, 512 x 64 4.8 -> 4.2 (one chunk per frame).
+    // Later in round 5 frames of up to 256 x 128 with W % 16 == 0 got a persistent kernel of their own (resize_dct_hash_tiled_kernel), which moved
+    // the line for those widths (tiled -> stream, gpurun_out/r06h against r05x): 160 x 120 5.3 -> 4.9, 192 x 108 5.6 -> 5.2, 192 x 128 5.7 -> 5.5,
+    // 208 x 117 5.4 -> 5.4, 224 x 126 5.8 -> 6.3, 256 x 128 5.7 -> 6.5.
     if (h > 128) return false;  // (not asked: such frames never fuse)
     if (w > 512) return h >= 64;  // the per-wave form
+    // (r06i, the same box for both: 192 x 128 5.7 -> 6.0, 208 x 117 5.5 -> 5.9, 240 x 100 5.4 -> 5.6, 256 x 96 6.0 -> 5.8: the line is at 24 000 pixels)
+    if (w <= 256 && w % 16 == 0) return h > 64 && (uint64_t)w * h >= 24000;  // the tiled kernel's widths
     return h > 64 && (uint64_t)w * h >= 19000;
 }
 
