@@ -532,10 +532,12 @@ int hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, ui
         // Resize on the matrix cores (exact i8 x i8 -> i32): small frames fuse the DCT into the same kernel.
         // frames taller than two 64-row groups go to the per-frame kernel; its whole-line form is the default
         // (round 5: except the wide, short ones that stream faster - resize_short_prefers_stream - where they are eligible to)
+        // (and the narrow ones of up to 256 rows that the tiled persistent kernel serves better than the stream kernels - resize_tall_prefers_tiled)
         const bool fused = ctx->resize_mode == 3 ||
                            (ctx->resize_mode == 0 && (h + 63) / 64 <= 2 &&
                             !(vdf::resize_short_prefers_stream(w, h) &&
-                              vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->wavestream_knob)));
+                              vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->wavestream_knob))) ||
+                           (ctx->resize_mode == 0 && !ctx->hash_no_persistent && vdf::resize_tall_prefers_tiled(w, h));
         // tightly packed frames stream linearly through LDS where that is the faster form (resize_stream_eligible)
         bool streamed = !fused && (ctx->resize_mode == 0 || ctx->resize_mode == 5) &&
                         vdf::resize_stream_eligible(d_frames, w, h, frame_stride, clip_stride, ctx->wavestream_knob);

@@ -640,8 +640,9 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     uint32_t *__restrict__ out_dontcare, uint32_t n_clips)
 {
     constexpr int MU = NKT > 2 ? 2 : 4;                 // 16-row blocks per unit
-    constexpr int RGU = NKT * NRG <= 2 ? NRG : 1;       // row groups per unit (the whole frame where that is eight loads)
+    constexpr int RGU = NKT == 1 && NRG >= 2 ? 2 : 1;   // row groups per unit: two where a row group is only four loads
     constexpr int UPF = (NRG / RGU) * (4 / MU);         // units per frame
+    static_assert(NRG % RGU == 0, "whole units");
     constexpr int NU = 4 * UPF;                         // units per wave and clip (four frames)
     constexpr bool FETCH_AV = UPF > 1;                  // vertical fragments fetched per unit instead of living in registers
     static_assert(NU % 2 == 0, "the two buffers alternate: the next clip's first unit lands in buffer 0");
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     v4i bh[NKT][2], av[NRG][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; kt++) { bh[kt][0] = T.bh[(kt * 2 + 0) * 64 + lane]; bh[kt][1] = T.bh[(kt * 2 + 1) * 64 + lane]; }
+    static_assert(FETCH_AV || NRG < 3, "fragments in registers: every row group exists");
     if constexpr (!FETCH_AV) {
 #pragma unroll
         for (int rg = 0; rg < NRG; rg++) { av[rg][0] = T.av[(rg * 2 + 0) * 64 + lane]; av[rg][1] = T.av[(rg * 2 + 1) * 64 + lane]; }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     const size_t lane_off = (size_t)r16 * W + 16u * g;
     typedef v4i UnitPx[RGU][NKT][MU];
     auto issue = [&](size_t clip, int u, UnitPx &px) __attribute__((always_inline)) {
-        const int q = u / UPF, r = u % UPF, rg0 = RGU > 1 ? 0 : r / (4 / MU), m0 = (r % (4 / MU)) * MU;
+        const int q = u / UPF, r = u % UPF, rg0 = (r / (4 / MU)) * RGU, m0 = (r % (4 / MU)) * MU;
         const uint8_t *base = frames + clip * clip_stride + (size_t)(f0 + q) * frame_stride + lane_off;
 #pragma unroll
         for (int ri = 0; ri < RGU; ri++)
@@ -680,18 +682,20 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
     v4i vh = {0, 0, 0, 0}, vl = bias_v;  // the frame's vertical sums, carried over its units
     v4i b = {0, 0, 0, 0};                // the row group's four block results, carried over its units (MU == 2)
     auto products = [&](int u, const UnitPx &px) __attribute__((always_inline)) {
-        const int q = u / UPF, r = u % UPF, rg0 = RGU > 1 ? 0 : r / (4 / MU), m0 = (r % (4 / MU)) * MU;
-        // (several units per frame: the vertical fragments are fetched per unit - L1 hits, consumed behind the unit's products - instead of
-        // living in 16 registers: that is what keeps the 2 x 2 shape at three workgroups per CU without a spill)
-        v4i avh_u = av[rg0][0], avl_u = av[rg0][1];
-        if constexpr (FETCH_AV) {
-            if (m0 + MU == 4) {
-                avh_u = T.av[(rg0 * 2 + 0) * 64 + lane];
-                avl_u = T.av[(rg0 * 2 + 1) * 64 + lane];
-            }
-        }
+        const int q = u / UPF, r = u % UPF, rg0 = (r / (4 / MU)) * RGU, m0 = (r % (4 / MU)) * MU;
 #pragma unroll
         for (int ri = 0; ri < RGU; ri++) {
+            // (several units per frame: the vertical fragments are fetched per row group - L1 hits, consumed behind the unit's products - instead
+            // of living in up to 32 registers: that is what keeps the 2 x 2 shape at three workgroups per CU without a spill.  NRG = 4 also
+            // serves frames of three row groups: the fourth has no rows - no loads - and no fragments)
+            const bool live = NRG < 3 || rg0 + ri < T.n_rg;  // workgroup-uniform
+            v4i avh_u = {0, 0, 0, 0}, avl_u = {0, 0, 0, 0};
+            if constexpr (FETCH_AV) {
+                if (m0 + MU == 4 && live) {
+                    avh_u = T.av[((rg0 + ri) * 2 + 0) * 64 + lane];
+                    avl_u = T.av[((rg0 + ri) * 2 + 1) * 64 + lane];
+                }
+            }
 #pragma unroll
             for (int mi = 0; mi < MU; mi++) {
                 v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256, WAVES) void resize_dct_hash_tiled_kernel(
                 }
                 b[m0 + mi] = (int)finalize4(ah, al, T.prec_h);
             }
-            if (m0 + MU == 4) {  // the row group's last unit
+            if (m0 + MU == 4 && live) {  // the row group's last unit
                 vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(FETCH_AV ? avh_u : av[rg0 + ri][0], b, vh, 0, 0, 0);
                 vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(FETCH_AV ? avl_u : av[rg0 + ri][1], b, vl, 0, 0, 0);
             }
@@ -2030,7 +2034,7 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
             hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<false>, dim3(grid), dim3(256), 0, stream, frames, w, h,
                                frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
                                (uint32_t)n_clips);
-    } else if (a.n_kt <= 4 && a.n_rg <= 2 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+    } else if (a.n_kt <= 4 && a.n_rg <= 4 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
         // up to 128 x 128: units of eight loads per lane in flight, persistent
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -2043,7 +2047,12 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
         hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride, make_tables(a),    \
                            cos_table, out_hashes, out_dontcare, (uint32_t)n_clips);                                              \
     } while (0)
-        if (a.n_kt == 4 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<4, 2, 2>));
+        if (a.n_rg > 2) {  // 129 ... 256 rows: four row groups (the fourth may be empty)
+            if (a.n_kt == 4) VDF_TILED((resize_dct_hash_tiled_kernel<4, 4, 2>));
+            else if (a.n_kt == 3) VDF_TILED((resize_dct_hash_tiled_kernel<3, 4, 3>));
+            else if (a.n_kt == 2) VDF_TILED((resize_dct_hash_tiled_kernel<2, 4, 2>));
+            else VDF_TILED((resize_dct_hash_tiled_kernel<1, 4, 3>));
+        } else if (a.n_kt == 4 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<4, 2, 2>));
         else if (a.n_kt == 4) VDF_TILED((resize_dct_hash_tiled_kernel<4, 1, 2>));
         else if (a.n_kt == 3 && a.n_rg == 2) VDF_TILED((resize_dct_hash_tiled_kernel<3, 2, 3>));
         else if (a.n_kt == 3) VDF_TILED((resize_dct_hash_tiled_kernel<3, 1, 3>));

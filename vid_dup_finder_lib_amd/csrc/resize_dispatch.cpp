@@ -137,6 +137,16 @@ bool resize_short_prefers_stream(uint32_t w, uint32_t h)
     return h > 64 && (uint64_t)w * h >= 19000;
 }
 
+bool resize_tall_prefers_tiled(uint32_t w, uint32_t h)
+{
+    // Narrow frames of 129 ... 256 rows: the chunk-stream kernel moves 64 rows at a time whatever the width - 11 KB of a 176-wide frame, 4 KB of
+    // a 64-wide one, two workgroups per CU: latency-bound.  The tiled persistent kernel (four row groups) keeps 16 KB per wave in flight.
+    // Measured, stream -> tiled (TB/s, gpurun_out/r06l = profiles/r05_short_frames.txt): 64 x 160 2.4 -> 5.5, 64 x 256 2.7 -> 4.9, 80 x 240 3.1 -> 5.2,
+    // 96 x 160 3.2 -> 5.1, 112 x 200 3.5 -> 5.4, 128 x 160 4.0 -> 5.4, 128 x 256 4.8 -> 5.4, 160 x 144 4.3 -> 4.9, 160 x 200 4.6 -> 5.0,
+    // 176 x 144 4.6 -> 5.1; level at 144 x 256, 176 x 208, 192 x 144; the other way from there: 208 x 160 5.4 -> 5.0, 240 x 160 6.1 -> 5.0.
+    return h > 128 && h <= 256 && w >= 16 && w <= 176 && w % 16 == 0 && (uint64_t)w * h <= 36000;
+}
+
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
 {
     uint32_t p = w;  // w % 16 == 0

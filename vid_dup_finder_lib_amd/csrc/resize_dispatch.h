@@ -67,6 +67,8 @@ bool resize_rowcrop_streams(uint32_t w);
 bool resize_stream_eligible(const uint8_t *frames, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, int knob = 0);
 // frames of at most 128 rows (the fused kernel's range) that measured faster on the stream kernels: wide, short ones
 bool resize_short_prefers_stream(uint32_t w, uint32_t h);
+// narrow frames of 129 ... 256 rows that measured faster on the tiled persistent kernel (the fused family) than on the stream kernels
+bool resize_tall_prefers_tiled(uint32_t w, uint32_t h);
 
 // K-split form (1024..4096 columns, a multiple of 16): LDS pitch (an odd multiple of 16) and blocks per chunk (0: does not fit)
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp);
