@@ -38,6 +38,7 @@ KNOBS = [
     ({"VDF_NO_ROWCROP": "1"}, "mfma"),
     ({"VDF_ROWCROP_ALL": "1"}, "mfma"),
     ({"VDF_NO_BOXSTREAM": "1"}, "mfma"),
+    ({"VDF_NO_SMALLCROP": "1"}, "mfma"),
     ({"VDF_NO_HIT_FILTER": "1"}, "mfma"),
     ({"VDF_CAND_CAPACITY": "64"}, "mfma"),
     ({"VDF_RESIZE_MODE": "4"}, "mfma"),
@@ -71,6 +72,15 @@ def workload():
     w["lb_want"] = np.stack([r[1] for r in res])
     w["lb_crops"] = np.array([r[3] for r in res], np.uint32)
     assert {tuple(c) for c in w["lb_crops"]} == {(0, 0, 90, 88), (160, 160, 0, 0), (0, 0, 0, 0)}  # the three shapes are what the oracle sees
+    # letterboxed small frames (64 x 64 and 90 x 160): one workgroup per clip since round 5 (VDF_NO_SMALLCROP: one per frame)
+    for key, (hh, ww) in (("lbs", (64, 64)), ("lbm", (90, 160))):
+        f = rng.integers(60, 200, size=(20, 16, hh, ww), dtype=np.uint8)
+        f[::2, :, :hh // 8] = 16
+        f[::2, :, -(hh // 7):] = 18
+        f[1::4, :, :, :ww // 9] = 15
+        res = [orc.hash_clip_letterbox(c) for c in f]
+        assert all(r[0] == 0 for r in res) and any(r[3] != (0, 0, 0, 0) for r in res)
+        w[key], w[key + "_want"], w[key + "_crops"] = f, np.stack([r[1] for r in res]), np.array([r[3] for r in res], np.uint32)
     words, dur = hg.planted_set(rng, 3000, n_clusters=60, durations="windowed")
     order = np.argsort(dur, kind="stable")
     w["words"], w["dur"] = words[order], dur[order]
@@ -102,8 +112,9 @@ def test_a_knob_never_changes_a_result(env, backend, workload, monkeypatch):
         assert np.array_equal(eng.hash_frames(w["small"]), w["small_want"])
         assert np.array_equal(eng.hash_frames(w["strided"]), w["strided_want"])
         assert np.array_equal(eng.hash_frames(w["wide"]), w["wide_want"])
-        got, crops = eng.hash_frames_letterbox(w["lb"])
-        assert np.array_equal(crops, w["lb_crops"]) and np.array_equal(got, w["lb_want"])
+        for key in ("lb", "lbs", "lbm"):
+            got, crops = eng.hash_frames_letterbox(w[key])
+            assert np.array_equal(crops, w[key + "_crops"]) and np.array_equal(got, w[key + "_want"]), key
         for tol in (350, 400):
             assert eng.search_self_sorted(w["words"], w["dur"], tol) == w["self_want"][tol]
         assert eng.search_refs_sorted(w["words"], w["dur"], w["words"][w["refs"]], w["dur"][w["refs"]], 350) == w["refs_want"]

@@ -535,6 +535,55 @@ def test_noisy_bars_are_accepted_by_their_range_and_wide_ranges_are_counted(engi
     assert tuple(want[14]) == (0, 0, 0, 0) and tuple(want[15]) == (0, 0, 0, 0)  # the "both ends common" bars are picture
 
 
+@pytest.mark.parametrize("h,w", [(64, 64), (48, 80), (96, 96), (128, 128), (90, 160), (100, 240), (128, 256), (33, 17), (64, 200), (120, 250), (17, 256), (128, 16)])
+def test_small_frames_crop_boxes_take_one_workgroup_per_clip(h, w):
+    """Round 5: crop boxes of small frames (at most 128 rows, 256 columns) go through resize_mfma_cropped_small_kernel - one workgroup per clip, a
+    wave per four frames - instead of one workgroup per frame.  Random boxes (none, rows only, sides only, all four, one-pixel and one-row boxes,
+    boxes that start off every alignment), 300 clips so that the last clips' loads reach the buffer's end (the careful loader), against the
+    oracle on the cropped copies and against the kernel before (VDF_NO_SMALLCROP)."""
+    import os
+
+    import vid_dup_finder_lib_amd as vdf
+
+    rng = np.random.default_rng(h * 11 + w)
+    n = 300
+    frames = rng.integers(0, 256, size=(n, 16, h, w), dtype=np.uint8)
+    crops = np.zeros((n, 4), np.uint32)
+    for c in range(n):
+        kind = c % 6
+        if kind == 0:
+            continue
+        t, b = (int(rng.integers(0, max(1, h // 2))) for _ in range(2))
+        l, r = (int(rng.integers(0, max(1, w // 2))) for _ in range(2))
+        if kind == 1: l = r = 0
+        if kind == 2: t = b = 0
+        if kind == 4: l, r, t, b = int(rng.integers(0, w)), 0, int(rng.integers(0, h)), 0; r = w - l - 1; b = h - t - 1  # one pixel
+        if kind == 5: t = int(rng.integers(0, h)); b = h - t - 1; l = r = 0                                               # one row
+        if t + b >= h: b = 0
+        if l + r >= w: r = 0
+        crops[c] = (l, r, t, b)
+    crops[n - 1] = (0, 0, h - 1, 0) if h > 1 else (0, 0, 0, 0)  # the last clip's box is the buffer's last row
+    want = np.stack([orc.hash_clip(np.ascontiguousarray(frames[c][:, crops[c][2]:h - crops[c][3], crops[c][0]:w - crops[c][1]]))[1] for c in range(n)])
+    d = torch.from_numpy(frames).cuda()
+    for env in ({}, {"VDF_NO_SMALLCROP": "1"}):
+        os.environ.update(env)
+        try:
+            eng = vdf.Engine(0)
+        finally:
+            for k in env:
+                os.environ.pop(k)
+        try:
+            out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.hash_frames_cropped_device(d.data_ptr(), n, 16, w, h, crops, out.data_ptr())
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint64)
+        finally:
+            eng.close()
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (env, bad[:8].tolist(), crops[bad[:8]].tolist())
+
+
 def test_frames_and_boxes_of_one_chunk_in_large_batches():
     """Round 5: a frame (or crop box) that fits ONE chunk of the chunk-stream kernels ends in the step that began with wave 0 reading the previous
     frame's partial sums, and nothing ordered that read before the other waves' next write - a wave without a block in a short chunk got

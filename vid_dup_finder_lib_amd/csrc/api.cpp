@@ -794,7 +794,9 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     // -- the whole-line cropped kernel, over `ids` (all clips, or the side-bar boxes of a mixed call whose full-width boxes stream)
     std::vector<vdf::CropClipDesc> desc;
     std::vector<vdf::CropTableEntry> entries;
-    const bool wide = w >= 192;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
+    // small frames (round 5): one workgroup per CLIP, a wave per four frames (resize_mfma_cropped_small_kernel) - plain vertical layout
+    const bool small_crop = !tall && w <= 256 && ctx->resize_mode == 0 && !ctx->no_smallcrop;
+    const bool wide = w >= 192 && !small_crop;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
     auto build_lines = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
         std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
         desc.assign(ids.size(), vdf::CropClipDesc{});
@@ -820,6 +822,11 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     };
     const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
     auto launch_lines = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
+        if (small_crop) {
+            VDF_HIP(ctx, vdf::launch_resize_mfma_cropped_small(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),
+                                                               bt.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), stream));
+            return VDF_OK;
+        }
         VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),
                                                      bt.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), wide, stream));
         return VDF_OK;
@@ -1031,6 +1038,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     ctx->no_rowcrop = std::getenv("VDF_NO_ROWCROP") != nullptr;
     ctx->rowcrop_all = std::getenv("VDF_ROWCROP_ALL") != nullptr;
     ctx->no_boxstream = std::getenv("VDF_NO_BOXSTREAM") != nullptr;
+    ctx->no_smallcrop = std::getenv("VDF_NO_SMALLCROP") != nullptr;
     if (std::getenv("VDF_LB_NC16")) ctx->lb_side_strips = 16;
     if (const char *s = std::getenv("VDF_COPY_THREADS")) { const int v = std::atoi(s); if (v >= 1 && v <= 64) ctx->copy_threads = v; }
     if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) { const long v = std::atol(s); if (v >= 1 && v <= 1024) ctx->host_chunk_bytes = (size_t)v << 20; }

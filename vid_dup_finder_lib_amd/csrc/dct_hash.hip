@@ -1985,6 +1985,60 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
     }
 }
 
+// Small frames (at most 128 rows, 256 columns; round 5): one workgroup per CLIP - a wave takes four of its frames, a frame's box whole (the
+// one-workgroup-per-clip kernel's resize_row_groups at the frame's pitch) - instead of one per frame: a 64 x 64 frame is one tile, and sixteen
+// workgroups of 256 threads per clip each did a quarter of one (20 000 letterboxed clips of 64 x 64: crop + hash 1.25 ms against 0.33 ms for
+// the same clips without bars).  Vertical tables in the plain layout (kMfmaLayoutVertical).
+__global__ __launch_bounds__(256) void resize_mfma_cropped_small_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
+                                                                        size_t frame_stride, size_t clip_stride,
+                                                                        const uint8_t *buf_end,
+                                                                        const CropClipDesc *__restrict__ desc,
+                                                                        const CropTableEntry *__restrict__ tables,
+                                                                        uint8_t *__restrict__ small)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const CropClipDesc d = desc[blockIdx.x];
+    const CropTableEntry th = tables[d.h_table], tv = tables[d.v_table];
+    MfmaResizeTables T;
+    T.bh = reinterpret_cast<const v4i *>(th.operand);
+    T.av = reinterpret_cast<const v4i *>(tv.operand);
+    T.bias_h = th.bias;
+    T.bias_v = tv.bias;
+    T.prec_h = th.precision;
+    T.prec_v = tv.precision;
+    T.n_kt = th.n_tiles;
+    T.n_rg = tv.n_tiles;
+    T.band_meta = nullptr;
+    T.band_stride = 0;
+    v4i bias_v;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t f = 4 * wave + q;
+        const uint8_t *src = frames + (size_t)d.src_clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
+        v4i vh = {0, 0, 0, 0}, vl = bias_v;
+        // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very end of the buffer
+        // needs the careful loader (wave-uniform test)
+        if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_groups<true>(src, d.w, d.h, buf_end, T, 0, 1, vh, vl, pitch);
+        else resize_row_groups<false>(src, d.w, d.h, buf_end, T, 0, 1, vh, vl, pitch);
+        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
+        uint8_t *dst = small + ((size_t)d.src_clip * 16 + f) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+    }
+}
+
+hipError_t launch_resize_mfma_cropped_small(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
+                                            size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
+                                            const CropTableEntry *tables, uint8_t *small, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    hipLaunchKernelGGL(resize_mfma_cropped_small_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, pitch, frame_stride,
+                       clip_stride, buf_end, desc, tables, small);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream)

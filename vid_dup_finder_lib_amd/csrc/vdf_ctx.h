@@ -161,6 +161,7 @@ struct vdf_ctx {
     // (Python writing os.environ while the multi-GPU worker threads hash), and decision and launcher must see the same value
     int wavestream_knob = 0;       // resize_dispatch.h: -1 = VDF_NO_WAVESTREAM, n > 0 = VDF_WAVESTREAM_NW=n
     bool no_rowcrop = false, rowcrop_all = false, no_boxstream = false;  // VDF_NO_ROWCROP / VDF_ROWCROP_ALL / VDF_NO_BOXSTREAM
+    bool no_smallcrop = false;  // VDF_NO_SMALLCROP: small frames' crop boxes through the one-workgroup-per-frame kernel (as before round 5)
     int lb_side_strips = 0;        // VDF_LB_NC16: 16 = the side walk never takes the 32-strip form
     int copy_threads = 0;          // VDF_COPY_THREADS (0: half the hardware threads, at most 8)
     size_t host_chunk_bytes = 32u << 20;  // VDF_HOST_CHUNK_MB: pinned staging chunk (x 2) of the host-frame path
