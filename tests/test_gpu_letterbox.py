@@ -537,7 +537,7 @@ def test_noisy_bars_are_accepted_by_their_range_and_wide_ranges_are_counted(engi
 
 @pytest.mark.parametrize("h,w", [(64, 64), (48, 80), (96, 96), (128, 128), (90, 160), (100, 240), (128, 256), (33, 17), (64, 200), (120, 250), (17, 256), (128, 16)])
 def test_small_frames_crop_boxes_take_one_workgroup_per_clip(h, w):
-    """Round 5: crop boxes of small frames (at most 128 rows, 256 columns) go through resize_mfma_cropped_small_kernel - one workgroup per clip, a
+    """Round 5: crop boxes of small frames (at most 128 rows, 256 columns) go through resize_dct_hash_cropped_small_kernel - one workgroup per clip, a
     wave per four frames - instead of one workgroup per frame.  Random boxes (none, rows only, sides only, all four, one-pixel and one-row boxes,
     boxes that start off every alignment), 300 clips so that the last clips' loads reach the buffer's end (the careful loader), against the
     oracle on the cropped copies and against the kernel before (VDF_NO_SMALLCROP)."""

@@ -660,6 +660,8 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     //  * the whole-line cropped kernel (below) - everything else: misaligned buffers, frames that do not end on 16 bytes, short frames,
     //    boxes whose tables do not fit the i8 split, VDF_RESIZE_MODE=4.
     const bool tall = (h + 63) / 64 > 2, ends16 = ((uint64_t)w * h) % 16 == 0 && (uint64_t)w * h < (1ull << 31);
+    // small frames (round 5): one workgroup per CLIP, a wave per four frames, resize + DCT (resize_dct_hash_cropped_small_kernel) - plain vertical layout
+    const bool small_crop = !tall && w <= 256 && ctx->resize_mode == 0 && !ctx->no_smallcrop;
     std::vector<uint32_t> rows_clips, side_clips;  // by box shape
     for (size_t c = 0; c < n_clips; c++) {
         const uint32_t l = crops[4 * c], r = crops[4 * c + 1], t = crops[4 * c + 2], b = crops[4 * c + 3];
@@ -788,14 +790,13 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
         return VDF_OK;
     };
     auto finish = [&]() -> int {
+        if (small_crop) return VDF_OK;  // every clip went through the small-frame kernel, which hashes too
         VDF_HIP(ctx, vdf::launch_dct_hash(ctx->small.as<uint8_t>(), 4096, 256, n_clips, ctx->cos_table.as<double>(), d_out, d_dc, stream));
         return VDF_OK;
     };
     // -- the whole-line cropped kernel, over `ids` (all clips, or the side-bar boxes of a mixed call whose full-width boxes stream)
     std::vector<vdf::CropClipDesc> desc;
     std::vector<vdf::CropTableEntry> entries;
-    // small frames (round 5): one workgroup per CLIP, a wave per four frames (resize_mfma_cropped_small_kernel) - plain vertical layout
-    const bool small_crop = !tall && w <= 256 && ctx->resize_mode == 0 && !ctx->no_smallcrop;
     const bool wide = w >= 192 && !small_crop;  // frames at least 1.5 windows wide read whole 128-byte lines (resize_row_quads)
     auto build_lines = [&](const std::vector<uint32_t> &ids, int *rc) -> bool {
         std::map<uint64_t, uint32_t> index;  // (size * 2 + vertical) -> entry
@@ -823,8 +824,8 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
     const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
     auto launch_lines = [&](size_t n_sub, DevBuf &bd, DevBuf &bt) -> int {
         if (small_crop) {
-            VDF_HIP(ctx, vdf::launch_resize_mfma_cropped_small(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),
-                                                               bt.as<vdf::CropTableEntry>(), ctx->small.as<uint8_t>(), stream));
+            VDF_HIP(ctx, vdf::launch_resize_dct_cropped_small(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),
+                                                              bt.as<vdf::CropTableEntry>(), ctx->cos_table.as<double>(), d_out, d_dc, stream));
             return VDF_OK;
         }
         VDF_HIP(ctx, vdf::launch_resize_mfma_cropped(d_frames, n_sub, w, frame_stride, clip_stride, buf_end, bd.as<vdf::CropClipDesc>(),

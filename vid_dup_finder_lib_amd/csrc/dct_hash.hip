@@ -1988,15 +1988,20 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
 // Small frames (at most 128 rows, 256 columns; round 5): one workgroup per CLIP - a wave takes four of its frames, a frame's box whole (the
 // one-workgroup-per-clip kernel's resize_row_groups at the frame's pitch) - instead of one per frame: a 64 x 64 frame is one tile, and sixteen
 // workgroups of 256 threads per clip each did a quarter of one (20 000 letterboxed clips of 64 x 64: crop + hash 1.25 ms against 0.33 ms for
-// the same clips without bars).  Vertical tables in the plain layout (kMfmaLayoutVertical).
-__global__ __launch_bounds__(256) void resize_mfma_cropped_small_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
-                                                                        size_t frame_stride, size_t clip_stride,
-                                                                        const uint8_t *buf_end,
-                                                                        const CropClipDesc *__restrict__ desc,
-                                                                        const CropTableEntry *__restrict__ tables,
-                                                                        uint8_t *__restrict__ small)
+// the same clips without bars).  Vertical tables in the plain layout (kMfmaLayoutVertical).  The DCT runs in the same workgroup (as in
+// resize_dct_hash_fused_kernel): no 16 x 16 frames through HBM, no second launch.
+__global__ __launch_bounds__(256) void resize_dct_hash_cropped_small_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
+                                                                            size_t frame_stride, size_t clip_stride,
+                                                                            const uint8_t *buf_end,
+                                                                            const CropClipDesc *__restrict__ desc,
+                                                                            const CropTableEntry *__restrict__ tables,
+                                                                            const double *__restrict__ cos_table,
+                                                                            uint64_t *__restrict__ out_hashes,
+                                                                            uint32_t *__restrict__ out_dontcare)
 {
+    __shared__ DctShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    if (tid < 32) sh.words[tid] = 0u;
     const CropClipDesc d = desc[blockIdx.x];
     const CropTableEntry th = tables[d.h_table], tv = tables[d.v_table];
     MfmaResizeTables T;
@@ -2022,20 +2027,20 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_small_kernel(const ui
         // needs the careful loader (wave-uniform test)
         if (src + (size_t)d.h * pitch + 64 > buf_end) resize_row_groups<true>(src, d.w, d.h, buf_end, T, 0, 1, vh, vl, pitch);
         else resize_row_groups<false>(src, d.w, d.h, buf_end, T, 0, 1, vh, vl, pitch);
-        const uint32_t px = finalize4(vh, vl, T.prec_v) ^ 0x80808080u;
-        uint8_t *dst = small + ((size_t)d.src_clip * 16 + f) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + r16] = (uint8_t)(px >> (8 * r));
+        sh.cube[f * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);  // centred bytes of out[oy = 4 g + r][x = r16], r = 0..3
     }
+    __syncthreads();
+    dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, d.src_clip, out_hashes, out_dontcare);
 }
 
-hipError_t launch_resize_mfma_cropped_small(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
-                                            size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
-                                            const CropTableEntry *tables, uint8_t *small, hipStream_t stream)
+hipError_t launch_resize_dct_cropped_small(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
+                                           size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
+                                           const CropTableEntry *tables, const double *cos_table, uint64_t *out_hashes,
+                                           uint32_t *out_dontcare, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_mfma_cropped_small_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, pitch, frame_stride,
-                       clip_stride, buf_end, desc, tables, small);
+    hipLaunchKernelGGL(resize_dct_hash_cropped_small_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, pitch, frame_stride,
+                       clip_stride, buf_end, desc, tables, cos_table, out_hashes, out_dontcare);
     return hipGetLastError();
 }
 

@@ -161,10 +161,11 @@ size_t letterbox_work_bytes(size_t n_clips, uint32_t frames_per_clip);
 // side_strips: 0 = by frame height (32 column strips per pass from 512 rows, 16 from 256, else 8), 16 = at most 16 (VDF_LB_NC16: A/B runs)
 hipError_t launch_letterbox(const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip, uint32_t w, uint32_t h,
                             size_t frame_stride, size_t clip_stride, uint32_t *crops, uint32_t *work, hipStream_t stream, int side_strips = 0);
-// small frames (at most 128 rows, 256 columns): one workgroup per clip; vertical tables in kMfmaLayoutVertical order
-hipError_t launch_resize_mfma_cropped_small(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
-                                            size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
-                                            const CropTableEntry *tables, uint8_t *small, hipStream_t stream);
+// small frames (at most 128 rows, 256 columns): one workgroup per clip, resize + DCT + hash; vertical tables in kMfmaLayoutVertical order
+hipError_t launch_resize_dct_cropped_small(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
+                                           size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
+                                           const CropTableEntry *tables, const double *cos_table, uint64_t *out_hashes,
+                                           uint32_t *out_dontcare, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);
