@@ -135,6 +135,7 @@ struct vdf_ctx {
     DevBuf small, frames, frames2, out_hashes, out_hashes2, out_dc, out_dc2, cos_table, crops, crop_desc, crop_tables, crop_desc2, crop_tables2, crop_work;
     PinBuf pin[2], pin_out[2];
     PinBuf pin_ctrl;   // search: the counters of a launch (pageable destinations make hipMemcpyAsync synchronous)
+    PinBuf pin_crops, pin_desc;  // letterbox: the detect's boxes on their way down, the crop descriptors on their way up (20 000 clips: 0.3 + 0.6 MB)
     const void *pinned_db = nullptr;  // vdf_ctx_pin_database: the caller promises these n x 16 words do not change until unpinned
     size_t pinned_n = 0;
     ExpOwner exp_owner;
