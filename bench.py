@@ -900,7 +900,7 @@ def main():
             # SURVEY 8f N3, the builder's default (Cropdetect::Letterbox before from_frames) at the decoder's native size: detect + crop +
             # hash of 1080p clips with bars, one vdf_hash_frames_u8_letterbox_device call per step (it downloads the boxes in between).
             # box_GB_per_s counts the bytes of the crop boxes (what the resize has to read); the probe reads of the detect pass are on top.
-            def letterbox_leg(n, w, h):
+            def letterbox_leg(n, w, h, key="letterbox_full_hd", names=("no_bars", "top_bottom_bars", "side_bars", "one_black_probe_frame_in_1000")):
                 res = {"clips": n, "w": w, "h": h}
                 base = torch.empty((n, 16, h, w), dtype=torch.uint8, device=dev)
                 chunk = max(1, (1 << 31) // (16 * h * w))
@@ -908,7 +908,7 @@ def main():
                     base[c0:c0 + chunk] = torch.randint(0, 256, (min(chunk, n - c0), 16, h, w), dtype=torch.uint8, device=dev, generator=g)
                 oh = torch.zeros((n, 16), dtype=torch.int64, device=dev)
                 bar_t, bar_s = int(h * 0.12), int(w * 0.125)
-                for name in ("no_bars", "top_bottom_bars", "side_bars", "one_black_probe_frame_in_1000"):
+                for name in names:
                     fr = base
                     if name != "no_bars":
                         fr = base.clone()
@@ -929,10 +929,12 @@ def main():
                                  "box_GB_per_s": n * 16 * kept / (ms_l * 1e-3) / 1e9}
                     if fr is not base:
                         del fr
-                hash_leg["letterbox_full_hd"] = res
+                hash_leg[key] = res
                 del base, oh
 
             letterbox_leg(args.hash_hd_clips, 1920, 1080)
+            # the headline's own frame shape with bars: boxes of small frames take one workgroup per clip with the DCT fused (round 5)
+            letterbox_leg(min(args.hash_clips, 20000), 64, 64, key="letterbox_64x64", names=("no_bars", "top_bottom_bars", "side_bars"))
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)

@@ -39,6 +39,8 @@ def test_bench_emits_the_contract_line(backend):
     assert lb["no_bars"]["crop_of_clip_0"] == [0, 0, 0, 0] and lb["top_bottom_bars"]["crop_of_clip_0"] == [0, 0, int(h_ * 0.12), int(h_ * 0.12)]
     assert lb["side_bars"]["crop_of_clip_0"] == [int(w_ * 0.125), int(w_ * 0.125), 0, 0]
     assert lb["one_black_probe_frame_in_1000"]["crop_of_clip_0"] == [0, 0, 0, 0] and all(lb[k]["ms_per_step"] > 0 for k in lb if isinstance(lb[k], dict))
+    ls = h["letterbox_64x64"]  # the headline's own frame shape with bars (small-frame crop kernel)
+    assert ls["no_bars"]["crop_of_clip_0"] == [0, 0, 0, 0] and ls["top_bottom_bars"]["crop_of_clip_0"] == [0, 0, 7, 7] and ls["side_bars"]["crop_of_clip_0"] == [8, 8, 0, 0]
     assert d["match_groups"] > 0 and d["windowed"]["pairs"] > 0 and d["windowed"]["steps"] == 1
     assert d["windowed"]["waste_ratio"] >= 1.0
     rf = d["refs_c5_shape"]
