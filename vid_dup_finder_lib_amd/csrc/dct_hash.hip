@@ -2018,10 +2018,49 @@ __global__ __launch_bounds__(256) void resize_dct_hash_cropped_small_kernel(cons
     v4i bias_v;
 #pragma unroll
     for (int r = 0; r < 4; r++) bias_v[r] = T.bias_v[4 * g + r];
+    const uint8_t *clip0 = frames + (size_t)d.src_clip * clip_stride + (size_t)d.y0 * pitch + d.x0;
+    // a box of one tile (at most 64 x 64: every box of the bench's 64 x 64 stacks) well inside the buffer: the wave's sixteen loads - four frames
+    // x four row blocks - all go out before the first product, as in resize_dct_hash_fused_kernel<true> (16 KB in flight per wave instead of 4)
+    if (T.n_kt == 1 && T.n_rg == 1 && clip0 + 15 * frame_stride + (size_t)d.h * pitch + 64 <= buf_end) {  // workgroup-uniform
+        const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+        v4i px[4][4];
+        const bool col_ok = 16u * g < d.w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint8_t *src = clip0 + (size_t)(4 * wave + q) * frame_stride;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const uint32_t row = 16u * m + r16;
+                px[q][m] = (v4i){0, 0, 0, 0};
+                if (row < d.h && col_ok) px[q][m] = load_pixels16<false>(src + (size_t)row * pitch + 16u * g, buf_end);
+            }
+        }
+        const v4i bh = T.bh[lane], bl = T.bh[64 + lane], avh = T.av[lane], avl = T.av[64 + lane];
+        const int32_t bias_h = T.bias_h[r16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4i a = px[q][m] ^ x80;
+                v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bh, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bl, al, 0, 0, 0);
+                b[m] = (int)finalize4(ah, al, T.prec_h);
+            }
+            v4i vh = {0, 0, 0, 0}, vl = bias_v;
+            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(avh, b, vh, 0, 0, 0);
+            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, vl, 0, 0, 0);
+            sh.cube[(4 * wave + q) * 64 + g * 16 + r16] = finalize4(vh, vl, T.prec_v);
+        }
+        __syncthreads();
+        dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, d.src_clip, out_hashes, out_dontcare);
+        return;
+    }
 #pragma unroll 1
     for (uint32_t q = 0; q < 4; q++) {
         const uint32_t f = 4 * wave + q;
-        const uint8_t *src = frames + (size_t)d.src_clip * clip_stride + (size_t)f * frame_stride + (size_t)d.y0 * pitch + d.x0;
+        const uint8_t *src = clip0 + (size_t)f * frame_stride;
         v4i vh = {0, 0, 0, 0}, vl = bias_v;
         // 16-byte loads may run past the crop box into the rest of the frame (zero coefficients there); only the very end of the buffer
         // needs the careful loader (wave-uniform test)
