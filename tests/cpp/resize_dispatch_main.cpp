@@ -93,7 +93,7 @@ int main()
                                                        {640, 120, true}, {854, 128, true}, {1920, 128, true}, {1920, 64, true}, {1920, 48, false}, {1920, 129, false}};
     for (auto &q : shorts) CHECK(resize_short_prefers_stream(q.w, q.h) == q.stream, "short frame %u x %u: stream %d", q.w, q.h, (int)q.stream);
     struct { uint32_t w, h; bool tiled; } talls[] = {{64, 160, true}, {64, 256, true}, {128, 256, true}, {176, 144, true}, {160, 200, true}, {16, 200, true}, {176, 208, false},
-                                                     {192, 144, false}, {240, 160, false}, {64, 257, false}, {64, 128, false}, {100, 200, false}, {144, 256, false}};
+                                                     {192, 144, false}, {240, 160, false}, {64, 257, false}, {64, 128, false}, {100, 200, true}, {90, 250, true}, {144, 256, false}};
     for (auto &q : talls) CHECK(resize_tall_prefers_tiled(q.w, q.h) == q.tiled, "tall frame %u x %u: tiled %d", q.w, q.h, (int)q.tiled);
     // the per-wave block streams: every M-class width (from 462 columns) whose pitch is at most 1920, with as many waves as block buffers fit; the (whole-KB) block
     // fits the wave's buffer, the workgroup fits the CU's LDS, and the width's band table fits the table array of that wave count

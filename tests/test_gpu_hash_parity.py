@@ -158,16 +158,20 @@ def test_linear_stream_resize_kernel_matches_oracle(mode, h, w, n, monkeypatch):
                                  (81, 144), (90, 160), (120, 160), (99, 176), (108, 192), (64, 192), (33, 176), (128, 144), (128, 192), (65, 160),
                                  (117, 208), (126, 224), (64, 256), (96, 256), (128, 256), (100, 240), (17, 256), (48, 208),
                                  (160, 64), (256, 64), (160, 96), (160, 128), (256, 128), (200, 112), (240, 80), (144, 176), (200, 160), (208, 176), (129, 16),
-                                 (256, 16), (192, 128), (130, 64), (193, 80), (256, 256), (144, 256), (192, 208)])
+                                 (256, 16), (192, 128), (130, 64), (193, 80), (256, 256), (144, 256), (192, 208),
+                                 (44, 60), (56, 100), (68, 120), (84, 150), (112, 200), (120, 250), (200, 100), (60, 60), (62, 62), (50, 50), (17, 33),
+                                 (100, 130), (250, 90), (129, 65), (64, 63), (65, 63), (128, 255), (256, 241)])  # widths off a multiple of 16: the last clip apart
 def test_tiled_persistent_kernel_matches_oracle_and_the_per_clip_kernel(h, w, monkeypatch):
-    """Round 5: frames of up to 256 x 256 whose width is a multiple of 16 (and that are not a single 64 x 64 tile) can take
+    """Round 5: frames of up to 256 x 256 (that are not a single 64 x 64 tile of a width that is a multiple of 16) can take
     resize_dct_hash_tiled_kernel - persistent workgroups, units of (at most) eight 16-byte loads per lane in two register buffers, the next
     clip's first unit in flight under the DCT.  All seven shapes (2 x 1, 1 x 2 tiles: a frame per unit; 2 x 2: a row group per unit; 3 and 4
     K tiles x 1 and 2 row groups: half a row group per unit, the block results carried between the halves; and the four-row-group forms of all
     four widths for 129 ... 256 rows, whose fourth group is empty up to 192 rows), partial tiles in both
     directions, more clips than resident workgroups (the persistent loop runs several times), the first clips against the oracle and every
     clip against the one-workgroup-per-clip kernel (VDF_HASH_NO_PERSISTENT) - through the fused family by force (VDF_RESIZE_MODE=3), since
-    the default dispatch hands the largest of these sizes to the stream kernels."""
+    the default dispatch hands the largest of these sizes to the stream kernels.  Widths off a multiple of 16 (rows whose last load runs into
+    the next row) go the same way, their last clip through the per-clip kernel's careful loader; the single-tile sizes among them take
+    resize_dct_hash_persistent_kernel."""
     import torch
 
     import vid_dup_finder_lib_amd as vdf

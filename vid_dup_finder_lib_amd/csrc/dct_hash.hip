@@ -2119,7 +2119,28 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
                                    hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    if (a.n_kt == 1 && a.n_rg == 1 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+    // The persistent kernels load 16 bytes at a time without looking at the buffer's end.  With W % 16 == 0 no load crosses a row's end; with any other
+    // width a row's last load runs up to 15 bytes into what follows - the next row, frame or clip, all inside the buffer, at zero coefficients -
+    // except behind the LAST clip: that one goes to the one-workgroup-per-clip kernel and its careful loader (round 5).
+    const bool persistent_ok = n_clips <= 0xFFFFFFFFull && !a.no_persistent && a.n_kt <= 4 && a.n_rg <= 4;
+    const bool tail = persistent_ok && w % 16 != 0 && n_clips >= 2;  // the last clip apart
+    const bool inside = w % 16 == 0 || tail;
+    const size_t n_all = n_clips;
+    if (tail) n_clips -= 1;
+    const auto last_clip = [&]() -> hipError_t {
+        if (!tail) return hipGetLastError();
+        const uint8_t *f = frames + (n_all - 1) * clip_stride;
+        uint64_t *oh = out_hashes + (n_all - 1) * 16;
+        uint32_t *od = out_dontcare ? out_dontcare + (n_all - 1) : nullptr;
+        if (a.n_kt == 1 && a.n_rg == 1)
+            hipLaunchKernelGGL(resize_dct_hash_fused_kernel<true>, dim3(1), dim3(256), 0, stream, f, w, h, frame_stride, clip_stride, buf_end,
+                               make_tables(a), cos_table, oh, od);
+        else
+            hipLaunchKernelGGL(resize_dct_hash_fused_kernel<false>, dim3(1), dim3(256), 0, stream, f, w, h, frame_stride, clip_stride, buf_end,
+                               make_tables(a), cos_table, oh, od);
+        return hipGetLastError();
+    };
+    if (a.n_kt == 1 && a.n_rg == 1 && inside && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2132,7 +2153,7 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
             hipLaunchKernelGGL(resize_dct_hash_persistent_kernel<false>, dim3(grid), dim3(256), 0, stream, frames, w, h,
                                frame_stride, clip_stride, make_tables(a), cos_table, out_hashes, out_dontcare,
                                (uint32_t)n_clips);
-    } else if (a.n_kt <= 4 && a.n_rg <= 4 && w % 16 == 0 && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
+    } else if (a.n_kt <= 4 && a.n_rg <= 4 && inside && n_clips <= 0xFFFFFFFFull && !a.no_persistent) {
         // up to 128 x 128: units of eight loads per lane in flight, persistent
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -2165,7 +2186,7 @@ hipError_t launch_resize_dct_fused(const uint8_t *frames, size_t n_clips, uint32
         hipLaunchKernelGGL(resize_dct_hash_fused_kernel<false>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames,
                            w, h, frame_stride, clip_stride, buf_end, make_tables(a), cos_table, out_hashes,
                            out_dontcare);
-    return hipGetLastError();
+    return last_clip();
 }
 
 hipError_t launch_resize_mfma_frames(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h,

@@ -144,7 +144,8 @@ bool resize_tall_prefers_tiled(uint32_t w, uint32_t h)
     // Measured, stream -> tiled (TB/s, gpurun_out/r06l = profiles/r05_short_frames.txt): 64 x 160 2.4 -> 5.5, 64 x 256 2.7 -> 4.9, 80 x 240 3.1 -> 5.2,
     // 96 x 160 3.2 -> 5.1, 112 x 200 3.5 -> 5.4, 128 x 160 4.0 -> 5.4, 128 x 256 4.8 -> 5.4, 160 x 144 4.3 -> 4.9, 160 x 200 4.6 -> 5.0,
     // 176 x 144 4.6 -> 5.1; level at 144 x 256, 176 x 208, 192 x 144; the other way from there: 208 x 160 5.4 -> 5.0, 240 x 160 6.1 -> 5.0.
-    return h > 128 && h <= 256 && w >= 16 && w <= 176 && w % 16 == 0 && (uint64_t)w * h <= 36000;
+    // (any width since the persistent kernels take the last clip apart: 100 x 200 3.1 -> 4.7, gpurun_out/r06z)
+    return h > 128 && h <= 256 && w >= 16 && w <= 176 && (uint64_t)w * h <= 36000;
 }
 
 uint32_t ksplit_geometry(uint32_t w, uint32_t *wp)
