@@ -186,11 +186,20 @@ int vdf_hash_frames_u8_cropped_device(vdf_ctx *ctx, const uint8_t *d_frames, siz
                                       uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                                       const uint32_t *crops, uint64_t *d_out_hashes, uint32_t *d_out_dontcare,
                                       void *stream);
-/* detect + crop + hash in one call; out_crops (HOST, nullable) receives the detected boxes. */
+/* detect + crop + hash in one call; out_crops (HOST, nullable) receives the detected boxes: they are there when the call returns (the
+ * call then ends with a wait for its own work; pass NULL, or use the _async form below, to only queue). */
 int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                                         uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
                                         uint64_t *d_out_hashes, uint32_t *d_out_dontcare, uint32_t *out_crops,
                                         void *stream);
+/* The same with the boxes left on the DEVICE (d_out_crops: [n_clips][4], nullable), ordered on `stream` like the hashes.  For frames of
+ * at most 256 columns and 128 rows the call only queues work: no copy to the host and no wait anywhere between detect and hash (frames of at
+ * most 64 x 64: one kernel does both) - the reference's builder likewise detects, crops and hashes a clip in one pass
+ * (video_hash_builder.rs:188-204).  Larger frames: the kernel per box shape is chosen on the host, so the call waits for the detect. */
+int vdf_hash_frames_u8_letterbox_device_async(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                              uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                              uint64_t *d_out_hashes, uint32_t *d_out_dontcare, uint32_t *d_out_crops,
+                                              void *stream);
 int vdf_hash_frames_u8_letterbox(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32_t frames_per_clip,
                                  uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *out_hashes,
                                  uint32_t *out_crops, uint32_t *out_dontcare);

@@ -135,6 +135,9 @@ SIGNATURES = {
     "vdf_hash_frames_u8_letterbox_device": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                       C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p]),
+    "vdf_hash_frames_u8_letterbox_device_async": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                            C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                            C.c_void_p]),
     "vdf_hash_frames_u8_letterbox": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vdf_search_self": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(VdfGroups)]),

@@ -31,6 +31,10 @@ vdf_ctx::~vdf_ctx()
         kv.second->operand.release(); kv.second->bias.release(); kv.second->meta.release();
         delete kv.second;
     }
+    for (auto &kv : box_tables) {
+        kv.second->blob.release(); kv.second->entries.release();
+        delete kv.second;
+    }
     DevBuf *all[] = {&row_lo, &row_hi, &tile_lo, &tile_hi, &tile_first, &tile_count, &tile_offset, &counters,
                      &hits, &perm, &matched, &exp_cols, &exp_rows, &pop_cols, &pop_rows, &cand, &group_cmin, &group_offset, &group_blocks, &up_hashes,
                      &up_dur, &up_ref_hashes, &up_ref_dur, &small, &frames, &frames2, &out_hashes, &out_hashes2, &out_dc,
@@ -452,6 +456,65 @@ DeviceMfmaTable *mfma_table(vdf_ctx *ctx, uint32_t in_size, int layout, hipStrea
     ctx->mfma_tables[key] = t;
     *rc = VDF_OK;
     return t;
+}
+
+// The tables of EVERY crop-box size of a w x h frame (vdf_ctx.h: BoxTableSet), built and uploaded once per context and frame size.
+BoxTableSet *box_table_set(vdf_ctx *ctx, uint32_t w, uint32_t h, hipStream_t stream, int *rc)
+{
+    const uint64_t key = ((uint64_t)w << 32) | h;
+    auto it = ctx->box_tables.find(key);
+    if (it != ctx->box_tables.end()) { *rc = VDF_OK; return it->second; }
+    BoxTableSet *set = new BoxTableSet();
+    set->one_tile = w <= 64 && h <= 64;
+    const size_t n_idx = (size_t)w + h + 2;
+    std::vector<vdf::CropTableEntry> entries(n_idx, vdf::CropTableEntry{nullptr, nullptr, 0, 0});
+    std::vector<size_t> offset(n_idx, 0);
+    std::vector<uint8_t> blob;
+    bool usable = true;
+    for (size_t idx = 0; idx < n_idx && usable; idx++) {
+        const bool vertical = idx > w;
+        const uint32_t size = (uint32_t)(vertical ? idx - w - 1 : idx);
+        offset[idx] = blob.size();
+        if (size == 0) {  // no such box; the one-tile form keeps the stride
+            if (set->one_tile) blob.resize(blob.size() + vdf::kSmallBoxTableStride, 0);
+            continue;
+        }
+        vdf::MfmaAxisTable t;
+        if (!vdf::build_mfma_axis_table(size, vertical ? vdf::kMfmaLayoutVertical : vdf::kMfmaLayoutHorizontal, t) || !t.ok) { usable = false; break; }
+        const size_t at = blob.size();
+        blob.resize(at + t.operand.size() + 128, 0);
+        std::memcpy(blob.data() + at, t.operand.data(), t.operand.size());
+        std::memcpy(blob.data() + at + t.operand.size(), t.bias.data(), 64);
+        const int32_t tail[2] = {t.precision, t.n_tiles};
+        std::memcpy(blob.data() + at + t.operand.size() + 64, tail, sizeof tail);
+        entries[idx].n_tiles = t.n_tiles;
+        entries[idx].precision = t.precision;
+        if (set->one_tile && blob.size() - at != vdf::kSmallBoxTableStride) usable = false;  // (cannot happen: sizes <= 64 are one tile)
+    }
+    int r = VDF_OK;
+    if (usable) {
+        r = upload(ctx, set->blob, blob.data(), blob.size(), stream);
+        if (r == VDF_OK) {
+            for (size_t idx = 0; idx < n_idx; idx++) {
+                if (!entries[idx].n_tiles) continue;
+                entries[idx].operand = set->blob.as<uint8_t>() + offset[idx];
+                entries[idx].bias = reinterpret_cast<const int32_t *>(set->blob.as<uint8_t>() + offset[idx] + (size_t)entries[idx].n_tiles * 2048);
+            }
+            r = upload(ctx, set->entries, entries.data(), entries.size() * sizeof(vdf::CropTableEntry), stream);
+        }
+        // (pageable sources: both copies have left the host buffers when hipMemcpyAsync returns, but the one-time wait keeps this like mfma_table)
+        if (r == VDF_OK && hipStreamSynchronize(stream) != hipSuccess) r = fail(ctx, VDF_E_HIP, "table upload failed");
+    }
+    if (r != VDF_OK) {
+        set->blob.release(); set->entries.release();
+        delete set;
+        *rc = r;
+        return nullptr;
+    }
+    set->usable = usable;
+    ctx->box_tables[key] = set;
+    *rc = VDF_OK;
+    return set;
 }
 
 vdf::ResizeAxisTable dev_view(const DeviceAxisTable *t)
@@ -944,7 +1007,7 @@ int hash_cropped_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, u
 
 int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                                  uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out,
-                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream)
+                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream, uint32_t *d_out_crops)
 {
     if (frames_per_clip < VDF_DCT_SIZE) return fail(ctx, VDF_E_NOT_ENOUGH_FRAMES, "fewer than 16 frames per clip");
     if (w == 0 || h == 0) return fail(ctx, VDF_E_BAD_DIMS, "zero frame dimension");
@@ -957,12 +1020,60 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
             int rc = letterbox_hash_device_locked(ctx, d_frames + c0 * clip_stride, nb, frames_per_clip, w, h,
                                                   frame_stride, clip_stride, d_out + c0 * VDF_HASH_WORDS,
                                                   d_dc ? d_dc + c0 : nullptr, out_crops ? out_crops + 4 * c0 : nullptr,
-                                                  stream);
+                                                  stream, d_out_crops ? d_out_crops + 4 * c0 : nullptr);
             if (rc) return rc;
         }
         return VDF_OK;
     }
     VDF_HIP(ctx, hipSetDevice(ctx->device));
+    // Small frames (round 6): the boxes never visit the host.  Every box size's tables are resident (box_table_set), so
+    //  * frames of at most 64 x 64 take ONE kernel that detects, crops, resizes, transforms and hashes (letterbox_resize_dct_hash_small_kernel);
+    //    the clips within 64 bytes of the buffer's end (the last one, as a rule) take the route below for its careful loader;
+    //  * other small frames: the two detect kernels, then the one-workgroup-per-clip kernel reads each clip's box where they left it.
+    // No copy to the host, no wait, no host loop over the clips between the launches; out_crops is filled by one copy queued behind them
+    // and waited for at the END of the call (d_out_crops: no wait at all).
+    const bool small_frames = (h + 63) / 64 <= 2 && w <= 256 && ctx->resize_mode == 0 && !ctx->no_smallcrop && !ctx->lb_host_plan &&
+                              n_clips <= 0x7FFFFFFull;
+    if (small_frames) {
+        int rc = ensure_cos_table(ctx, stream);
+        if (rc) return rc;
+        BoxTableSet *set = box_table_set(ctx, w, h, stream, &rc);
+        if (rc) return rc;
+        if (set->usable) {
+            uint32_t *d_crops = d_out_crops;
+            if (!d_crops) {
+                VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
+                d_crops = ctx->crops.as<uint32_t>();
+            }
+            const uint8_t *buf_end = d_frames + (n_clips - 1) * clip_stride + (VDF_DCT_SIZE - 1) * frame_stride + (size_t)w * h;
+            size_t n_fused = 0;
+            if (set->one_tile && !ctx->no_lb_fused) {
+                // clip c's loads stay inside the buffer iff it ends at least 64 bytes before the last clip does: (n - 1 - c) * clip_stride >= 64
+                const size_t n_tail = clip_stride == 0 ? n_clips : std::min<size_t>(n_clips, (64 + clip_stride - 1) / clip_stride);
+                n_fused = n_clips - n_tail;
+                VDF_HIP(ctx, vdf::launch_letterbox_hash_small(d_frames, n_fused, w, h, frame_stride, clip_stride, set->blob.p, ctx->cos_table.as<double>(),
+                                                              d_out, d_dc, d_crops, ctx->hash_wgs_per_cu_set ? ctx->hash_wgs_per_cu : 0, stream));
+            }
+            if (n_fused < n_clips) {
+                const size_t nr = n_clips - n_fused;
+                const uint8_t *fr = d_frames + n_fused * clip_stride;
+                VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(nr, frames_per_clip)));
+                VDF_HIP(ctx, vdf::launch_letterbox(fr, nr, frames_per_clip, w, h, frame_stride, clip_stride, d_crops + 4 * n_fused,
+                                                   ctx->crop_work.as<uint32_t>(), stream, ctx->lb_side_strips));
+                VDF_HIP(ctx, vdf::launch_resize_dct_cropped_small_boxes(fr, nr, w, h, frame_stride, clip_stride, buf_end, d_crops + 4 * n_fused,
+                                                                        set->entries.as<vdf::CropTableEntry>(), ctx->cos_table.as<double>(),
+                                                                        d_out + n_fused * VDF_HASH_WORDS, d_dc ? d_dc + n_fused : nullptr, stream));
+            }
+            if (out_crops) {
+                if (!ctx->pin_crops.reserve(n_clips * 16)) return fail(ctx, VDF_E_OOM, "host staging for the crop boxes");
+                VDF_HIP(ctx, hipMemcpyAsync(ctx->pin_crops.p, d_crops, n_clips * 16, hipMemcpyDeviceToHost, stream));
+                VDF_HIP(ctx, hipEventRecord(ctx->ev_mid, stream));
+                VDF_HIP(ctx, hipEventSynchronize(ctx->ev_mid));  // everything of this call is queued: the wait costs the GPU nothing
+                std::memcpy(out_crops, ctx->pin_crops.p, n_clips * 16);
+            }
+            return VDF_OK;
+        }
+    }
     // (Cutting a large batch into chunks whose detect passes run on a second stream under the resize of the chunks before them was
     // built and measured in round 5 - profiles/r05_letterbox_ab.txt: the resize kernels fill every CU's LDS, so the walkers only got in
     // between the chunks, and three chunk boundaries cost more than the hidden detect time saved: 1000 pillarboxed 1080p clips 5.45 ms
@@ -977,6 +1088,7 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     VDF_HIP(ctx, hipMemcpyAsync(crops, ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
     if (out_crops) std::memcpy(out_crops, crops, n_clips * 16);
+    if (d_out_crops) VDF_HIP(ctx, hipMemcpyAsync(d_out_crops, ctx->crops.p, n_clips * 16, hipMemcpyDeviceToDevice, stream));
     return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops, d_out, d_dc, stream);
 }
 
@@ -1078,6 +1190,8 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     ctx->rowcrop_all = std::getenv("VDF_ROWCROP_ALL") != nullptr;
     ctx->no_boxstream = std::getenv("VDF_NO_BOXSTREAM") != nullptr;
     ctx->no_smallcrop = std::getenv("VDF_NO_SMALLCROP") != nullptr;
+    ctx->lb_host_plan = std::getenv("VDF_LB_HOST_PLAN") != nullptr;
+    ctx->no_lb_fused = std::getenv("VDF_NO_LB_FUSED") != nullptr;
     if (std::getenv("VDF_LB_NC16")) ctx->lb_side_strips = 16;
     if (const char *s = std::getenv("VDF_COPY_THREADS")) { const int v = std::atoi(s); if (v >= 1 && v <= 64) ctx->copy_threads = v; }
     if (const char *s = std::getenv("VDF_HOST_CHUNK_MB")) { const long v = std::atol(s); if (v >= 1 && v <= 1024) ctx->host_chunk_bytes = (size_t)v << 20; }
@@ -1085,7 +1199,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     if (const char *s = std::getenv("VDF_HASH_NO_PERSISTENT")) ctx->hash_no_persistent = std::atoi(s) != 0;
     if (const char *s = std::getenv("VDF_HASH_WGS_PER_CU")) {
         int v = std::atoi(s);
-        if (v >= 1 && v <= 8) ctx->hash_wgs_per_cu = v;
+        if (v >= 1 && v <= 8) { ctx->hash_wgs_per_cu = v; ctx->hash_wgs_per_cu_set = true; }
     }
     if (const char *s = std::getenv("VDF_CHUNK_COLS")) {
         long c = std::atol(s);
@@ -1454,6 +1568,19 @@ int vdf_hash_frames_u8_letterbox_device(vdf_ctx *ctx, const uint8_t *d_frames, s
     return letterbox_hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
                                         d_out_hashes, d_out_dontcare, out_crops,
                                         stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int vdf_hash_frames_u8_letterbox_device_async(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
+                                              uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                              uint64_t *d_out_hashes, uint32_t *d_out_dontcare, uint32_t *d_out_crops,
+                                              void *stream)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VDF_SINGLE_DEVICE_ONLY(ctx);
+    return letterbox_hash_device_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
+                                        d_out_hashes, d_out_dontcare, nullptr,
+                                        stream ? (hipStream_t)stream : ctx->stream, d_out_crops);
 }
 
 int vdf_groups_max_distance(vdf_ctx *ctx, const uint64_t *hashes, size_t n, const uint64_t *ref_hashes, size_t n_ref,

@@ -1990,6 +1990,11 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_kernel(const uint8_t 
 // workgroups of 256 threads per clip each did a quarter of one (20 000 letterboxed clips of 64 x 64: crop + hash 1.25 ms against 0.33 ms for
 // the same clips without bars).  Vertical tables in the plain layout (kMfmaLayoutVertical).  The DCT runs in the same workgroup (as in
 // resize_dct_hash_fused_kernel): no 16 x 16 frames through HBM, no second launch.
+// DEVICE_BOX (round 6): no descriptors from the host - the workgroup reads its clip's box {left, right, top, bottom} where the detect kernels
+// left it (`boxes`, device memory) and finds the tables of that box size in the per-(W, H) set of ALL box sizes (`tables`: horizontal
+// table of box width bw at [bw], vertical of box height bh at [pitch + 1 + bh]; api.cpp: box_table_set), so nothing of the detect's result visits the host
+// between the two launches (the reference crops and hashes in one pass per clip: video_hash_builder.rs:188-204).
+template <bool DEVICE_BOX>
 __global__ __launch_bounds__(256) void resize_dct_hash_cropped_small_kernel(const uint8_t *__restrict__ frames, uint32_t pitch,
                                                                             size_t frame_stride, size_t clip_stride,
                                                                             const uint8_t *buf_end,
@@ -1997,12 +2002,20 @@ __global__ __launch_bounds__(256) void resize_dct_hash_cropped_small_kernel(cons
                                                                             const CropTableEntry *__restrict__ tables,
                                                                             const double *__restrict__ cos_table,
                                                                             uint64_t *__restrict__ out_hashes,
-                                                                            uint32_t *__restrict__ out_dontcare)
+                                                                            uint32_t *__restrict__ out_dontcare,
+                                                                            const uint32_t *__restrict__ boxes, uint32_t frame_rows)
 {
     __shared__ DctShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
     if (tid < 32) sh.words[tid] = 0u;
-    const CropClipDesc d = desc[blockIdx.x];
+    CropClipDesc d;
+    if (DEVICE_BOX) {
+        const uint4 b = reinterpret_cast<const uint4 *>(boxes)[blockIdx.x];  // left, right, top, bottom (the detect never leaves an empty box)
+        d.x0 = b.x; d.y0 = b.z; d.w = pitch - b.x - b.y; d.h = frame_rows - b.z - b.w;
+        d.h_table = d.w; d.v_table = pitch + 1 + d.h; d.src_clip = blockIdx.x; d.pad = 0;
+    } else {
+        d = desc[blockIdx.x];
+    }
     const CropTableEntry th = tables[d.h_table], tv = tables[d.v_table];
     MfmaResizeTables T;
     T.bh = reinterpret_cast<const v4i *>(th.operand);
@@ -2078,8 +2091,335 @@ hipError_t launch_resize_dct_cropped_small(const uint8_t *frames, size_t n_clips
                                            uint32_t *out_dontcare, hipStream_t stream)
 {
     if (n_clips == 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_dct_hash_cropped_small_kernel, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, pitch, frame_stride,
-                       clip_stride, buf_end, desc, tables, cos_table, out_hashes, out_dontcare);
+    hipLaunchKernelGGL(resize_dct_hash_cropped_small_kernel<false>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, pitch, frame_stride,
+                       clip_stride, buf_end, desc, tables, cos_table, out_hashes, out_dontcare, (const uint32_t *)nullptr, 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_dct_cropped_small_boxes(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                                 size_t clip_stride, const uint8_t *buf_end, const uint32_t *boxes,
+                                                 const CropTableEntry *tables, const double *cos_table, uint64_t *out_hashes,
+                                                 uint32_t *out_dontcare, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    hipLaunchKernelGGL(resize_dct_hash_cropped_small_kernel<true>, dim3((uint32_t)n_clips), dim3(256), 0, stream, frames, w, frame_stride,
+                       clip_stride, buf_end, (const CropClipDesc *)nullptr, tables, cos_table, out_hashes, out_dontcare, boxes, h);
+    return hipGetLastError();
+}
+
+// ---- small frames (W, H <= 64): letterbox detect + crop + resize + DCT + hash in ONE persistent kernel (round 6) -----------------------
+// Replaces, for one-tile frames, the chain  letterbox_kernel -> letterbox_sides_kernel -> copy of the boxes to the host -> host plan ->
+// resize_dct_hash_cropped_small_kernel  (the reference detects, crops and hashes clip by clip: video_hash_builder.rs:188-204,
+// video_frames_gray.rs:38-128,201-210).  A workgroup owns a clip: the two probed frames (0 and 8) go to LDS, wave e walks in from edge e
+// (left / right / top / bottom) of BOTH probes at LDS latency, the box is the per-edge minimum of the two probes' crops (crop.rs:53-68),
+// and the sixteen frames' box pixels are then loaded straight into the MFMA operand registers (unaligned 16-byte loads at the box origin;
+// the probes come back from L2).  Software pipeline per workgroup: detect of clip i + 1 runs BETWEEN the resize and the DCT of clip i, so
+// clip i + 1's pixel loads and clip i + 2's probe loads are in flight under the f64 DCT, as in resize_dct_hash_persistent_kernel.
+// Strip test (exact, all integer): four strips per wave instruction stream, one per 16-lane DPP row, two consecutive strips of each
+// probe judged speculatively in walking order (the reference's take_while):
+//   accept  max - min <= tol      (every pixel within tol of any value of the strip, so of its mode: count = len)
+//   reject  no two ADJACENT value bins of width 32 hold more than 9/10 of the strip (the window mode +- tol <= 16 spans at most 33 values,
+//           so at most two adjacent bins: its count cannot exceed the best pair)
+//   else    the strip's 256-bin histogram in LDS (mode = last maximum; count over [mode - tol, mode + tol]; 10 count > 9 len), one strip per wave.
+namespace lbs {
+constexpr uint32_t kPitch = 68;                 // LDS row pitch of a probe: 17 dwords (odd), so a column walk touches 16 different banks
+constexpr uint32_t kProbeBytes = 64 * kPitch;
+constexpr uint32_t kTableStride = 2176;         // bytes per one-tile table of the box-size set: operand hi | lo (2 x 1024), bias[16], precision
+
+struct Shared {
+    __attribute__((aligned(16))) uint8_t probe[2 * kProbeBytes];
+    uint32_t hist[4][256];  // the exact test's histogram, one per wave
+    uint32_t edge[2][4];    // [probe][left, right, top, bottom] strips found
+    // the tables of the NEXT clip's box (requested right after its detect, parked here across the DCT of the current clip: in registers they
+    // were 23 more than three workgroups per CU have): [0 .. 127] horizontal hi | lo, [128 .. 255] vertical hi | lo; tail: bias[16], precision
+    __attribute__((aligned(16))) v4i tab[256];
+    __attribute__((aligned(16))) v4i tail[2][8];
+};
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <int ROR> __device__ __forceinline__ uint32_t row_ror(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + ROR, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = max(v, row_ror<8>(v)); v = max(v, row_ror<4>(v)); v = max(v, row_ror<2>(v)); v = max(v, row_ror<1>(v));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// One strip of len <= 64 pixels at s[i * step], exactly as video_frames_gray.rs:52-99 counts it.  All 64 lanes must call.
+__device__ __forceinline__ bool strip_exact(const uint8_t *s, uint32_t step, uint32_t len, uint32_t tol, uint32_t *hist)
+{
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; k++) hist[lane + 64 * k] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < len) atomicAdd(&hist[s[lane * step]], 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t h[4], key = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        h[k] = hist[lane + 64 * k];
+        key = max(key, (h[k] << 8) | (lane + 64 * k));  // max count, ties -> the larger value (Iterator::max_by_key keeps the LAST maximum)
+    }
+    const uint32_t mode = wave_max_u32(key) & 255u;
+    const uint32_t lo = mode > tol ? mode - tol : 0u, hi = min(mode + tol, 255u);
+    uint32_t count = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v = lane + 64 * k;
+        if (v >= lo && v <= hi) count += h[k];
+    }
+    count = wave_sum_u32(count);
+    __builtin_amdgcn_wave_barrier();
+    return 10u * count > 9u * len;  // count / len > 0.9 in f64, exactly (cropdetect.hip: more_than_nine_tenths)
+}
+
+// Edge e (0 left, 1 right, 2 top, 3 bottom) of both probes: n0 / n1 = how many strips from that edge inwards are letterbox.
+__device__ __forceinline__ void walk_edge(const uint8_t *probe, uint32_t e, uint32_t W, uint32_t H, uint32_t tol, uint32_t *hist,
+                                          uint32_t &n0_out, uint32_t &n1_out)
+{
+    const uint32_t lane = threadIdx.x & 63, rr = lane >> 4, q = lane & 15, p = rr >> 1, k = rr & 1;
+    const bool is_row = e >= 2, from_far = (e & 1u) != 0;  // wave-uniform
+    const uint32_t limit = is_row ? H : W, len = is_row ? W : H;
+    const int32_t left = (int32_t)len - 4 * (int32_t)q;
+    const uint32_t nv = (uint32_t)(left < 0 ? 0 : left > 4 ? 4 : left);  // this lane's pixels 4 q .. 4 q + nv - 1 of the strip
+    uint32_t n0 = 0, n1 = 0;
+    bool live0 = true, live1 = true;
+    while (live0 || live1) {
+        const uint32_t s = min((p ? n1 : n0) + k, limit - 1);  // (a strip past the end is judged and never looked at)
+        const uint32_t idx = from_far ? limit - 1 - s : s;
+        const uint8_t *f = probe + p * kProbeBytes;
+        uint32_t d;
+        if (is_row) {
+            d = *reinterpret_cast<const uint32_t *>(f + idx * kPitch + 4u * min(q, (len - 1) >> 2));
+            const uint32_t keep = nv >= 4 ? 0xFFFFFFFFu : (1u << (8u * nv)) - 1u;  // bytes past the row's end repeat its first byte of this lane
+            d = (d & keep) | (((d & 255u) * 0x01010101u) & ~keep);
+        } else {
+            const uint8_t *c = f + idx;
+            d = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) d |= (uint32_t)c[min(4u * q + j, len - 1) * kPitch] << (8u * j);  // clamped rows repeat the last pixel
+        }
+        // accept: max - min <= tol
+        const u16x2 ev = __builtin_bit_cast(u16x2, d & 0x00FF00FFu), od = __builtin_bit_cast(u16x2, (d >> 8) & 0x00FF00FFu);
+        const u16x2 mx2 = __builtin_elementwise_max(ev, od), mn2 = __builtin_elementwise_min(ev, od);
+        uint32_t mx = max((uint32_t)mx2.x, (uint32_t)mx2.y), mn = min((uint32_t)mn2.x, (uint32_t)mn2.y);
+        if (nv == 0) { mx = 0; mn = 255; }
+        u16x2 mm = {(unsigned short)mx, (unsigned short)(255u - mn)};
+        mm = __builtin_elementwise_max(mm, __builtin_bit_cast(u16x2, row_ror<8>(__builtin_bit_cast(uint32_t, mm))));
+        mm = __builtin_elementwise_max(mm, __builtin_bit_cast(u16x2, row_ror<4>(__builtin_bit_cast(uint32_t, mm))));
+        mm = __builtin_elementwise_max(mm, __builtin_bit_cast(u16x2, row_ror<2>(__builtin_bit_cast(uint32_t, mm))));
+        mm = __builtin_elementwise_max(mm, __builtin_bit_cast(u16x2, row_ror<1>(__builtin_bit_cast(uint32_t, mm))));
+        const bool accept = (uint32_t)mm.x + (uint32_t)mm.y <= 255u + tol;
+        // reject: eight bins of 32 values, byte counters (a strip has at most 64 pixels); best adjacent pair
+        uint32_t clo = 0, chi = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t v = (d >> (8u * j)) & 255u, b = v >> 5, inc = j < nv ? 1u << (8u * (b & 3u)) : 0u;
+            clo += (b & 4u) ? 0u : inc;
+            chi += (b & 4u) ? inc : 0u;
+        }
+        clo += row_ror<8>(clo); chi += row_ror<8>(chi);
+        clo += row_ror<4>(clo); chi += row_ror<4>(chi);
+        clo += row_ror<2>(clo); chi += row_ror<2>(chi);
+        clo += row_ror<1>(clo); chi += row_ror<1>(chi);
+        const uint32_t pl = clo + (clo >> 8), ph = chi + (chi >> 8), mid = (clo >> 24) + (chi & 255u);  // sums <= 128: no carries between bytes
+        const uint32_t best = max(max(max(pl & 255u, (pl >> 8) & 255u), max((pl >> 16) & 255u, mid)),
+                                  max(max(ph & 255u, (ph >> 8) & 255u), (ph >> 16) & 255u));
+        const bool reject = !accept && !(10u * best > 9u * len) && tol <= 16u;
+        const uint64_t acc_m = __builtin_amdgcn_ballot_w64(accept), rej_m = __builtin_amdgcn_ballot_w64(reject);
+        // the four verdicts in walking order
+#pragma unroll
+        for (uint32_t pp = 0; pp < 2; pp++) {
+            uint32_t &n = pp ? n1 : n0;
+            bool &live = pp ? live1 : live0;
+#pragma unroll
+            for (uint32_t kk = 0; kk < 2; kk++) {
+                if (live) {
+                    if (n >= limit) {
+                        live = false;
+                    } else {
+                        const uint32_t bit = 16u * (2u * pp + kk);
+                        bool ok;
+                        if ((acc_m >> bit) & 1ull) ok = true;
+                        else if ((rej_m >> bit) & 1ull) ok = false;
+                        else {
+                            const uint32_t at = from_far ? limit - 1 - n : n;
+                            ok = strip_exact(probe + pp * kProbeBytes + (is_row ? at * kPitch : at), is_row ? 1u : kPitch, len, tol, hist);
+                        }
+                        if (ok) n++;
+                        else live = false;
+                    }
+                }
+            }
+            if (n >= limit) live = false;
+        }
+    }
+    n0_out = n0;
+    n1_out = n1;
+}
+}  // namespace lbs
+
+__global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
+    const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
+    const uint8_t *__restrict__ box_tables, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
+    uint32_t *__restrict__ out_dontcare, uint32_t *__restrict__ out_crops, uint32_t n_clips, uint32_t tol)
+{
+    __shared__ DctShared sh;
+    __shared__ lbs::Shared lb;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (tid < 32) sh.words[tid] = 0u;
+    const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+
+    // probes: thread tid moves the 16 bytes at (row tid / 4, column 16 (tid % 4)) of frames 0 and 8
+    const uint32_t prow = tid >> 2, pcol = 16u * (tid & 3u);
+    const bool p_ok = prow < H && pcol < W;
+    v4i pr[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // (addresses as a uniform 64-bit base plus a 32-bit lane offset - the global_load saddr form: as 64-bit lane pointers the loop's
+    // invariant addresses were the values that no longer fitted three workgroups per CU, and a spill's reload waits with vmcnt(0))
+    const uint32_t p_off = prow * W + pcol;
+    auto issue_probe = [&](uint32_t clip) {
+        const uint8_t *cb = frames + (size_t)clip * clip_stride;
+        if (p_ok) {
+            pr[0] = load_pixels16<false>(cb + p_off, nullptr);
+            pr[1] = load_pixels16<false>(cb + 8 * frame_stride + p_off, nullptr);
+        }
+    };
+    auto store_probe = [&]() {
+        if (p_ok) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                uint32_t *d = reinterpret_cast<uint32_t *>(lb.probe + k * lbs::kProbeBytes + prow * lbs::kPitch + pcol);
+#pragma unroll
+                for (int j = 0; j < 4; j++) d[j] = (uint32_t)pr[k][j];
+            }
+        }
+    };
+    // box of the clip whose probes are in LDS (all threads; one barrier inside); writes it to out_crops
+    uint32_t bx0 = 0, by0 = 0, bw = W, bh = H;
+    auto detect = [&](uint32_t clip) {
+        uint32_t n0, n1;
+        lbs::walk_edge(lb.probe, wave, W, H, tol, lb.hist[wave], n0, n1);
+        if (lane == 0) { lb.edge[0][wave] = n0; lb.edge[1][wave] = n1; }
+        __syncthreads();
+        uint32_t c[4];
+        {
+            const uint32_t l0 = lb.edge[0][0], r0 = lb.edge[0][1], t0 = lb.edge[0][2], b0 = lb.edge[0][3];
+            const uint32_t l1 = lb.edge[1][0], r1 = lb.edge[1][1], t1 = lb.edge[1][2], b1 = lb.edge[1][3];
+            // video_frames_gray.rs:119-127: converging edges (a uniform frame) mean "no crop" for that frame; crop.rs:53-68: per-edge minimum
+            const bool ok0 = (int32_t)W - (int32_t)l0 - (int32_t)r0 >= 1 && (int32_t)H - (int32_t)t0 - (int32_t)b0 >= 1;
+            const bool ok1 = (int32_t)W - (int32_t)l1 - (int32_t)r1 >= 1 && (int32_t)H - (int32_t)t1 - (int32_t)b1 >= 1;
+            c[0] = min(ok0 ? l0 : 0u, ok1 ? l1 : 0u);
+            c[1] = min(ok0 ? r0 : 0u, ok1 ? r1 : 0u);
+            c[2] = min(ok0 ? t0 : 0u, ok1 ? t1 : 0u);
+            c[3] = min(ok0 ? b0 : 0u, ok1 ? b1 : 0u);
+        }
+        if (tid < 4) (out_crops + (size_t)clip * 4)[tid] = tid == 0 ? c[0] : tid == 1 ? c[1] : tid == 2 ? c[2] : c[3];
+        bx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[0]);
+        by0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[2]);
+        bw = W - bx0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[1]);
+        bh = H - by0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[3]);
+    };
+    // the box's pixels of this wave's four frames (4 wave .. 4 wave + 3); the tables of its size: thread tid fetches 16 bytes of the 4 KB
+    // (horizontal table of bw | vertical table of bh), the first eight threads of each half the 128-byte tail (bias, precision) as well
+    v4i px[4][4], tq = {0, 0, 0, 0}, tq_tail = {0, 0, 0, 0};
+    const uint32_t l_off = r16 * W + 16u * g;
+    auto issue_pixels = [&](uint32_t clip) {
+        // (the table requests go out FIRST: they come back from L2 and are parked in LDS while the pixel loads behind them are still in flight)
+        const uint8_t *t = box_tables + (size_t)(wave < 2 ? bw : W + 1 + bh) * lbs::kTableStride;  // (wave-uniform)
+        tq = *reinterpret_cast<const v4i *>(t + 16u * (tid & 127u));
+        if ((tid & 127u) < 8) tq_tail = *reinterpret_cast<const v4i *>(t + 2048 + 16u * (tid & 127u));
+        const uint8_t *cb = frames + (size_t)clip * clip_stride + (size_t)(4 * wave) * frame_stride + (size_t)by0 * W + bx0;
+        const bool col_ok = 16u * g < bw;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                px[q][m] = (v4i){0, 0, 0, 0};
+                if (16u * m + r16 < bh && col_ok) px[q][m] = load_pixels16<false>(cb + (size_t)q * frame_stride + (size_t)(16 * m) * W + l_off, nullptr);
+            }
+        }
+    };
+    auto park_tables = [&]() {
+        lb.tab[tid] = tq;
+        if ((tid & 127u) < 8) lb.tail[tid >> 7][tid & 127u] = tq_tail;
+    };
+
+    uint32_t clip = blockIdx.x;
+    if (clip < n_clips) {
+        issue_probe(clip);
+        store_probe();
+        __syncthreads();
+        detect(clip);
+        issue_pixels(clip);
+        if (clip + gridDim.x < n_clips) issue_probe(clip + gridDim.x);
+        park_tables();
+        __syncthreads();
+    }
+    while (clip < n_clips) {
+        const uint32_t next = clip + gridDim.x;
+        const v4i t_bh = lb.tab[lane], t_bl = lb.tab[64 + lane], t_avh = lb.tab[128 + lane], t_avl = lb.tab[192 + lane];
+        const int32_t bias_h = reinterpret_cast<const int32_t *>(lb.tail[0])[r16];
+        const v4i bias_v = lb.tail[1][g];
+        const int32_t prec_h = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[0])[16]);
+        const int32_t prec_v = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[1])[16]);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            v4i b;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v4i a = px[q][m] ^ x80;
+                v4i ah = {0, 0, 0, 0}, al = {bias_h, bias_h, bias_h, bias_h};
+                ah = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, t_bh, ah, 0, 0, 0);
+                al = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, t_bl, al, 0, 0, 0);
+                b[m] = (int)finalize4(ah, al, prec_h);
+            }
+            v4i vh = {0, 0, 0, 0}, vl = bias_v;
+            vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(t_avh, b, vh, 0, 0, 0);
+            vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(t_avl, b, vl, 0, 0, 0);
+            sh.cube[(4 * wave + q) * 64 + g * 16 + r16] = finalize4(vh, vl, prec_v);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // the cube is complete; the previous detect's reads of lb.probe are long over
+        if (next < n_clips) {  // workgroup-uniform
+            store_probe();
+            __syncthreads();
+            detect(next);
+            issue_pixels(next);                                      // in flight during the whole DCT below
+            if (next + gridDim.x < n_clips) issue_probe(next + gridDim.x);  // ... and the next resize
+            park_tables();  // (the resize above was the last reader of the previous clip's, a barrier ago; the DCT's barriers come before the next)
+        }
+        dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
+        clip = next;
+    }
+}
+
+hipError_t launch_letterbox_hash_small(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                       const void *box_tables, const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare,
+                                       uint32_t *out_crops, int wgs_per_cu, hipStream_t stream)
+{
+    if (n_clips == 0) return hipSuccess;
+    if (w > 64 || h > 64 || n_clips > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    int dev = 0, cus = 256, per_cu = 3;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, letterbox_resize_dct_hash_small_kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+    if (wgs_per_cu > 0) per_cu = std::min(per_cu, wgs_per_cu);
+    const uint32_t grid = (uint32_t)std::min<size_t>(n_clips, (size_t)cus * (size_t)per_cu);
+    hipLaunchKernelGGL(letterbox_resize_dct_hash_small_kernel, dim3(grid), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
+                       reinterpret_cast<const uint8_t *>(box_tables), cos_table, out_hashes, out_dontcare, out_crops, (uint32_t)n_clips, 16u);
     return hipGetLastError();
 }
 

@@ -82,6 +82,17 @@ struct DeviceMfmaTable {
     vdf::MfmaAxisTable host;
 };
 
+// Every crop-box size of one small frame size (w <= 256, at most two 64-row groups), resident: what lets the letterbox path go from detect
+// to hash without showing the boxes to the host (api.cpp: box_table_set).  blob: per index one table - operand (n_tiles x {hi, lo} x 1 KB),
+// bias[16], {precision, n_tiles} padded to 64 B; index bw = horizontal table of box width bw (1 .. w), index w + 1 + bh = vertical
+// (kMfmaLayoutVertical) table of box height bh (1 .. h).  entries: the same as vdf::CropTableEntry[w + h + 2] (device pointers into blob).
+// one_tile (w, h <= 64): every table is vdf::kSmallBoxTableStride bytes, so the fused kernel finds a table by multiplication.
+struct BoxTableSet {
+    DevBuf blob, entries;
+    bool usable = false;  // false: some box size's coefficients do not fit the i8 split - the caller keeps the host-planned route
+    bool one_tile = false;
+};
+
 namespace vdf_impl {
 struct Worker;     // one host thread bound to one device (multi.cpp)
 struct RcclState;  // communicators of a multi-GPU context (multi.cpp)
@@ -146,7 +157,11 @@ struct vdf_ctx {
     PinBuf pin_small;  // search: reference durations / permutation and small hit lists (pageable copies of 0.4 MB cost 0.3-1 ms each)
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
+    std::map<uint64_t, BoxTableSet *> box_tables;       // key = w << 32 | h
+    bool lb_host_plan = false;     // VDF_LB_HOST_PLAN: small frames' boxes visit the host between detect and hash (as before round 6: A/B runs)
+    bool no_lb_fused = false;      // VDF_NO_LB_FUSED: frames of at most 64 x 64 take detect kernels + cropped kernel instead of the fused kernel
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;
+    bool hash_wgs_per_cu_set = false;  // VDF_HASH_WGS_PER_CU given (the fused letterbox kernel otherwise takes what fits)
     uint32_t mfma_chunk_cols = 0, mfma_group = 8192;  // 0 = pick the chunk width per search (search_core); VDF_MFMA_CHUNK_COLS overrides
     DevBuf group_cmin, group_offset, group_blocks;
     uint32_t mfma_min_wgs = 8192;  // adaptive chunk width: at least this many (row tile, chunk) workgroups (VDF_MFMA_MIN_WGS)
@@ -248,7 +263,7 @@ int search_refs_resident(vdf_ctx *ctx, size_t n_cand, const std::vector<size_t> 
                          uint32_t tol_int, vdf_groups *out);
 int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n_clips, uint32_t frames_per_clip,
                                  uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride, uint64_t *d_out,
-                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream);
+                                 uint32_t *d_dc, uint32_t *out_crops, hipStream_t stream, uint32_t *d_out_crops = nullptr);
 void destroy_copy_pool(vdf_ctx *ctx);
 bool is_sorted_u32(const uint32_t *d, size_t n);
 

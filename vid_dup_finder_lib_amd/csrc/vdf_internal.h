@@ -166,6 +166,20 @@ hipError_t launch_resize_dct_cropped_small(const uint8_t *frames, size_t n_clips
                                            size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                            const CropTableEntry *tables, const double *cos_table, uint64_t *out_hashes,
                                            uint32_t *out_dontcare, hipStream_t stream);
+// the same kernel fed from the device (round 6): boxes = the detect's output [n_clips][4] {left, right, top, bottom} in device memory, tables = the
+// (w, h) set of ALL box sizes - horizontal table of box width bw at [bw], vertical table of box height bh at [w + 1 + bh] (api.cpp: box_table_set)
+hipError_t launch_resize_dct_cropped_small_boxes(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride,
+                                                 size_t clip_stride, const uint8_t *buf_end, const uint32_t *boxes,
+                                                 const CropTableEntry *tables, const double *cos_table, uint64_t *out_hashes,
+                                                 uint32_t *out_dontcare, hipStream_t stream);
+// frames of at most 64 x 64: detect + crop + resize + DCT + hash in one persistent kernel (dct_hash.hip: letterbox_resize_dct_hash_small_kernel).
+// Every clip's 16-byte loads must stay inside the caller's buffer: the caller keeps the clips within 64 bytes of its end out of this launch.
+// box_tables: the set's tables at kSmallBoxTableStride bytes each, in the order above: operand hi | lo (2 x 1024 B), bias[16], precision.
+// out_crops: DEVICE [n_clips][4], always written.  wgs_per_cu: 0 = what fits.
+constexpr uint32_t kSmallBoxTableStride = 2176;
+hipError_t launch_letterbox_hash_small(const uint8_t *frames, size_t n_clips, uint32_t w, uint32_t h, size_t frame_stride, size_t clip_stride,
+                                       const void *box_tables, const double *cos_table, uint64_t *out_hashes, uint32_t *out_dontcare,
+                                       uint32_t *out_crops, int wgs_per_cu, hipStream_t stream);
 hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uint32_t pitch, size_t frame_stride,
                                       size_t clip_stride, const uint8_t *buf_end, const CropClipDesc *desc,
                                       const CropTableEntry *tables, uint8_t *small, bool wide, hipStream_t stream);

@@ -215,10 +215,18 @@ class Engine:
 
     def hash_frames_letterbox_device(self, d_frames: int, n_clips: int, frames_per_clip: int, w: int, h: int,
                                      d_out: int, d_dontcare: int = 0, stream: int = 0,
-                                     frame_stride: Optional[int] = None, clip_stride: Optional[int] = None) -> np.ndarray:
-        crops = np.zeros((n_clips, 4), np.uint32)
+                                     frame_stride: Optional[int] = None, clip_stride: Optional[int] = None,
+                                     d_crops: Optional[int] = None) -> Optional[np.ndarray]:
+        """Cropdetect::Letterbox + from_frames on device frames.  Default: returns the boxes as a host array (the call then ends with a
+        wait for its own work).  d_crops = device pointer to n_clips x 4 uint32 (0: the boxes are not wanted): the boxes stay on the
+        device, ordered on `stream` like the hashes, and the call only queues work (vdf_hash_frames_u8_letterbox_device_async)."""
         fs = w * h if frame_stride is None else frame_stride
         cs = fs * frames_per_clip if clip_stride is None else clip_stride
+        if d_crops is not None:
+            self._check(self.lib.vdf_hash_frames_u8_letterbox_device_async(self.ctx, d_frames, n_clips, frames_per_clip, w, h, fs, cs,
+                                                                           d_out, d_dontcare or None, d_crops or None, stream or None))
+            return None
+        crops = np.zeros((n_clips, 4), np.uint32)
         self._check(self.lib.vdf_hash_frames_u8_letterbox_device(self.ctx, d_frames, n_clips, frames_per_clip, w, h,
                                                                  fs, cs, d_out, d_dontcare or None, crops.ctypes.data,
                                                                  stream or None))
