@@ -907,6 +907,7 @@ def main():
                 for c0 in range(0, n, chunk):
                     base[c0:c0 + chunk] = torch.randint(0, 256, (min(chunk, n - c0), 16, h, w), dtype=torch.uint8, device=dev, generator=g)
                 oh = torch.zeros((n, 16), dtype=torch.int64, device=dev)
+                dcr = torch.zeros((n, 4), dtype=torch.int32, device=dev)  # the boxes stay on the device (vdf_hash_frames_u8_letterbox_device_async)
                 bar_t, bar_s = int(h * 0.12), int(w * 0.125)
                 for name in names:
                     fr = base
@@ -920,17 +921,18 @@ def main():
                         fr[:, :, :, w - bar_s:] = 16
                     elif name == "one_black_probe_frame_in_1000":  # a fade-in: every strip is letterbox, the edges converge, "no crop"
                         fr[::1000, 0] = 16
-                    eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream)
-                    ts, crops = timed_steps(lambda: eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream))
+                    eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream, d_crops=dcr.data_ptr())
+                    ts, _ = timed_steps(lambda: eng.hash_frames_letterbox_device(fr.data_ptr(), n, 16, w, h, oh.data_ptr(), stream=stream,
+                                                                                 d_crops=dcr.data_ptr()))
                     ms_l, ms_lo = med_min(ts)
-                    c0 = [int(x) for x in crops[0]]
+                    c0 = [int(x) for x in dcr[0].cpu()]
                     kept = (w - c0[0] - c0[1]) * (h - c0[2] - c0[3])
                     res[name] = {"ms_per_step": ms_l, "ms_min": ms_lo, "frames_per_s_per_gpu": n * 16 / (ms_l * 1e-3), "crop_of_clip_0": c0,
                                  "box_GB_per_s": n * 16 * kept / (ms_l * 1e-3) / 1e9}
                     if fr is not base:
                         del fr
                 hash_leg[key] = res
-                del base, oh
+                del base, oh, dcr
 
             letterbox_leg(args.hash_hd_clips, 1920, 1080)
             # the headline's own frame shape with bars: boxes of small frames take one workgroup per clip with the DCT fused (round 5)

@@ -39,6 +39,8 @@ KNOBS = [
     ({"VDF_ROWCROP_ALL": "1"}, "mfma"),
     ({"VDF_NO_BOXSTREAM": "1"}, "mfma"),
     ({"VDF_NO_SMALLCROP": "1"}, "mfma"),
+    ({"VDF_NO_LB_FUSED": "1"}, "mfma"),
+    ({"VDF_LB_HOST_PLAN": "1"}, "mfma"),
     ({"VDF_NO_HIT_FILTER": "1"}, "mfma"),
     ({"VDF_CAND_CAPACITY": "64"}, "mfma"),
     ({"VDF_RESIZE_MODE": "4"}, "mfma"),

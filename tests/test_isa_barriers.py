@@ -56,7 +56,7 @@ def test_no_stream_kernel_spills(isa):
     other = {k: v for k, v in sp.items() if (v[0] or v[2]) and k not in search and k not in resize}
     # the letterbox detect: letterbox_kernel (eight waves per SIMD, 64 registers) parked 4 values of its four-row walk in scratch until round 5
     # made its wave index wave-uniform for the compiler (readfirstlane): the per-wave LDS addresses moved to SGPRs
-    detect = {k: v for k, v in sp.items() if "letterbox_" in k}
+    detect = {k: v for k, v in sp.items() if "letterbox_" in k and "resize" not in k}  # (the fused small-frame kernel counts as a resize kernel)
     assert len(detect) == 4 and all(v[0] == 0 and v[2] == 0 for v in detect.values()), detect
     assert not other, other
 

@@ -2130,10 +2130,10 @@ struct Shared {
     __attribute__((aligned(16))) uint8_t probe[2 * kProbeBytes];
     uint32_t hist[4][256];  // the exact test's histogram, one per wave
     uint32_t edge[2][4];    // [probe][left, right, top, bottom] strips found
-    // the tables of the NEXT clip's box (requested right after its detect, parked here across the DCT of the current clip: in registers they
-    // were 23 more than three workgroups per CU have): [0 .. 127] horizontal hi | lo, [128 .. 255] vertical hi | lo; tail: bias[16], precision
-    __attribute__((aligned(16))) v4i tab[256];
-    __attribute__((aligned(16))) v4i tail[2][8];
+    // the tables of the current and the next clip's box (LDS-DMA right after a clip's detect; in registers across the DCT they were 23 more than
+    // three workgroups per CU have): [buffer][0 .. 127] horizontal hi | lo, [128 .. 255] vertical hi | lo; tail: [buffer][h | v] bias[16], precision
+    __attribute__((aligned(16))) v4i tab[2][256];
+    __attribute__((aligned(16))) v4i tail[2][2][8];
 };
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -2188,7 +2188,11 @@ __device__ __forceinline__ bool strip_exact(const uint8_t *s, uint32_t step, uin
 __device__ __forceinline__ void walk_edge(const uint8_t *probe, uint32_t e, uint32_t W, uint32_t H, uint32_t tol, uint32_t *hist,
                                           uint32_t &n0_out, uint32_t &n1_out)
 {
-    const uint32_t lane = threadIdx.x & 63, rr = lane >> 4, q = lane & 15, p = rr >> 1, k = rr & 1;
+    // (everything a lane derives from its number is re-derived per call, behind an asm the compiler cannot see through: hoisted out of the
+    // caller's persistent loop these values stayed live across the resize and the DCT - sixteen registers the kernel does not have)
+    uint32_t lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const uint32_t rr = lane >> 4, q = lane & 15, p = rr >> 1, k = rr & 1;
     const bool is_row = e >= 2, from_far = (e & 1u) != 0;  // wave-uniform
     const uint32_t limit = is_row ? H : W, len = is_row ? W : H;
     const int32_t left = (int32_t)len - 4 * (int32_t)q;
@@ -2273,8 +2277,9 @@ __device__ __forceinline__ void walk_edge(const uint8_t *probe, uint32_t e, uint
 __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
     const uint8_t *__restrict__ frames, uint32_t W, uint32_t H, size_t frame_stride, size_t clip_stride,
     const uint8_t *__restrict__ box_tables, const double *__restrict__ cos_table, uint64_t *__restrict__ out_hashes,
-    uint32_t *__restrict__ out_dontcare, uint32_t *__restrict__ out_crops, uint32_t n_clips, uint32_t tol)
+    uint32_t *__restrict__ out_dontcare, uint32_t *__restrict__ out_crops, uint32_t n_clips)
 {
+    [[maybe_unused]] constexpr uint32_t tol = 16;  // LetterboxColour::AnyColour(16): video_frames_gray.rs:205
     __shared__ DctShared sh;
     __shared__ lbs::Shared lb;
     const uint32_t tid = threadIdx.x, lane = tid & 63, g = lane >> 4, r16 = lane & 15;
@@ -2283,13 +2288,13 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
     const v4i x80 = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
 
     // probes: thread tid moves the 16 bytes at (row tid / 4, column 16 (tid % 4)) of frames 0 and 8
-    const uint32_t prow = tid >> 2, pcol = 16u * (tid & 3u);
-    const bool p_ok = prow < H && pcol < W;
     v4i pr[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    // (addresses as a uniform 64-bit base plus a 32-bit lane offset - the global_load saddr form: as 64-bit lane pointers the loop's
-    // invariant addresses were the values that no longer fitted three workgroups per CU, and a spill's reload waits with vmcnt(0))
-    const uint32_t p_off = prow * W + pcol;
+    // (addresses as a uniform 64-bit base plus a 32-bit lane offset - the global_load saddr form - and the lane offsets re-derived at
+    // every use behind an opaque asm: as loop invariants they were the registers that no longer fitted three workgroups per CU)
+    auto opaque_tid = [&]() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
     auto issue_probe = [&](uint32_t clip) {
+        const uint32_t t = opaque_tid(), prow = t >> 2, pcol = 16u * (t & 3u), p_off = prow * W + pcol;
+        const bool p_ok = prow < H && pcol < W;
         const uint8_t *cb = frames + (size_t)clip * clip_stride;
         if (p_ok) {
             pr[0] = load_pixels16<false>(cb + p_off, nullptr);
@@ -2297,6 +2302,8 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
         }
     };
     auto store_probe = [&]() {
+        const uint32_t t = opaque_tid(), prow = t >> 2, pcol = 16u * (t & 3u);
+        const bool p_ok = prow < H && pcol < W;
         if (p_ok) {
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -2309,8 +2316,10 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
     // box of the clip whose probes are in LDS (all threads; one barrier inside); writes it to out_crops
     uint32_t bx0 = 0, by0 = 0, bw = W, bh = H;
     auto detect = [&](uint32_t clip) {
-        uint32_t n0, n1;
+        uint32_t n0 = 0, n1 = 0;
+#ifndef VDF_ABL_NO_WALK
         lbs::walk_edge(lb.probe, wave, W, H, tol, lb.hist[wave], n0, n1);
+#endif
         if (lane == 0) { lb.edge[0][wave] = n0; lb.edge[1][wave] = n1; }
         __syncthreads();
         uint32_t c[4];
@@ -2331,49 +2340,72 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
         bw = W - bx0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[1]);
         bh = H - by0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[3]);
     };
-    // the box's pixels of this wave's four frames (4 wave .. 4 wave + 3); the tables of its size: thread tid fetches 16 bytes of the 4 KB
-    // (horizontal table of bw | vertical table of bh), the first eight threads of each half the 128-byte tail (bias, precision) as well
-    v4i px[4][4], tq = {0, 0, 0, 0}, tq_tail = {0, 0, 0, 0};
-    const uint32_t l_off = r16 * W + 16u * g;
-    auto issue_pixels = [&](uint32_t clip) {
-        // (the table requests go out FIRST: they come back from L2 and are parked in LDS while the pixel loads behind them are still in flight)
-        const uint8_t *t = box_tables + (size_t)(wave < 2 ? bw : W + 1 + bh) * lbs::kTableStride;  // (wave-uniform)
-        tq = *reinterpret_cast<const v4i *>(t + 16u * (tid & 127u));
-        if ((tid & 127u) < 8) tq_tail = *reinterpret_cast<const v4i *>(t + 2048 + 16u * (tid & 127u));
-        const uint8_t *cb = frames + (size_t)clip * clip_stride + (size_t)(4 * wave) * frame_stride + (size_t)by0 * W + bx0;
-        const bool col_ok = 16u * g < bw;
+    // The tables of the current box (bw, bh) -> lb.tab[buf] / lb.tail[buf] by LDS-DMA: no registers, no wait here.  Wave 0 / 1 bring the
+    // horizontal table's hi / lo half, wave 2 / 3 the vertical's; the first eight lanes of waves 0 and 2 the 128-byte tail (bias, precision).
+    // The reader (the resize of the clip after the current one) sits behind an `s_waitcnt vmcnt(0)` of every wave and a barrier.
+    const __amdgpu_buffer_rsrc_t tab_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(box_tables), 0, (W + H + 2u) * lbs::kTableStride, 0x00020000);
+    auto dma_tables = [&](uint32_t buf) {
+        const uint32_t at = (wave < 2 ? bw : W + 1u + bh) * lbs::kTableStride;  // wave-uniform
+        const uint32_t ln = opaque_tid() & 63u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (__attribute__((address_space(3))) void *)&lb.tab[buf][64u * wave], 16,
+                                                 (int)(at + 1024u * (wave & 1u) + 16u * ln), 0, 0, 0);
+        if ((wave & 1u) == 0 && ln < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (__attribute__((address_space(3))) void *)&lb.tail[buf][wave >> 1][0], 16,
+                                                     (int)(at + 2048u + 16u * ln), 0, 0, 0);
+    };
+    // the box's pixels of this wave's four frames (4 wave .. 4 wave + 3): quartet q = frame 4 wave + q, four 16-row blocks
+    v4i px[4][4];
+    auto issue_pixels_q = [&](uint32_t clip, int q) {
+        const uint32_t t = opaque_tid(), ln = t & 63u, l_off = (ln & 15u) * W + (ln & 48u);  // row r16, column 16 g
+        const uint8_t *cb = frames + (size_t)clip * clip_stride + (size_t)(4 * wave + q) * frame_stride + (size_t)by0 * W + bx0;
+        const bool col_ok = (ln & 48u) < bw;
+        // Non-temporal: the pixel stream is read once and must not push the PROBE frames out of L2 before this very loop reads them again as
+        // frames 0 and 8 (96 workgroups per XCD x 72 KB per clip is more than its 4 MB).  Measured, 20 000 clips of 64 x 64: no bars
+        // 0.252 -> 0.240 ms, side bars 0.286 -> 0.279; the stream alone (no walk, no DCT) 0.233 -> 0.203 (gpurun_out/r6e).  -DVDF_LBS_NT=0: plain loads.
+#ifndef VDF_LBS_NT
+#define VDF_LBS_NT 1
+#endif
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                px[q][m] = (v4i){0, 0, 0, 0};
-                if (16u * m + r16 < bh && col_ok) px[q][m] = load_pixels16<false>(cb + (size_t)q * frame_stride + (size_t)(16 * m) * W + l_off, nullptr);
-            }
+        for (int m = 0; m < 4; m++) {
+            px[q][m] = (v4i){0, 0, 0, 0};
+            if (16u * m + (ln & 15u) < bh && col_ok) px[q][m] = load_pixels16<false, VDF_LBS_NT != 0>(cb + (size_t)(16 * m) * W + l_off, nullptr);
         }
     };
-    auto park_tables = [&]() {
-        lb.tab[tid] = tq;
-        if ((tid & 127u) < 8) lb.tail[tid >> 7][tid & 127u] = tq_tail;
-    };
 
-    uint32_t clip = blockIdx.x;
+    // Per workgroup, clip by clip:   [probes of clip + 1 -> LDS, detect, its tables by DMA]  [resize of clip; every frame quartet's registers
+    // are refilled with clip + 1's pixels as soon as they are consumed]  [probe loads of clip + 2]  [DCT of clip]
+    // so the pixel stream of clip + 1 is in flight under the rest of the resize and the whole DCT, as in resize_dct_hash_persistent_kernel,
+    // and the detect works at LDS latency on probes that arrived a DCT ago.
+    uint32_t clip = blockIdx.x, cur = 0;
     if (clip < n_clips) {
         issue_probe(clip);
         store_probe();
         __syncthreads();
         detect(clip);
-        issue_pixels(clip);
+        dma_tables(0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) issue_pixels_q(clip, q);
         if (clip + gridDim.x < n_clips) issue_probe(clip + gridDim.x);
-        park_tables();
-        __syncthreads();
     }
     while (clip < n_clips) {
         const uint32_t next = clip + gridDim.x;
-        const v4i t_bh = lb.tab[lane], t_bl = lb.tab[64 + lane], t_avh = lb.tab[128 + lane], t_avl = lb.tab[192 + lane];
-        const int32_t bias_h = reinterpret_cast<const int32_t *>(lb.tail[0])[r16];
-        const v4i bias_v = lb.tail[1][g];
-        const int32_t prec_h = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[0])[16]);
-        const int32_t prec_v = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[1])[16]);
+        const bool more = next < n_clips;  // workgroup-uniform
+        // everything this wave asked for has landed: the probes of `next`, its share of tab[cur], the pixels of `clip`
+#ifdef VDF_LBS_PRIO_TOP
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) store_probe();
+        __syncthreads();  // probes and tab[cur] complete (the previous detect's reads of lb.probe and lb.edge are a DCT ago)
+        if (more) {
+            detect(next);
+            dma_tables(cur ^ 1u);  // (last read: the resize of the clip before `clip`)
+        }
+        const v4i t_bh = lb.tab[cur][lane], t_bl = lb.tab[cur][64 + lane], t_avh = lb.tab[cur][128 + lane], t_avl = lb.tab[cur][192 + lane];
+        const int32_t bias_h = reinterpret_cast<const int32_t *>(lb.tail[cur][0])[r16];
+        const v4i bias_v = lb.tail[cur][1][g];
+        const int32_t prec_h = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[cur][0])[16]);
+        const int32_t prec_v = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int32_t *>(lb.tail[cur][1])[16]);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -2390,19 +2422,21 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
             vh = __builtin_amdgcn_mfma_i32_16x16x64_i8(t_avh, b, vh, 0, 0, 0);
             vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(t_avl, b, vl, 0, 0, 0);
             sh.cube[(4 * wave + q) * 64 + g * 16 + r16] = finalize4(vh, vl, prec_v);
+            if (more) issue_pixels_q(next, q);  // in flight during the rest of the resize and the whole DCT below
         }
+#ifndef VDF_ABL_NO_PREFETCH
+        if (next + gridDim.x < n_clips) issue_probe(next + gridDim.x);
+#endif
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();  // the cube is complete; the previous detect's reads of lb.probe are long over
-        if (next < n_clips) {  // workgroup-uniform
-            store_probe();
-            __syncthreads();
-            detect(next);
-            issue_pixels(next);                                      // in flight during the whole DCT below
-            if (next + gridDim.x < n_clips) issue_probe(next + gridDim.x);  // ... and the next resize
-            park_tables();  // (the resize above was the last reader of the previous clip's, a barrier ago; the DCT's barriers come before the next)
-        }
+        __syncthreads();  // the cube is complete
+#ifdef VDF_ABL_NO_DCT2
+        if (tid < 16) out_hashes[(size_t)clip * 16 + tid] = sh.cube[tid * 64];
+        __syncthreads();
+#else
         dct_hash_block(sh, (const_f64_ptr)(uintptr_t)cos_table, clip, out_hashes, out_dontcare);
+#endif
         clip = next;
+        cur ^= 1u;
     }
 }
 
@@ -2419,7 +2453,7 @@ hipError_t launch_letterbox_hash_small(const uint8_t *frames, size_t n_clips, ui
     if (wgs_per_cu > 0) per_cu = std::min(per_cu, wgs_per_cu);
     const uint32_t grid = (uint32_t)std::min<size_t>(n_clips, (size_t)cus * (size_t)per_cu);
     hipLaunchKernelGGL(letterbox_resize_dct_hash_small_kernel, dim3(grid), dim3(256), 0, stream, frames, w, h, frame_stride, clip_stride,
-                       reinterpret_cast<const uint8_t *>(box_tables), cos_table, out_hashes, out_dontcare, out_crops, (uint32_t)n_clips, 16u);
+                       reinterpret_cast<const uint8_t *>(box_tables), cos_table, out_hashes, out_dontcare, out_crops, (uint32_t)n_clips);
     return hipGetLastError();
 }
 
