@@ -297,7 +297,8 @@ def search_with_references(ref_hashes, ref_durations, ref_paths, hashes, duratio
 
 
 # --- numpy / scipy twin (independent restatement used to cross-check the C oracle) ---------------
-def np_lanczos3_coeffs(in_size: int, out_size: int = DCT_SIZE):
+def np_lanczos3_weights(in_size: int, out_size: int = DCT_SIZE):
+    """(window, start[out], size[out], w[out, window] f64): the normalised Lanczos3 weights before quantisation."""
     scale = in_size / out_size
     fscale = max(scale, 1.0)
     radius = 3.0 * fscale
@@ -326,7 +327,11 @@ def np_lanczos3_coeffs(in_size: int, out_size: int = DCT_SIZE):
         starts.append(x_min)
         sizes.append(trail)
         rows.append(row)
-    vals = np.stack(rows)
+    return window, np.array(starts), np.array(sizes), np.stack(rows)
+
+
+def np_lanczos3_coeffs(in_size: int, out_size: int = DCT_SIZE):
+    window, starts, sizes, vals = np_lanczos3_weights(in_size, out_size)
     max_w = vals.max()
     precision = 0
     for p in range(16):
@@ -334,7 +339,7 @@ def np_lanczos3_coeffs(in_size: int, out_size: int = DCT_SIZE):
         if int(np.floor(max_w * (1 << (p + 1)) + 0.5)) >= (1 << 15):
             break
     q = np.floor(np.abs(vals) * (1 << precision) + 0.5) * np.sign(vals)  # round half away from zero
-    return precision, window, np.array(starts), np.array(sizes), q.astype(np.int64)
+    return precision, window, starts, sizes, q.astype(np.int64)
 
 
 def np_resize_frame(frame: np.ndarray) -> np.ndarray:
