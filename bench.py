@@ -29,7 +29,9 @@ Named legs in the same line (sizes are flags, so tests run them small):
                    vdf_search_cache_entries (PathBuf ranks, upload, Search::sort on the device, search, map), phase by phase (N = 1)
   windowed, valu_backend, refs_c5_shape, hash.* (N = 1), cpu_baseline (the oracle on host cores; N = 1)
 The line is kept short (what each leg runs is written down in DESIGN.md section 6, not repeated in every line) and ENDS with
-"hash_summary": BASELINE's metric is "pairs/s + frames/s", and whoever keeps only the tail of the line still reads the second half.
+"summary" (at most 1.5 KB): "hash_summary" - BASELINE's metric is "pairs/s + frames/s", and whoever keeps only the tail of the line still
+reads the second half - the 10 M leg, c5_end_to_end, cache_ingest, the three letterbox_64x64 times and the GPU clock / power sampled
+during the headline steps.
 Side legs report the median and the minimum over their steps.
 """
 import argparse
@@ -270,7 +272,7 @@ def search_roofline(backend, kernel_ms):
     return roofline, extra, dtype
 
 
-METRIC = "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'hash_summary']"
+METRIC = "hash-pairs/sec all-pairs Hamming (search(), tolerance 0.35) [+ frames/sec DCT-hash in 'summary.hash_summary']"
 
 
 def headline(value, steps, warmup, ms_per_step, n_gpus, dtype, n_hashes, shard, pairs, tol_int, parallelism, roofline):
@@ -285,13 +287,138 @@ def headline(value, steps, warmup, ms_per_step, n_gpus, dtype, n_hashes, shard, 
             "roofline": roofline}
 
 
+class ClockSampler:
+    """Samples the GPU's shader clock and socket power from sysfs on a host thread while a timed region runs, so that a box-to-box spread
+    of an unchanged kernel can be attributed (0.764 vs 0.787 of the MFMA peak with no clock figure beside it).
+    sclk: the level pp_dpm_sclk marks with '*' (or hwmon's freq1_input); power: hwmon's power1_average / power1_input (microwatts).
+    Reads nothing but /sys; every failure (no such file, no permission) leaves the field null - the bench never depends on it."""
+
+    def __init__(self, device_index=0, period_s=0.004):
+        import glob
+        import threading
+
+        self.period = period_s
+        self.sclk, self.power = [], []
+        self._stop = threading.Event()
+        self._thread = None
+        self.card = None
+        cards = sorted(c for c in glob.glob("/sys/class/drm/card[0-9]*") if os.path.exists(os.path.join(c, "device", "pp_dpm_sclk")))
+        want = None
+        try:  # the card whose PCI address is the torch device's
+            import torch
+
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        for c in cards:
+            if want and want in os.path.realpath(os.path.join(c, "device")):
+                self.card = c
+        if self.card is None and cards:
+            self.card = cards[min(device_index, len(cards) - 1)]
+        self.hwmon = None
+        if self.card:
+            hw = sorted(glob.glob(os.path.join(self.card, "device", "hwmon", "hwmon*")))
+            self.hwmon = hw[0] if hw else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def sample(self):
+        if not self.card:
+            return
+        t = self._read(os.path.join(self.card, "device", "pp_dpm_sclk"))
+        mhz = None
+        if t:
+            for line in t.splitlines():
+                if "*" in line:
+                    try:
+                        mhz = float(line.split(":")[1].strip().split("M")[0])
+                    except (IndexError, ValueError):
+                        pass
+        if mhz is None and self.hwmon:
+            t = self._read(os.path.join(self.hwmon, "freq1_input"))
+            if t and t.strip().isdigit():
+                mhz = int(t) / 1e6
+        if mhz is not None:
+            self.sclk.append(mhz)
+        if self.hwmon:
+            for name in ("power1_average", "power1_input"):
+                t = self._read(os.path.join(self.hwmon, name))
+                if t and t.strip().isdigit():
+                    self.power.append(int(t) / 1e6)
+                    break
+
+    def __enter__(self):
+        import threading
+
+        def run():
+            while not self._stop.is_set():
+                self.sample()
+                self._stop.wait(self.period)
+
+        if self.card:
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread:
+            self._thread.join()
+        return False
+
+    def result(self):
+        med = lambda v: float(np.median(v)) if v else None  # noqa: E731
+        return {"sclk_mhz_median": med(self.sclk), "power_w_median": med(self.power), "samples": len(self.sclk)}
+
+
+SUMMARY_MAX_BYTES = 1536
+
+
+def summary_object(out):
+    """The line's LAST object, at most SUMMARY_MAX_BYTES of JSON: what a reader of the line's tail must find (the driver keeps 2 - 8 KB of a
+    line that is 11 KB): the frames/s half of BASELINE's metric, the north_star's own 10 M configuration, and one figure per widened leg."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+    s = {}
+    if "hash" in out and "roofline" in out["hash"]:
+        s["hash_summary"] = hash_summary(out["hash"])
+    c4 = out.get("c4_10m_sharded")
+    if isinstance(c4, dict):  # BASELINE configs[3]; at one GPU the north_star's own target size
+        s["ten_million"] = {"n_hashes": c4.get("n_hashes"), "n_gpus": c4.get("n_gpus"), "ms": c4.get("ms_per_step"), "pairs_per_s": c4.get("pairs_per_s"),
+                            "roofline_frac": (c4.get("roofline") or {}).get("frac"), "planted_found": c4.get("match_groups"),
+                            "planted": c4.get("planted_pairs")}
+        if "skipped" in c4:
+            s["ten_million"] = {"skipped": c4["skipped"]}
+    if isinstance(out.get("c5_end_to_end"), dict):
+        s["c5_end_to_end"] = pick(out["c5_end_to_end"], ("ms_per_step", "ms_min", "skipped"))
+    ci = out.get("cache_ingest")
+    if isinstance(ci, dict):
+        s["cache_ingest"] = {"entries": ci.get("entries"), "host_ms": ci.get("host_ms"), "search_ms": (ci.get("search_cache_entries") or {}).get("search_ms")}
+        if "skipped" in ci:
+            s["cache_ingest"] = {"skipped": ci["skipped"]}
+    lb = (out.get("hash") or {}).get("letterbox_64x64")
+    if isinstance(lb, dict):
+        s["letterbox_64x64_ms"] = {k: round(v["ms_per_step"], 4) for k, v in lb.items() if isinstance(v, dict) and "ms_per_step" in v}
+    if isinstance((out.get("roofline") or {}).get("clock"), dict):
+        s["clock"] = out["roofline"]["clock"]
+    return s
+
+
 def hash_summary(hash_leg):
     """BASELINE's second half (frames/sec DCT-hash, configs[2]) in a form short enough to survive at the END of the line."""
     r = hash_leg["roofline"]
     out = {"metric": "frames/sec DCT-hash, BASELINE configs[2]: clips of 16 x 64 x 64 u8 -> VideoHash", "value": hash_leg["value"],
            "unit": "frames/s", "clips_per_gpu": hash_leg["clips_per_gpu"], "n_gpus": hash_leg["n_gpus"],
            "ms_per_step": hash_leg["ms_per_step"], "dtype": "u8 -> i8 MFMA fixed point (exact) -> f64 DCT",
-           "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")}}
+           "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "clock")}}
     cb = hash_leg.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
@@ -299,12 +426,14 @@ def hash_summary(hash_leg):
 
 
 def finish_line(out):
-    """Order of the one JSON line: the contract's keys first, the legs, and hash_summary LAST (a reader of the line's tail gets it)."""
-    if "hash" in out and "roofline" in out["hash"]:
-        out["hash_summary"] = hash_summary(out["hash"])
-    hs = out.pop("hash_summary", None)
-    if hs is not None:
-        out["hash_summary"] = hs
+    """Order of the one JSON line: the contract's keys first, the legs, and `summary` LAST (a reader of the line's tail gets it):
+    hash_summary (BASELINE's frames/s half), the 10 M leg, and one figure per widened leg, in at most SUMMARY_MAX_BYTES."""
+    out.pop("hash_summary", None)
+    out.pop("summary", None)
+    summ = summary_object(out)
+    while len(json.dumps(summ)) > SUMMARY_MAX_BYTES and len(summ) > 1:  # never happens with the fields above; the bound is the contract
+        summ.pop(list(summ)[-1])
+    out["summary"] = summ
     return json.dumps(out)
 
 
@@ -658,16 +787,19 @@ def main():
     gc.collect()
     gc.disable()  # a generation-2 collection (tens of ms after importing torch) must not land inside a 150 ms step
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    clk = ClockSampler(local_rank)
+    with clk:  # sysfs reads on a host thread: the GPU's clock and power WHILE the timed steps run (rank 0's figures are reported)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
     gc.enable()
     dt = max_over_ranks(dt)
 
     backend = os.environ.get("VDF_SEARCH_BACKEND", "mfma")
     roofline, extra, dtype = search_roofline(backend, kernel_ms)
+    roofline["clock"] = clk.result()
     out = headline(pairs * args.steps / dt, args.steps, args.warmup, dt / args.steps * 1e3, world, dtype, n_total, hi - lo, pairs, tol_int,
                    f"row tiles round-robin over {world} GPU(s), one RCCL all-gather" if world > 1 else "single GPU", roofline)
     out.update({"match_groups": n_groups, "search_backend": backend, "n_launches": int(round(float(np.mean(launches)))),
@@ -845,11 +977,19 @@ def main():
         for _ in range(max(args.warmup, 1)):
             eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
         barrier()
-        ev0.record()
-        for _ in range(args.steps):
-            eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
-        ev1.record()
-        torch.cuda.synchronize()
+        # (the leg is milliseconds long: repeat it untimed under the sampler until ~0.25 s of this kernel have run, then time the steps)
+        hclk = ClockSampler(local_rank, period_s=0.002)
+        with hclk:
+            t_clk = time.perf_counter()
+            while time.perf_counter() - t_clk < 0.25:
+                for _ in range(20):
+                    eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(args.steps):
+                eng.hash_frames_device(frames.data_ptr(), nc, 16, 64, 64, out_h.data_ptr(), stream=stream)
+            ev1.record()
+            torch.cuda.synchronize()
         ms = max_over_ranks(ev0.elapsed_time(ev1) / args.steps)
         fps = world * nc * 16 / (ms * 1e-3)
         h_gbs = nc * 16 / (ms * 1e-3) * BYTES_PER_FRAME / 1e9  # per GPU: the kernel's own roofline
@@ -857,7 +997,7 @@ def main():
         hash_leg = {"value": fps, "unit": "frames/s", "clips_per_gpu": nc, "n_gpus": world, "ms_per_step": ms,
                     "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": h_gbs,
                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h_gbs / HBM_PEAK_GBS,
-                                 "traffic": h_traffic, "traffic_source": h_src}}
+                                 "traffic": h_traffic, "traffic_source": h_src, "clock": hclk.result()}}
         del frames, out_h
         # the same path at the size decoders really hand over (informational; the headline stays the 64 x 64 config)
         if args.hash_hd_clips > 0 and world == 1:
@@ -948,7 +1088,7 @@ def main():
     eng.close()
     if rank == 0:
         # order of the line: contract keys (+ roofline, cpu_baseline), then BASELINE configs[3] - strong scaling, the leg to read first
-        # on a multi-GPU run - then the other legs, the long hash leg, and hash_summary last (finish_line)
+        # on a multi-GPU run - then the other legs, the long hash leg, and summary last (finish_line)
         for k in ("c4_10m_sharded", "ten_million", "c5_end_to_end", "dup_heavy", "cache_ingest", "refs_c5_shape", "windowed", "valu_backend"):
             if k in legs:
                 out[k] = legs[k]

@@ -57,18 +57,69 @@ def test_search_roofline_and_headline_assemble(backend, tmp_path, monkeypatch):
                               "vs_baseline", "dtype", "data", "config"]
     assert out["vs_baseline"] is None and out["config"]["workload"].startswith("BASELINE configs[1]")
     out["cpu_baseline"] = {"value": 3.6e8, "unit": "pairs/s", "cores": 1, "kind": "port", "sample": "x"}
-    out["c4_10m_sharded"] = bench.c4_summary(10_000_000, 8, 1400.0)
+    out["c4_10m_sharded"] = dict(bench.c4_summary(10_000_000, 8, 1400.0), match_groups=100, planted_pairs=100,
+                                 roofline={"bound": "mfma", "frac": 0.81, "kernel": "hamming_mfma2_kernel"})
+    out["c5_end_to_end"] = {"workload": "x" * 200, "ms_per_step": 13.3, "ms_min": 13.0, "phases_ms": {"hash_ms": 11.2}}
+    out["cache_ingest"] = {"entries": 10_000_000, "host_ms": 281.9, "search_cache_entries": {"search_ms": 271.4, "rank_ms": 214.9}}
+    out["roofline"]["clock"] = {"sclk_mhz_median": 2150.0, "power_w_median": 1390.5, "samples": 400}
+    lb = {"clips": 20000, "w": 64, "h": 64}
+    for name, ms in (("no_bars", 0.2301), ("top_bottom_bars", 0.2604), ("side_bars", 0.2712)):
+        lb[name] = {"ms_per_step": ms, "ms_min": ms, "frames_per_s_per_gpu": 1.3e9, "crop_of_clip_0": [0, 0, 7, 7], "box_GB_per_s": 5000.0}
     out["hash"] = {"value": 1.5e9, "unit": "frames/s", "clips_per_gpu": 100_000, "n_gpus": 1, "ms_per_step": 1.04,
                    "roofline": {"bound": "hbm", "kernel": "resize_dct_hash_persistent_kernel", "achieved": 6300.0, "peak": 8000.0,
-                                "unit": "GB/s", "frac": 0.7875, "traffic": None, "traffic_source": "x"},
-                   "full_hd": {"blah": "x" * 3000}, "cpu_baseline": {"value": 6e5, "unit": "frames/s", "cores": 256, "kind": "port", "sample": "y"}}
+                                "unit": "GB/s", "frac": 0.7875, "traffic": None, "traffic_source": "x",
+                                "clock": {"sclk_mhz_median": 2390.0, "power_w_median": 900.1, "samples": 120}},
+                   "letterbox_64x64": lb,
+                   "full_hd": {"blah": "x" * 3000},
+                   "cpu_baseline": {"value": 6e5, "unit": "frames/s", "cores": 256, "kind": "port",
+                                    "sample": "oracle from_frames over a 256-thread pool, 24576 clips of 16x64x64 (single thread: 384 clips)"}}
     line = bench.finish_line(out)
     d = json.loads(line)
-    assert list(d)[-1] == "hash_summary" and '"hash_summary"' in line[-1500:]  # a reader of the line's TAIL gets the second half of the metric
-    hs = d["hash_summary"]
+    # a reader of the line's TAIL gets, in one object of at most 1.5 KB: the second half of the metric, the north_star's 10 M leg and one
+    # figure per widened leg (the driver keeps 2 - 8 KB of a line that is 11 KB: VERDICT r05 weak 6)
+    assert list(d)[-1] == "summary" and "hash_summary" not in d
+    sm = d["summary"]
+    assert len(json.dumps(sm)) <= bench.SUMMARY_MAX_BYTES == 1536 and line.endswith(json.dumps(sm) + "}")
+    assert set(sm) == {"hash_summary", "ten_million", "c5_end_to_end", "cache_ingest", "letterbox_64x64_ms", "clock"}
+    hs = sm["hash_summary"]
     assert hs["value"] == 1.5e9 and hs["roofline"]["frac"] == 0.7875 and hs["cpu_baseline"]["cores"] == 256 and hs["unit"] == "frames/s"
+    assert hs["roofline"]["clock"]["sclk_mhz_median"] == 2390.0 and sm["clock"]["power_w_median"] == 1390.5
+    assert sm["ten_million"] == {"n_hashes": 10_000_000, "n_gpus": 8, "ms": 1400.0, "pairs_per_s": d["c4_10m_sharded"]["pairs_per_s"],
+                                 "roofline_frac": 0.81, "planted_found": 100, "planted": 100}
+    assert sm["c5_end_to_end"] == {"ms_per_step": 13.3, "ms_min": 13.0} and sm["cache_ingest"] == {"entries": 10_000_000, "host_ms": 281.9, "search_ms": 271.4}
+    assert sm["letterbox_64x64_ms"] == {"no_bars": 0.2301, "top_bottom_bars": 0.2604, "side_bars": 0.2712}
     c4 = d["c4_10m_sharded"]
     assert c4["scaling"] == "strong" and abs(c4["speedup_vs_n1_model"] - bench.C4_N1_REFERENCE_MS / 8 / 1400.0) < 1e-12
+    # legs that did not run leave no key behind, and the summary of a headline-only line is still valid JSON at the tail
+    bare = json.loads(bench.finish_line({"metric": "m", "roofline": {"frac": 0.8}}))
+    assert list(bare)[-1] == "summary" and bare["summary"] == {}
+
+
+def test_clock_sampler_reads_what_sysfs_offers(tmp_path, monkeypatch):
+    """ClockSampler on a fake /sys tree: the '*' level of pp_dpm_sclk, hwmon's power in microwatts; and nothing at all without a card."""
+    import glob as _glob
+
+    card = tmp_path / "card1" / "device"
+    (card / "hwmon" / "hwmon3").mkdir(parents=True)
+    (card / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 2150Mhz *\n2: 2400Mhz\n")
+    (card / "hwmon" / "hwmon3" / "power1_average").write_text("1391000000\n")
+    real_glob = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: real_glob(pat.replace("/sys/class/drm", str(tmp_path))))
+    real_exists = os.path.exists
+    monkeypatch.setattr(os.path, "exists", lambda p: real_exists(p))
+    s = bench.ClockSampler(0, period_s=0.001)
+    assert s.card and s.card.endswith("card1")
+    with s:
+        import time
+
+        time.sleep(0.02)
+    r = s.result()
+    assert r["sclk_mhz_median"] == 2150.0 and r["power_w_median"] == 1391.0 and r["samples"] >= 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    s = bench.ClockSampler(0)
+    with s:
+        pass
+    assert s.result() == {"sclk_mhz_median": None, "power_w_median": None, "samples": 0}
 
 
 def test_executed_pairs_and_medians():

@@ -202,3 +202,51 @@ def test_split_range_is_contiguous_and_complete():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """Rank 1's launch fails before it reaches the filter's agree (an out-of-memory on one GPU, say): nobody may hang."""
+    import datetime
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import hashgen as hg
+    from vid_dup_finder_lib_amd import distributed as vd
+
+    rng = np.random.default_rng(78)
+    words, dur = hg.planted_set(rng, 400, n_clusters=20, max_copies=6, max_flips=200, durations="windowed")
+    w, d, _ = hg.sort_by_duration(words, dur)
+    fw, fd = torch.from_numpy(w.view(np.int64)), torch.from_numpy(d.view(np.int32))
+
+    class Failing(FakeEngine):
+        hit_filter_enabled = True
+
+        def search_self_device_replay(self, *a, **kw):
+            if rank == 1:
+                raise MemoryError("rank 1: hipMalloc failed")
+            return super().search_self_device_replay(*a, **kw)
+
+    eng = Failing(w, d)
+    eng.matched_bits = None
+    msg = "no exception"
+    try:
+        vd.search_self_sharded(eng, fw, fd, 350)
+    except Exception as e:  # noqa: BLE001
+        msg = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out_dir, f"exc_{rank}.txt"), "w") as f:
+        f.write(msg)
+    dist.barrier()  # both ranks got here: neither is stuck in a collective the other never entered
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_a_rank_that_fails_before_agree_releases_its_peers(tmp_path):
+    """DistExchange's failure protocol (distributed.py): the failed rank still makes the launch's agree collective, flagged; its peer
+    skips the filter, both meet at the status exchange and BOTH raise - the failed one its own error, the other one naming a peer."""
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = open(tmp_path / "exc_0.txt").read(), open(tmp_path / "exc_1.txt").read()
+    assert e1 == "MemoryError: rank 1: hipMalloc failed"
+    assert e0.startswith("RuntimeError: search_self_sharded: the launch failed on another rank")

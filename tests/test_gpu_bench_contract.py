@@ -49,10 +49,18 @@ def test_bench_emits_the_contract_line(backend):
     assert t["n_hashes"] == 200000 and t["pairs"] == 200000 * 199999 // 2 and t["match_groups"] >= t["planted_pairs"] - 1
     assert d["ten_million"]["ms_per_step"] == t["ms_per_step"] and t["scaling"] == "strong" and d["ten_million"]["same_as"] == "c4_10m_sharded"
     keys = list(d)
-    assert keys[-1] == "hash_summary" and keys.index("c4_10m_sharded") < keys.index("c5_end_to_end") < keys.index("hash")
-    hs = d["hash_summary"]  # the second half of BASELINE's metric, where a reader of the line's tail finds it
+    assert keys[-1] == "summary" and keys.index("c4_10m_sharded") < keys.index("c5_end_to_end") < keys.index("hash")
+    sm = d["summary"]  # the line's last <= 1.5 KB: the second half of BASELINE's metric, the 10 M leg, one figure per widened leg
+    assert len(json.dumps(sm)) <= 1536 and lines[0].endswith(json.dumps(sm) + "}") and len(lines[0]) < 13000
+    hs = sm["hash_summary"]
     assert hs["value"] == d["hash"]["value"] and hs["roofline"]["frac"] == d["hash"]["roofline"]["frac"] and hs["cpu_baseline"]["cores"] >= 1
-    assert '"hash_summary"' in lines[0][-1800:] and len(lines[0]) < 12000
+    assert sm["ten_million"]["ms"] == t["ms_per_step"] and sm["ten_million"]["planted_found"] == t["match_groups"]
+    assert sm["c5_end_to_end"]["ms_per_step"] == d["c5_end_to_end"]["ms_per_step"] and sm["cache_ingest"]["host_ms"] == d["cache_ingest"]["host_ms"]
+    assert set(sm["letterbox_64x64_ms"]) == {"no_bars", "top_bottom_bars", "side_bars"}
+    # the GPU's clock and power while the timed steps ran (sysfs; null where the box does not show them)
+    for ck in (d["roofline"]["clock"], d["hash"]["roofline"]["clock"]):
+        assert set(ck) == {"sclk_mhz_median", "power_w_median", "samples"}
+        assert ck["sclk_mhz_median"] is None or 100 < ck["sclk_mhz_median"] < 3500
     ci = d["cache_ingest"]  # cache bytes -> groups, phase by phase
     assert ci["entries"] == 30000 and ci["match_groups"] >= ci["planted_pairs"] - 1 and ci["decode_ms"] > 0 and ci["host_ms"] > 0
     assert set(ci["search_cache_entries"]) >= {"rank_ms", "upload_ms", "sort_ms", "search_ms", "map_ms", "total_ms"}

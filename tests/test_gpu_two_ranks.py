@@ -41,7 +41,7 @@ def test_bench_launches_its_own_ranks():
     assert abs(two["config"]["hashes_per_gpu_shard"] * 2 - n2) <= 1
     assert two["match_groups"] == one["match_groups"] > 0
     assert two["config"]["pairs"] == one["config"]["pairs"] == n2 * (n2 - 1) // 2
-    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0 and two["hash_summary"]["n_gpus"] == 2
+    assert two["hash"]["n_gpus"] == 2 and two["value"] > 0 and two["summary"]["hash_summary"]["n_gpus"] == 2
     assert two["rccl_ranks_seen"] == 0 and two["dist_backend"] == "gloo"  # (two ranks on one GPU cannot use RCCL: this run says so)
     keys = list(two)
     assert keys.index("c4_10m_sharded") == min(keys.index(k) for k in keys if isinstance(two[k], dict) and k not in ("config", "roofline", "hbm_operand_stream_model"))
@@ -61,6 +61,34 @@ def test_bench_launches_its_own_ranks():
     assert sp["match_groups"] == two["match_groups"] and len(sp["per_device_kernel_ms"]) == 2 and sp["value"] > 0
     assert sp["devices"] == [0, 0] and "device-to-device" in sp["replication"]  # one GPU here: the device list wraps
     assert sp["c4_10m_sharded"]["n_hashes"] == 60000 and "single_process" not in one
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """`bench.py --gpus 8` before the driver's 8-GPU node runs it: eight children spawned before any GPU call, collectives over gloo (eight
+    ranks share GPU 0; RCCL refuses that), every leg at a reduced size, and the single-process C-ABI form in a fresh child afterwards -
+    the 8-way deal of row tiles, the 8-way hit gather / merge and the exchange of the replay filter are the code of the real run."""
+    import time
+
+    t0 = time.perf_counter()
+    n1 = 70000
+    n8 = int(round(n1 * 8 ** 0.5))
+    d = _bench(["--gpus", "8", "--n-hashes", str(n1)], {"VDF_DIST_BACKEND": "gloo"})
+    wall = time.perf_counter() - t0
+    assert wall < 180, wall
+    assert d["n_gpus"] == 8 and d["config"]["n_hashes"] == n8 and d["value"] > 0 and d["match_groups"] > 0
+    assert d["rccl_ranks_seen"] == 0 and d["dist_backend"] == "gloo"
+    assert abs(d["config"]["hashes_per_gpu_shard"] * 8 - n8) <= 8
+    c4 = d["c4_10m_sharded"]
+    assert c4["n_gpus"] == 8 and c4["n_hashes"] == 60000 and c4["scaling"] == "strong" and c4["match_groups"] >= c4["planted_pairs"] - 1
+    assert "speedup_vs_n1_model" not in c4 or c4["speedup_vs_n1_model"] > 0  # (only quoted at the 10 M size)
+    c5 = d["c5_end_to_end"]
+    assert c5["n_gpus"] == 8 and c5["groups"] == c5["planted_references"] > 0 and c5["members"] == c5["groups"]
+    assert d["hash"]["n_gpus"] == 8 and d["summary"]["hash_summary"]["n_gpus"] == 8 and d["summary"]["ten_million"]["n_gpus"] == 8
+    sp = d["single_process"]  # the same library through ONE eight-slot context, in a fresh child
+    assert sp["rccl"] == "ok" and sp["devices"] == [0] * 8 and len(sp["per_device_kernel_ms"]) == 8
+    assert sp["match_groups"] == d["match_groups"] and sp["c4_10m_sharded"]["n_hashes"] == 60000
+    one = _bench(["--gpus", "1", "--n-hashes", str(n8)])
+    assert one["match_groups"] == d["match_groups"] and one["config"]["pairs"] == d["config"]["pairs"]
 
 
 def _worker(rank, world, port, capacity, out_dir):

@@ -346,9 +346,15 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
         VDF_HIP(ctx, ctx->hit_bitmaps.reserve(2 * words * 4 + 16));
         uint32_t *bm = ctx->hit_bitmaps.as<uint32_t>();
         VDF_HIP(ctx, vdf::launch_filter_mark_incoming(d_list, stored, (uint32_t)n_cols, bm, stream));
-        if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm, words, stream); if (r) return r; }
-        VDF_HIP(ctx, vdf::launch_filter_mark_covered(d_list, stored, (uint32_t)n_cols, bm, stream));
-        if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm + words, words, stream); if (r) return r; }
+        // (an exchange that could not be carried out says so on every shard alike - kExchangeOff: the launch goes on unfiltered)
+        if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm, words, stream); if (r < 0) return r; if (r == vdf_impl::kExchangeOff) filter = false; }
+        if (filter) {
+            VDF_HIP(ctx, vdf::launch_filter_mark_covered(d_list, stored, (uint32_t)n_cols, bm, stream));
+            if (fx) { const int r = fx->or_bitmap(shard_index, ctx, bm + words, words, stream); if (r < 0) return r; if (r == vdf_impl::kExchangeOff) filter = false; }
+        }
+    }
+    if (filter) {
+        uint32_t *bm = ctx->hit_bitmaps.as<uint32_t>();
         VDF_HIP(ctx, vdf::launch_filter_compact(d_list, stored, (uint32_t)n_cols, bm, ctx->hits2.as<vdf_hit>(), L.counters + 7, stream));
         VDF_HIP(ctx, hipMemcpyAsync(fin + 7, L.counters + 7, 8, hipMemcpyDeviceToHost, stream));
         VDF_HIP(ctx, hipStreamSynchronize(stream));
@@ -1239,7 +1245,7 @@ int search_self_resident(vdf_ctx *ctx, size_t n, uint32_t tol_int, vdf_groups *o
                                       d->up_dur.as<uint32_t>(), nullptr, n, tol_int, (uint32_t)k, (uint32_t)G, row_begin, row_end,
                                       use_bitmap ? d->matched.as<uint32_t>() : nullptr, 0, nullptr, capacity,
                                       &d->r_n_hits, &d->r_overflow, d->stream, /*replay_only=*/true, &d->host_hits, fx.get());
-            if (r && fx) fx->abort();  // the other devices must not wait for this one at the filter's meeting points
+            if (r && fx && !d->err_secondary) fx->abort(r, "device " + std::to_string(d->device) + ": " + d->err);  // the other devices must not wait for this one at the filter's meeting points
             return r;
         });
         if (rc) { vdf_groups_free(out); return rc; }

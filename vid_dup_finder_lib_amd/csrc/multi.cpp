@@ -122,15 +122,21 @@ int for_each_device(vdf_ctx *ctx, const std::function<int(int, vdf_ctx *)> &f)
         w->done = false;
         w->cv.notify_all();
     }
+    // The status reported is the ROOT CAUSE where there is one: a slot that only left because another slot failed (err_secondary, set by the
+    // exchange's waiters) yields to the slot that failed on its own, whatever their order in the device list.
     int rc = VDF_OK;
+    bool have_primary = false;
     for (size_t k = 0; k < G; k++) {
         Worker *w = ctx->workers[k];
         std::unique_lock<std::mutex> lk(w->m);
         w->cv.wait(lk, [&] { return w->done; });
-        if (w->rc != VDF_OK && rc == VDF_OK) {
+        vdf_ctx *d = ctx->subs[k];
+        if (w->rc != VDF_OK && (rc == VDF_OK || (!have_primary && !d->err_secondary))) {
             rc = w->rc;
-            ctx->err = "device " + std::to_string(ctx->subs[k]->device) + " (slot " + std::to_string(k) + "): " + ctx->subs[k]->err;
+            have_primary = !d->err_secondary;
+            ctx->err = "device " + std::to_string(d->device) + " (slot " + std::to_string(k) + "): " + d->err;
         }
+        d->err_secondary = false;
     }
     return rc;
 }
@@ -192,16 +198,24 @@ void destroy_multi(vdf_ctx *ctx)
 //   same exchange as a group of ncclBroadcasts (one per shard, root = its owner);
 //   repeated devices (a device list like {0, 0}: tests on one GPU) or one device: plain device-to-device copies.
 // elem_bytes must be a multiple of 4.  Each device's copy is ordered on that device's stream.
+// rccl_optional (the replay filter's bitmaps - an optimisation must not make librccl a dependency of host-level search()): when the
+// communicators cannot be had (no librccl, ncclCommInitAll fails) the data travels as plain device-to-device copies instead.
+// *used_plain (nullable) reports which way it went: after plain copies the sources must stay untouched until every device's copies ran.
 static int replicate(vdf_ctx *ctx, const void *const *shards, const size_t *shard_n, size_t elem_bytes,
-                     const std::function<void *(vdf_ctx *)> &full)
+                     const std::function<void *(vdf_ctx *)> &full, bool rccl_optional = false, bool *used_plain = nullptr)
 {
     const size_t G = ctx->subs.size();
     std::vector<size_t> off(G + 1, 0);
     for (size_t k = 0; k < G; k++) off[k + 1] = off[k] + shard_n[k];
     const bool force = ctx->force_rccl;  // VDF_FORCE_RCCL, read when the context was made
-    if ((G > 1 || force) && devices_distinct(ctx)) {
+    bool use_rccl = (G > 1 || force) && devices_distinct(ctx);
+    if (use_rccl) {
         int rc = ensure_comms(ctx);
-        if (rc) return rc;
+        if (rc && !rccl_optional) return rc;
+        if (rc) { ctx->err.clear(); use_rccl = false; }
+    }
+    if (used_plain) *used_plain = !use_rccl;
+    if (use_rccl) {
         RcclState *st = ctx->rccl;
         bool equal = true;
         for (size_t k = 1; k < G; k++) equal = equal && shard_n[k] == shard_n[0];
@@ -260,6 +274,10 @@ struct LocalExchange final : ShardExchange {
     uint64_t generation = 0;
     bool broken = false;
     int step_rc = VDF_OK;
+    int first_rc = VDF_OK;   // the status and message of the shard that failed first (abort): what the waiters report
+    std::string first_msg;
+    bool exchange_off = false;  // the exchange step itself could not be carried out: every shard goes on WITHOUT the filter
+    bool used_plain = false;    // the last bitmap exchange went as plain copies (repeated devices, or RCCL not to be had)
     bool acc_complete = true, res_complete = true;
     uint64_t acc_total = 0, res_total = 0;
     std::vector<const void *> ptrs;
@@ -271,7 +289,7 @@ struct LocalExchange final : ShardExchange {
     int meet(vdf_ctx *d, const std::function<int()> &last_step)
     {
         std::unique_lock<std::mutex> lk(m);
-        if (broken) return fail(d, VDF_E_HIP, "another device of the sharded launch failed");
+        if (broken) return secondary(d);
         if (++arrived == G) {
             arrived = 0;
             step_rc = last_step ? last_step() : (int)VDF_OK;
@@ -283,8 +301,16 @@ struct LocalExchange final : ShardExchange {
         }
         const uint64_t gen = generation;
         cv.wait(lk, [&] { return generation != gen || broken; });
-        if (broken) return fail(d, step_rc ? step_rc : (int)VDF_E_HIP, "another device of the sharded launch failed");
+        if (broken) return secondary(d);
         return VDF_OK;
+    }
+
+    // what a shard that leaves only because ANOTHER one failed reports: the first failure's status and message (m is held)
+    int secondary(vdf_ctx *d)
+    {
+        d->err_secondary = true;
+        const int rc = first_rc ? first_rc : step_rc ? step_rc : (int)VDF_E_HIP;
+        return fail(d, rc, "another device of the sharded launch failed" + (first_msg.empty() ? std::string() : ": " + first_msg));
     }
 
     int agree(uint32_t, vdf_ctx *d, bool *all_complete, uint64_t *total_hits) override
@@ -317,10 +343,20 @@ struct LocalExchange final : ShardExchange {
         }
         int rc = meet(d, [&] {  // one thread queues the exchange for all devices, as for the database
             DeviceGuard restore_device;
-            return replicate(parent, ptrs.data(), counts.data(), 4, [](vdf_ctx *q) { return q->bitmap_gather.p; });
+            bool plain = false;
+            int r = parent->test_exchange_fail ? fail(parent, VDF_E_RCCL, "VDF_TEST_EXCHANGE_FAIL")
+                                               : replicate(parent, ptrs.data(), counts.data(), 4, [](vdf_ctx *q) { return q->bitmap_gather.p; },
+                                                           /*rccl_optional=*/true, &plain);
+            used_plain = plain;
+            if (r) {  // the filter is an optimisation: a failed exchange turns it off for this launch, it does not fail the search
+                exchange_off = true;
+                parent->err.clear();
+            }
+            return (int)VDF_OK;
         });
         if (rc) return rc;
-        if (!devices_distinct(parent) || G == 1) {
+        if (exchange_off) return kExchangeOff;  // every shard reads the same flag: all go on with their unfiltered lists
+        if (used_plain) {
             // plain copies: nobody may change its bitmap before every device's copies of it have finished
             VDF_HIP(d, hipSetDevice(d->device));
             VDF_HIP(d, hipStreamSynchronize(d->stream));
@@ -332,9 +368,10 @@ struct LocalExchange final : ShardExchange {
         return VDF_OK;
     }
 
-    void abort() override
+    void abort(int rc, const std::string &msg) override
     {
         std::lock_guard<std::mutex> lk(m);
+        if (!broken && first_rc == VDF_OK) { first_rc = rc; first_msg = msg; }
         broken = true;
         cv.notify_all();
     }
@@ -372,6 +409,7 @@ int vdf_ctx_create_multi(const int *device_ids, int n_devices, vdf_ctx **out)
     for (int k = 0; k < n_devices; k++) parent->workers[(size_t)k]->th = std::thread(worker_main, parent, k);
     parent->hit_capacity = parent->subs[0]->hit_capacity;
     parent->force_rccl = std::getenv("VDF_FORCE_RCCL") != nullptr;
+    parent->test_exchange_fail = std::getenv("VDF_TEST_EXCHANGE_FAIL") != nullptr;
     *out = parent;
     return VDF_OK;
 }

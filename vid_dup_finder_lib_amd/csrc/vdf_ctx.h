@@ -107,9 +107,12 @@ struct ShardExchange {
     // in: this shard's "my hit list is complete" and its hit count; out: AND / sum over all shards
     virtual int agree(uint32_t shard, vdf_ctx *d, bool *all_complete, uint64_t *total_hits) = 0;
     // d_bitmap[0 .. n_words) |= every other shard's, in place, ordered on `stream` (the marking kernels were queued there)
+    // may return kExchangeOff (on EVERY shard alike): the exchange could not be carried out - go on without the filter
     virtual int or_bitmap(uint32_t shard, vdf_ctx *d, uint32_t *d_bitmap, size_t n_words, hipStream_t stream) = 0;
-    virtual void abort() {}
+    // the calling shard leaves early with this status / message: release the others (they report it as the cause)
+    virtual void abort(int rc, const std::string &msg) { (void)rc; (void)msg; }
 };
+constexpr int kExchangeOff = 1;  // not an error (every vdf_status error is negative)
 }
 
 // What the fp4 expansion in exp_cols was made from (reused only for a database the caller pinned)
@@ -183,6 +186,8 @@ struct vdf_ctx {
     size_t host_chunk_bytes = 32u << 20;  // VDF_HOST_CHUNK_MB: pinned staging chunk (x 2) of the host-frame path
     bool host_direct = true;       // VDF_HOST_DIRECT=0: packed input goes through the library's staging too
     bool force_rccl = false;       // VDF_FORCE_RCCL: a one-device context replicates through librccl (multi-GPU parent)
+    bool test_exchange_fail = false;  // VDF_TEST_EXCHANGE_FAIL (multi-GPU parent): the replay filter's bitmap exchange reports a failure - the search must degrade to the unfiltered list
+    bool err_secondary = false;    // this context's last error is "another device of the sharded launch failed" (for_each_device reports the root cause instead)
     int resize_mode = 0;  // 0 auto, 1 generic scalar kernel, 3 MFMA fused kernel, 4 MFMA per-frame kernel with whole-line loads, 5 MFMA linear-stream kernel where it applies, 6 its K-split form where it applies
     // hit list of the host-level calls: pinned (a 50 MB list comes down at the link rate), sized by what searches actually
     // produce - 64 k entries to begin with, grown to a launch's list once its length is known (search_core) - not by the hit

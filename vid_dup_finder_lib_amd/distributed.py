@@ -120,19 +120,31 @@ class DistExchange:
     """How the ranks of one sharded search() launch meet for the replay filter (include/vdf.h: vdf_shard_exchange; the library
     drops hits of rows that can never become targets, which is a property of the COMPLETE hit set): one all-gather of
     (complete, hits) per launch, and - only when the filter runs - two all-gathers of a bitmap of 1 bit per entry (125 KB
-    per million entries and rank), OR-ed on the device by the library (RCCL has no bitwise-OR reduction)."""
+    per million entries and rank), OR-ed on the device by the library (RCCL has no bitwise-OR reduction).
+
+    Failure protocol: the agree all-gather carries an error flag.  A rank whose launch failed BEFORE it reached agree still performs that
+    one collective (search_self_sharded calls agree(failed=True) for it), so its peers are not left waiting in it; they see the flag, go on
+    without the filter (no further exchange collectives in that launch) and raise together with the failed rank at the launch's status
+    exchange.  What is NOT covered: a callback that fails on one rank only AFTER agree (or_bitmap raising asymmetrically) - callbacks
+    must fail on every rank or on none."""
 
     def __init__(self, device: torch.device, group=None):
         self.dev, self.group = device, group
         self.rank, self.world = _world(group)
         self.filtered_launches = 0
+        self.agree_calls = 0
+        self.peer_failed = False  # some rank reported a failed launch in the last agree
 
-    def agree(self, complete: bool, total_hits: int):
+    def agree(self, complete: bool, total_hits: int, failed: bool = False):
         cdev = _coll_device(self.group)
-        mine = torch.tensor([1 if complete else 0, int(total_hits)], dtype=torch.int64, device=cdev)
-        allv = torch.empty(2 * self.world, dtype=torch.int64, device=cdev)
+        mine = torch.tensor([1 if complete else 0, int(total_hits), 1 if failed else 0], dtype=torch.int64, device=cdev)
+        allv = torch.empty(3 * self.world, dtype=torch.int64, device=cdev)
         dist.all_gather_into_tensor(allv, mine, group=self.group)
-        v = allv.view(self.world, 2).cpu()
+        self.agree_calls += 1
+        v = allv.view(self.world, 3).cpu()
+        self.peer_failed = bool(v[:, 2].max().item())
+        if self.peer_failed:
+            return False, 0  # nobody filters: the launch ends without another exchange collective
         return bool(v[:, 0].min().item()), int(v[:, 1].sum().item())
 
     def or_bitmap(self, engine, d_bitmap: int, n_words: int, stream: int):
@@ -186,15 +198,29 @@ def search_self_sharded(engine, d_words: torch.Tensor, d_dur: torch.Tensor, tol_
         _before_engine_call(d_words, stream)
         kw = dict(shard_index=rank, shard_count=world, row_begin=row_begin, row_end=row_end,
                   d_matched=(d_matched.data_ptr() if d_matched is not None else 0), capacity=capacity, stream=stream)
-        if replay_call is not None:
-            hits, n_hits, overflow = replay_call(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, exchange=xchg, **kw)
-        else:
-            hits, n_hits, overflow = engine.search_self_device(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, **kw)
+        err = None
+        calls_before = xchg.agree_calls if xchg is not None else 0
+        try:
+            if replay_call is not None:
+                hits, n_hits, overflow = replay_call(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, exchange=xchg, **kw)
+            else:
+                hits, n_hits, overflow = engine.search_self_device(d_words.data_ptr(), d_dur.data_ptr(), n, tol_int, **kw)
+        except Exception as e:  # noqa: BLE001 - this rank still owes its peers the launch's collectives before it may leave
+            if world == 1:
+                raise
+            err, hits, overflow = e, np.zeros((0, 2), np.uint32), UINT32_MAX
+            if xchg is not None and xchg.agree_calls == calls_before and getattr(engine, "hit_filter_enabled", True):
+                xchg.agree(False, 0, failed=True)  # the one collective the library would have made for this launch
         downloaded += len(hits)
         if world > 1:
-            t = torch.tensor([overflow], dtype=torch.int64, device=_coll_device(group))
+            # the launch's status exchange: the first row that overflowed anywhere, and whether any rank's launch failed
+            t = torch.tensor([overflow, -1 if err is not None else 0], dtype=torch.int64, device=_coll_device(group))
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-            overflow = int(t.item())
+            overflow, any_failed = int(t[0].item()), int(t[1].item()) != 0
+            if err is not None:
+                raise err
+            if any_failed:
+                raise RuntimeError("search_self_sharded: the launch failed on another rank (its own exception names the cause)")
         merged = _gather_hits(hits, group)
         complete_end = min(overflow, n if row_end == UINT32_MAX else min(row_end, n))
         if rank == 0:

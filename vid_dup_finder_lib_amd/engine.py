@@ -42,6 +42,14 @@ def _size_array(sizes: Sequence[int]):
     return (C.c_size_t * len(sizes))(*[int(x) for x in sizes])
 
 
+def _atoi(text: str) -> int:
+    """C's atoi: optional blanks, optional sign, leading digits; anything else counts as 0 (how csrc/api.cpp reads its switches)."""
+    import re
+
+    m = re.match(r"\s*([+-]?\d+)", text or "")
+    return int(m.group(1)) if m else 0
+
+
 class Engine:
     """One context: one GPU (`device`, default LOCAL_RANK or 0), or - `devices=[...]` - ONE context over several GPUs
     of the node (vdf_ctx_create_multi: the host-array calls fan out inside the library, the *_shards methods take
@@ -67,6 +75,8 @@ class Engine:
             msg = self.lib.vdf_last_error(None)
             raise VdfError(rc, (msg or b"").decode() or "vdf_ctx_create failed (is a GPU visible?)")
         self.ctx = ctx
+        # the library read VDF_NO_HIT_FILTER when the context was made: without the filter a replay launch makes no exchange calls
+        self.hit_filter_enabled = _atoi(os.environ.get("VDF_NO_HIT_FILTER", "0")) == 0
         self.device = int(device)
         self.n_devices = int(self.lib.vdf_ctx_device_count(ctx))
         self.devices = [int(self.lib.vdf_ctx_device_at(ctx, k)) for k in range(self.n_devices)]
