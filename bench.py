@@ -311,8 +311,8 @@ class ClockSampler:
             want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
         except Exception:
             pass
-        for c in cards:
-            if want and want in os.path.realpath(os.path.join(c, "device")):
+        for c in cards:  # (the device link's last component is the GPU's own address; the ones before it are bridges)
+            if want and os.path.basename(os.path.realpath(os.path.join(c, "device"))).startswith(want):
                 self.card = c
         if self.card is None and cards:
             self.card = cards[min(device_index, len(cards) - 1)]

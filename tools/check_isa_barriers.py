@@ -32,7 +32,7 @@ def assembly(path=None):
     csrc = os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc")
     text = ""
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("dct_hash.hip", "hamming.hip", "cropdetect.hip"):
+        for src in ("dct_hash.hip", "hamming.hip", "cropdetect.hip", "sort_order.hip"):
             out = os.path.join(tmp, src + ".s")
             subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S",
                             "--cuda-device-only", "-I" + os.path.join(ROOT, "include"), os.path.join(csrc, src), "-o", out],

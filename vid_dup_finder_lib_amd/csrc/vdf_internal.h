@@ -191,7 +191,8 @@ hipError_t launch_sort_order(const uint32_t *dur, const uint32_t *rank, uint32_t
 // hashes_out[k] = hashes[perm[k]], dur_out[k] = dur[perm[k]] (dur / dur_out nullable)
 // hit list into (row, col) order, in place on the device; rows < 2^row_bits
 size_t sort_hits_scratch_bytes(size_t n);
-hipError_t launch_sort_hits(vdf_hit *hits, size_t n, unsigned row_bits, void *scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_sort_hits(vdf_hit *hits, size_t n, unsigned row_bits, void *scratch, size_t scratch_bytes, hipStream_t stream,
+                            unsigned col_bits = 32);  // columns < 2^col_bits
 hipError_t launch_gather_hashes(const uint64_t *hashes, const uint32_t *dur, const uint32_t *perm, uint32_t n, uint64_t *hashes_out,
                                 uint32_t *dur_out, hipStream_t stream);
 hipError_t launch_dct_hash(const uint8_t *small, size_t small_clip_stride, size_t small_frame_stride, size_t n_clips,
