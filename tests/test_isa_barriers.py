@@ -42,6 +42,43 @@ def test_every_per_wave_stream_instantiation_waits_for_its_own_block(isa):
 
 
 @needs_hipcc
+def test_every_lds_reuse_keeps_its_barriers(isa):
+    """LDS buffers re-used across the iterations of a persistent loop are ordered by barriers; every instantiation of every
+    such kernel still holds them in the generated code (round 5's race was one missing LDS-only barrier in two kernel families)."""
+    mod, text = isa
+    seen, bad = mod.check_reuse_barriers(text)
+    assert seen >= 85, seen
+    assert not bad, bad
+
+
+def test_the_reuse_check_sees_a_missing_barrier():
+    mod = _mod()
+    good = """_ZN3vdf31resize_mfma_frame_stream_kernelILi1ELi8ELi0ELb0EEEvv:
+\ts_waitcnt vmcnt(0)
+\ts_barrier
+\ts_barrier
+\ts_barrier
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(0)
+\ts_barrier
+\t;;#ASMEND
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(0)
+\ts_barrier
+\t;;#ASMEND
+\ts_endpgm
+.Lfunc_end0:
+"""
+    assert mod.check_reuse_barriers(good) == (1, [])
+    one_gone = good.replace("\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\t;;#ASMEND\n", "", 1)  # the library before ce37e43
+    seen, bad = mod.check_reuse_barriers(one_gone)
+    assert seen == 1 and len(bad) == 1 and bad[0][1:] == (3, 1, (3, 2))
+    assert len(mod.check_reuse_barriers(good.replace("\ts_barrier\n", "", 1))[1]) == 1  # a plain __syncthreads() gone
+    other = good.replace("resize_mfma_frame_stream_kernel", "some_other_kernel_of_31_characters"[:31])
+    assert mod.check_reuse_barriers(other) == (0, [])
+
+
+@needs_hipcc
 def test_no_stream_kernel_spills(isa):
     """`.vgpr_spill_count` / scratch size of every kernel of the three kernel files, as `llvm-readelf --notes` shows them for the shipped
     code objects: the search kernels of tolerances above 0.357 (K = 14 ... 16 k-steps) spilled 6 - 9 VGPRs into their MFMA stream until

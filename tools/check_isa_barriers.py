@@ -121,6 +121,60 @@ def check_wave_waits(text):
     return seen, bad
 
 
+# LDS buffers that live across iterations of a persistent loop (or across the passes of the DCT) are ordered by workgroup barriers; DESIGN.md
+# section 4.4 has the table (buffer, writer, reader, the barrier in the source).  A barrier that disappears from the source - or from the
+# generated code - shows up here as a count below what every instantiation of the kernel family has today:
+#   family: (plain s_barrier instructions at least, hand-written LDS-only barriers `s_waitcnt lgkmcnt(0); s_barrier` exactly)
+REUSE_BARRIERS = {
+    "dct_hash_kernel": (5, 0),                                # b / c overlay, words: dct_hash_block's four + the cube's
+    "resize_dct_hash_fused_kernel": (5, 0),
+    "resize_dct_hash_persistent_kernel": (5, 0),              # sh.cube / sh.b|c / sh.words across clips
+    "resize_dct_hash_tiled_kernel": (5, 0),
+    "resize_dct_hash_cropped_small_kernel": (10, 0),          # two code paths x 5
+    "letterbox_resize_dct_hash_small_kernel": (9, 0),         # prologue 2 + per clip: probes / tables hand-over, detect, cube, DCT 4
+    "resize_mfma_frame_stream_kernel": (3, 2),                # chunk hand-over, frame end; LDS-only: K... one-chunk frame (round 5's race), reduction
+    "resize_mfma_frame_ksplit_kernel": (3, 2),
+    "resize_mfma_cropped_stream_kernel": (5, 2),
+    "resize_mfma_frame_wavestream_kernel": (1, 1),
+    "hamming_mfma2_kernel": (3, 0),                           # candidate stages
+    "letterbox_kernel": (2, 0),
+    "letterbox_sides_kernel": (3, 0),                         # s_edge / s_prog across work-list entries
+    "radix_scatter_kernel": (3, 0),
+}
+
+
+def check_reuse_barriers(text):
+    """-> (kernels checked, list of (kernel symbol, plain barriers, LDS-only barriers, expected)) for every instantiation of REUSE_BARRIERS"""
+    counts, kernel, in_asm, asm_lgkm = {}, None, False, False
+    for raw in text.split("\n"):
+        m = re.match(r"^(_ZN3vdf\w+):", raw)
+        if m:
+            kernel = m.group(1)
+            counts[kernel] = [0, 0]
+            continue
+        if kernel is None:
+            continue
+        line = raw.strip()
+        if line.startswith(".Lfunc_end"):
+            kernel = None
+        elif line.startswith(";;#ASMSTART"):
+            in_asm, asm_lgkm = True, False
+        elif line.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm and "lgkmcnt(0)" in line and "vmcnt" not in line:
+            asm_lgkm = True
+        elif line.startswith("s_barrier"):
+            counts[kernel][1 if (in_asm and asm_lgkm) else 0] += 1
+    seen, bad = 0, []
+    for sym, (plain, lds_only) in counts.items():
+        for fam, (want_plain, want_lds) in REUSE_BARRIERS.items():
+            if re.search(r"\d+" + fam + r"(I|E)", sym):  # the family's own name, length-prefixed in the mangled symbol
+                seen += 1
+                if plain < want_plain or lds_only != want_lds:
+                    bad.append((sym, plain, lds_only, (want_plain, want_lds)))
+    return seen, bad
+
+
 def spills(text):
     """-> {kernel symbol: (vgpr spills, sgpr spills, scratch bytes)} from the code object metadata of the assembly (what
     `llvm-readelf --notes` shows for the shipped library): a spilled register in a stream kernel is a scratch round trip per use."""
@@ -158,7 +212,11 @@ if __name__ == "__main__":
     for k, why in badw:
         print(f"per-wave stream kernel: {why}: {k}")
     print(f"{nw} per-wave stream instantiations checked, {len(badw)} bad")
+    nr, badr = check_reuse_barriers(text)
+    for k, plain, lds_only, want in badr:
+        print(f"re-use barriers: {k}: {plain} s_barrier + {lds_only} LDS-only, expected at least {want[0]} + exactly {want[1]}")
+    print(f"{nr} kernels with LDS re-use checked, {len(badr)} short of their barriers")
     sp = {k: v for k, v in spills(text).items() if v[0] or v[2]}
     for k, v in sorted(sp.items()):
         print(f"spills: {k}: {v[0]} VGPRs, {v[1]} SGPRs, scratch {v[2]} B")
-    sys.exit(1 if bad or n == 0 or badw or nw == 0 else 0)
+    sys.exit(1 if bad or n == 0 or badw or nw == 0 or badr or nr == 0 else 0)

@@ -302,9 +302,11 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
     VDF_HIP(ctx, hipMemcpyAsync(fin, ctx->counters.p, 64, hipMemcpyDeviceToHost, stream));
     unsigned row_bits = 1;
     while (row_bits < 32 && ((uint64_t)row_index_base + n_rows) >> row_bits) row_bits++;
+    unsigned col_bits = 1;  // columns are candidate indices below n_cols: the hit sort skips the bytes above them
+    while (col_bits < 32 && ((uint64_t)n_cols >> col_bits)) col_bits++;
     if (spec_sort) {
         VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_hits_scratch_bytes((size_t)spec)));
-        VDF_HIP(ctx, vdf::launch_sort_hits(ctx->hits.as<vdf_hit>(), (size_t)spec, row_bits, ctx->sort_scratch.p, ctx->sort_scratch.cap, stream));
+        VDF_HIP(ctx, vdf::launch_sort_hits(ctx->hits.as<vdf_hit>(), (size_t)spec, row_bits, ctx->sort_scratch.p, ctx->sort_scratch.cap, stream, col_bits));
     }
     if (spec) VDF_HIP(ctx, hipMemcpyAsync(ctx->pin_small.p, ctx->hits.p, (size_t)spec * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
@@ -377,7 +379,7 @@ int search_core(vdf_ctx *ctx, int mode, const uint64_t *d_col_hashes, const uint
             const bool dev_sort = stored >= (d_list == ctx->hits.as<vdf_hit>() ? kDeviceSortHits : kDeviceSortHits / 16);  // after the filter nothing of the list is on the host yet
             if (dev_sort) {
                 VDF_HIP(ctx, ctx->sort_scratch.reserve(vdf::sort_hits_scratch_bytes((size_t)stored)));
-                VDF_HIP(ctx, vdf::launch_sort_hits(d_list, (size_t)stored, row_bits, ctx->sort_scratch.p, ctx->sort_scratch.cap, stream));
+                VDF_HIP(ctx, vdf::launch_sort_hits(d_list, (size_t)stored, row_bits, ctx->sort_scratch.p, ctx->sort_scratch.cap, stream, col_bits));
                 VDF_HIP(ctx, hipMemcpyAsync(hits, d_list, (size_t)stored * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));
             } else {
                 VDF_HIP(ctx, hipMemcpyAsync(hits + have, d_list + have, (size_t)(stored - have) * sizeof(vdf_hit), hipMemcpyDeviceToHost, stream));

@@ -1086,7 +1086,9 @@ __global__ __launch_bounds__(256) void resize_mfma_frame_stream_kernel(const uin
             // nothing orders that read before the writes below - a wave without a block in a short chunk gets here at once (seen, round 5:
             // 1 - 2 clips in 30 000 of 64 x 48 through this kernel by force; in the product path only a letterbox box of at most one chunk
             // can get here).  Frames of two chunks and more have the next step's barrier in between.  LDS-only: the DMA stays in flight.
+#ifndef VDF_ABL_NO_ONE_CHUNK_BARRIER  // (ablation build: the library before ce37e43, for showing that the sweeps and the ISA check see the race)
             if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
@@ -1851,7 +1853,9 @@ __global__ __launch_bounds__(256) void resize_mfma_cropped_stream_kernel(const u
             acc_vl = __builtin_amdgcn_mfma_i32_16x16x64_i8(avl, b, acc_vl, 0, 0, 0);
         }
         if (wraps) {  // frame complete
+#ifndef VDF_ABL_NO_ONE_CHUNK_BARRIER
             if (c == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // a box of one chunk: see resize_mfma_frame_stream_kernel
+#endif
             if (wave > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) s_part[wave - 1][lane][r] = (acc_vh[r] << 8) + acc_vl[r];
