@@ -85,6 +85,17 @@ for tag_, fd, wd in (("resize_mfma_frame_wavestream_kernel@1920x1080", "fetch_hd
         if k.startswith(tag_.split("@")[0]):
             t[tag_] = traffic(fd, wd, k, 2, "frames stream through buffer_load ... lds (16 B/lane): FETCH_SIZE doubled per the gfx950 correction; "
                                             "launch = tools/bench_hash.py at the bench leg's shape")
+for k in summary.get("fetch_lbs", {}):
+    if k.startswith("letterbox_resize_dct_hash_small_kernel"):
+        t["letterbox_resize_dct_hash_small_kernel"] = traffic("fetch_lbs", "write_lbs", k, 2,
+                                                              "16 B/lane reads (pixels non-temporal, probes and tables plain): FETCH_SIZE doubled per the gfx950 "
+                                                              "correction; launch = tools/bench_letterbox_small.py, 20 000 clips of 16 x 64 x 64 (average over its six bar patterns)")
+stats_l = glob.glob(os.path.join(src, "kt_lbs", "*", "*_kernel_stats.csv"))
+if stats_l:
+    rows = list(csv.reader(open(stats_l[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if "vdf::" in r[0]]
+    with open(os.path.join(out, f"{tag}_kernel_stats_letterbox_small.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(keep)
 # The file is rebuilt from THIS profile run only (entries of kernels that no longer exist must not linger) and records which binary
 # it belongs to: bench.py reports a traffic figure only when the library it loads has this sha256 (tools/profile_round.sh writes the
 # sha of the .so it profiled next to the counters; the in-tree file is the fallback - the same file, gpurun ships it).

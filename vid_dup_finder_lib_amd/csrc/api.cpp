@@ -1086,17 +1086,23 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     // built and measured in round 5 - profiles/r05_letterbox_ab.txt: the resize kernels fill every CU's LDS, so the walkers only got in
     // between the chunks, and three chunk boundaries cost more than the hidden detect time saved: 1000 pillarboxed 1080p clips 5.45 ms
     // against 5.32.  The detect pass was made faster instead: csrc/cropdetect.hip.)
-    VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
+    // Larger frames: which kernel a box takes (row-range stream, column-range stream, gather, whole-line) and the tables of its size are
+    // decided per box SHAPE on the host - tables for every box size of a 1080p frame would be 50 MB and a second of host time per frame size -
+    // so the boxes come down once and the call waits for the detect.  (The detect writes straight into the caller's d_out_crops when given.)
+    uint32_t *d_crops = d_out_crops;
+    if (!d_crops) {
+        VDF_HIP(ctx, ctx->crops.reserve(n_clips * 16));
+        d_crops = ctx->crops.as<uint32_t>();
+    }
     VDF_HIP(ctx, ctx->crop_work.reserve(vdf::letterbox_work_bytes(n_clips, frames_per_clip)));
-    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride,
-                                       ctx->crops.as<uint32_t>(), ctx->crop_work.as<uint32_t>(), stream, ctx->lb_side_strips));
+    VDF_HIP(ctx, vdf::launch_letterbox(d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, d_crops, ctx->crop_work.as<uint32_t>(),
+                                       stream, ctx->lb_side_strips));
     // (pinned: a pageable destination makes the copy synchronous and slow - 0.3 MB for 20 000 clips)
     if (!ctx->pin_crops.reserve(n_clips * 16)) return fail(ctx, VDF_E_OOM, "host staging for the crop boxes");
     uint32_t *crops = ctx->pin_crops.as<uint32_t>();
-    VDF_HIP(ctx, hipMemcpyAsync(crops, ctx->crops.p, n_clips * 16, hipMemcpyDeviceToHost, stream));
+    VDF_HIP(ctx, hipMemcpyAsync(crops, d_crops, n_clips * 16, hipMemcpyDeviceToHost, stream));
     VDF_HIP(ctx, hipStreamSynchronize(stream));
     if (out_crops) std::memcpy(out_crops, crops, n_clips * 16);
-    if (d_out_crops) VDF_HIP(ctx, hipMemcpyAsync(d_out_crops, ctx->crops.p, n_clips * 16, hipMemcpyDeviceToDevice, stream));
     return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops, d_out, d_dc, stream);
 }
 
