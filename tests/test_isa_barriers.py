@@ -98,7 +98,7 @@ def test_no_stream_kernel_spills(isa):
     assert not other, other
     # round 6: the device-side sorts are hand-written (csrc/sort_order.hip) - rocPRIM's radix sort was the only scratch user of the library
     sorts = {k: v for k, v in sp.items() if "radix_" in k or "sort_keys" in k or "gather_hashes" in k}
-    assert len(sorts) >= 8 and all(v == (0, 0, 0) for v in sorts.values()), sorts
+    assert len(sorts) >= 7 and all(v == (0, 0, 0) for v in sorts.values()), sorts  # keys, gather, histogram x 2 key types, onesweep x 3
     assert all(v[2] == 0 for v in sp.values()), {k: v for k, v in sp.items() if v[2]}  # no kernel of the library uses scratch memory
 
 

@@ -139,7 +139,7 @@ REUSE_BARRIERS = {
     "hamming_mfma2_kernel": (3, 0),                           # candidate stages
     "letterbox_kernel": (2, 0),
     "letterbox_sides_kernel": (3, 0),                         # s_edge / s_prog across work-list entries
-    "radix_scatter_kernel": (3, 0),
+    "radix_onesweep_kernel": (6, 0),                          # ticket, uniform-digit vote, per-wave counts, digit scan (2), bases
 }
 
 

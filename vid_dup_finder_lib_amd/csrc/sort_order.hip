@@ -7,9 +7,9 @@
 //
 // The sort is a hand-written stable LSD radix sort, 8 bits per pass (round 6; rocPRIM's generic radix_sort_* was 627 kernel
 // instantiations and 6.5 MB of an 8.2 MB library - its code object loaded on every process's first call - for keys of at most a
-// few 10^7 entries that are sorted once per search).  Per pass four small launches: per-tile digit histogram, per-digit scan over
-// the tiles, digit bases, stable scatter.  A pass whose digit is the same in every key (the high bytes of durations that are
-// seconds, of indices below 2^24) degenerates to a straight copy, decided on the device.
+// few 10^7 entries that are sorted once per search): one histogram launch for all passes, one scatter launch per pass (look-back
+// over the tiles in front).  A pass whose digit is the same in every key (the high bytes of durations that are seconds, of indices
+// below 2^24) degenerates to a straight copy, decided on the device.
 #include <algorithm>
 #include <cstring>
 
@@ -40,31 +40,41 @@ __global__ __launch_bounds__(256) void gather_hashes_kernel(const uint4 *__restr
     }
 }
 
-// ---- stable LSD radix sort, 8 bits per pass ---------------------------------------------------------------------------------------
+// ---- stable LSD radix sort, 8 bits per pass, ONE scatter launch per pass ("onesweep": chained scan with decoupled look-back) --------------
 // Tile = 4096 keys per workgroup of four waves; wave w owns the tile's w-th quarter and walks it in sixteen rounds of 64 keys, so the
 // order inside a tile is (wave, round, lane) = index order and every step below keeps equal digits in index order (stability).
-constexpr uint32_t kRadixTile = 4096, kRadixRounds = 16;
+// Launches per sort: one memset (tile status + tickets + histograms), one histogram kernel for ALL passes, one scatter per pass.  (The
+// first form - histogram, per-digit scan, digit bases and scatter as four launches per pass - cost a reference search of the configs[4]
+// shape 0.1 ms: its two sorts of 1e5 keys were 40 launches.)  In the scatter a tile takes a ticket (tiles are numbered in the order
+// they start, so every predecessor of a tile is running or done), publishes its per-digit counts, and thread d looks back over the tiles
+// before it - adding AGGREGATE counts until it meets an inclusive PREFIX - for the number of keys of digit d in front of its tile.
+constexpr uint32_t kRadixTile = 4096, kRadixRounds = 16, kRadixMaxPasses = 8;
+constexpr unsigned long long kFlagAggregate = 1ull << 62, kFlagPrefix = 2ull << 62, kFlagMask = 3ull << 62;
 
-struct RadixWork {       // device scratch of one sort (radix_work_bytes)
-    uint32_t *counts;    // [256][n_tiles]: per-tile digit counts, then (scan) their exclusive prefix along the tiles of each digit
-    uint32_t *totals;    // [256] keys per digit
-    uint32_t *bases;     // [256] exclusive prefix of totals, [256] = 1 if one digit holds every key (the pass is a copy)
+struct RadixWork {                 // device scratch of one sort (radix_work_bytes), zeroed by one memset per sort
+    uint32_t *hist;                // [kRadixMaxPasses][256] keys per digit, per pass
+    uint32_t *ticket;              // [kRadixMaxPasses] next tile number of each pass's scatter
+    unsigned long long *status;    // [n_tiles][256]: flag (2 bits) | pass tag (6 bits) | count or inclusive prefix (32 bits)
 };
 
+struct RadixShifts { unsigned s[kRadixMaxPasses]; int n; };
+
+// digit counts of every pass at once; a workgroup accumulates many tiles in LDS before it touches the global counters
 template <class Key>
-__global__ __launch_bounds__(256) void radix_hist_kernel(const Key *__restrict__ keys, size_t n, unsigned shift, uint32_t *__restrict__ counts,
-                                                         uint32_t n_tiles)
+__global__ __launch_bounds__(256) void radix_hist_kernel(const Key *__restrict__ keys, size_t n, RadixShifts sh, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t s_hist[256];
-    s_hist[threadIdx.x] = 0;
+    __shared__ uint32_t s_hist[kRadixMaxPasses][256];
+    for (int p = 0; p < sh.n; p++) s_hist[p][threadIdx.x] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * kRadixTile;
-    for (uint32_t r = 0; r < kRadixRounds; r++) {
-        const size_t i = base + (size_t)r * 256 + threadIdx.x;  // (any order: a histogram)
-        if (i < n) atomicAdd(&s_hist[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const Key k = keys[i];
+        for (int p = 0; p < sh.n; p++) atomicAdd(&s_hist[p][(uint32_t)(k >> sh.s[p]) & 255u], 1u);
     }
     __syncthreads();
-    counts[(size_t)threadIdx.x * n_tiles + blockIdx.x] = s_hist[threadIdx.x];
+    for (int p = 0; p < sh.n; p++) {
+        const uint32_t c = s_hist[p][threadIdx.x];
+        if (c) atomicAdd(&hist[p * 256 + threadIdx.x], c);
+    }
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); *total = the sum
@@ -91,46 +101,26 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return before + inc - v;
 }
 
-// workgroup d: counts[d][0 .. n_tiles) -> its exclusive prefix, totals[d] = its sum
-__global__ __launch_bounds__(256) void radix_scan_kernel(uint32_t *__restrict__ counts, uint32_t n_tiles, uint32_t *__restrict__ totals)
-{
-    __shared__ uint32_t s_wave[4];
-    uint32_t *row = counts + (size_t)blockIdx.x * n_tiles;
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 256) {
-        const uint32_t i = c0 + threadIdx.x;
-        const uint32_t v = i < n_tiles ? row[i] : 0u;
-        uint32_t sum;
-        const uint32_t ex = block_exclusive_scan(v, s_wave, &sum);
-        if (i < n_tiles) row[i] = carry + ex;
-        carry += sum;
-    }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
-}
-
-__global__ __launch_bounds__(256) void radix_bases_kernel(const uint32_t *__restrict__ totals, uint32_t *__restrict__ bases, size_t n)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t t = totals[threadIdx.x];
-    uint32_t sum;
-    bases[threadIdx.x] = block_exclusive_scan(t, s_wave, &sum);
-    const bool whole = (size_t)t == n;
-    if (__syncthreads_or(whole)) { if (threadIdx.x == 0) bases[256] = 1u; }
-    else if (threadIdx.x == 0) bases[256] = 0u;
-}
-
-// keys (and values) of tile blockIdx.x to their places: base of the digit + keys of that digit in earlier tiles + in earlier waves of
-// this tile + in earlier rounds of this wave + in lower lanes of this round.  iota: the values are the keys' indices (first pass).
+// One pass: the keys (and values) of a tile to their places - base of the digit (scan of the pass's histogram) + keys of that digit in the
+// tiles before this one (look-back) + in earlier waves of this tile + in earlier rounds of this wave + in lower lanes of this round.
+// iota: the values are the keys' indices (first pass).  tag = pass + 1 (a status word of another pass, or the memset's zero, is "not ready").
 template <class Key, bool HAS_VAL>
-__global__ __launch_bounds__(256) void radix_scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
-                                                            uint32_t *__restrict__ vout, size_t n, unsigned shift,
-                                                            const uint32_t *__restrict__ counts, const uint32_t *__restrict__ bases,
-                                                            uint32_t n_tiles, int iota)
+__global__ __launch_bounds__(256) void radix_onesweep_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
+                                                             uint32_t *__restrict__ vout, size_t n, unsigned shift, const uint32_t *__restrict__ hist,
+                                                             uint32_t *__restrict__ ticket, unsigned long long *__restrict__ status,
+                                                             unsigned long long tag, int iota)
 {
     __shared__ uint32_t s_run[4][256];  // per wave: keys of each digit in the wave's quarter, then the running offset while it is walked
     __shared__ uint32_t s_base[256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_tile;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t first = (size_t)blockIdx.x * kRadixTile + (size_t)wave * (kRadixTile / 4) + lane;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) s_run[w][tid] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const size_t first = (size_t)tile * kRadixTile + (size_t)wave * (kRadixTile / 4) + lane;
     Key k[kRadixRounds];
     uint32_t v[kRadixRounds];
 #pragma unroll
@@ -139,7 +129,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const Key *__restric
         k[r] = i < n ? kin[i] : (Key)0;
         if (HAS_VAL) v[r] = iota ? (uint32_t)i : (i < n ? vin[i] : 0u);
     }
-    if (bases[256]) {  // every key has the same digit: the order does not change (workgroup-uniform)
+    const uint32_t total_d = hist[tid];  // keys of digit tid in the whole array (this pass's row of the histogram)
+    if (__syncthreads_or((size_t)total_d == n)) {  // every key has the same digit: the order does not change
 #pragma unroll
         for (uint32_t r = 0; r < kRadixRounds; r++) {
             const size_t i = first + (size_t)r * 64;
@@ -148,17 +139,28 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const Key *__restric
         return;
     }
 #pragma unroll
-    for (uint32_t w = 0; w < 4; w++) s_run[w][tid] = 0;
-    __syncthreads();
-#pragma unroll
     for (uint32_t r = 0; r < kRadixRounds; r++)
         if (first + (size_t)r * 64 < n) atomicAdd(&s_run[wave][(uint32_t)(k[r] >> shift) & 255u], 1u);
     __syncthreads();
-    {   // thread d: where digit d of this tile begins; the waves' counts become their exclusive prefix over the waves
-        s_base[tid] = bases[tid] + counts[(size_t)tid * n_tiles + blockIdx.x];
-        uint32_t before = 0;
+    {   // thread d = digit d
+        uint32_t local = 0;
 #pragma unroll
-        for (uint32_t w = 0; w < 4; w++) { const uint32_t c = s_run[w][tid]; s_run[w][tid] = before; before += c; }
+        for (uint32_t w = 0; w < 4; w++) { const uint32_t c = s_run[w][tid]; s_run[w][tid] = local; local += c; }  // exclusive over the waves
+        unsigned long long *mine = status + (size_t)tile * 256 + tid;
+        if (tile != 0) __hip_atomic_store(mine, kFlagAggregate | tag | local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t ignore;
+        const uint32_t digit_base = block_exclusive_scan(total_d, s_wave, &ignore);
+        uint32_t before = 0;  // keys of this digit in tiles 0 .. tile - 1
+        for (uint32_t t = tile; t-- > 0;) {
+            unsigned long long w;
+            do {
+                w = __hip_atomic_load(status + (size_t)t * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((w & (63ull << 56)) != tag || (w & kFlagMask) == 0);
+            before += (uint32_t)w;
+            if ((w & kFlagMask) == kFlagPrefix) break;
+        }
+        __hip_atomic_store(mine, kFlagPrefix | tag | (unsigned long long)(before + local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base[tid] = digit_base + before;
     }
     __syncthreads();
     uint32_t *run = s_run[wave];
@@ -189,41 +191,48 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const Key *__restric
 static size_t radix_work_bytes(size_t n)
 {
     const size_t n_tiles = (n + kRadixTile - 1) / kRadixTile;
-    return ((256 * n_tiles * 4 + 255) & ~(size_t)255) + 256 * 4 + 260 * 4 + 256;
+    return kRadixMaxPasses * 256 * 4 + 256 + n_tiles * 256 * 8 + 256;
 }
 
 static RadixWork radix_work(void *p, size_t n)
 {
-    const size_t n_tiles = (n + kRadixTile - 1) / kRadixTile;
+    (void)n;
     char *c = static_cast<char *>(p);
     RadixWork w;
-    w.counts = reinterpret_cast<uint32_t *>(c);
-    c += (256 * n_tiles * 4 + 255) & ~(size_t)255;
-    w.totals = reinterpret_cast<uint32_t *>(c);
-    w.bases = w.totals + 256;
+    w.hist = reinterpret_cast<uint32_t *>(c);
+    w.ticket = reinterpret_cast<uint32_t *>(c + kRadixMaxPasses * 256 * 4);
+    w.status = reinterpret_cast<unsigned long long *>(c + kRadixMaxPasses * 256 * 4 + 256);
     return w;
 }
 
 // One pass per entry of shifts (least significant digit first).  Pass 0 reads (k_in, v_in or the indices), pass p > 0 reads what pass
 // p - 1 wrote; passes write to (k_a, v_a), (k_b, v_b) alternately, the LAST pass's values to v_final when it is given.
-// Returns where the last pass's keys went (0: k_a, 1: k_b).
+// Returns where the last pass's keys went (0: k_a, 1: k_b).  work_base: the RadixWork's memory (256-byte aligned, radix_work_bytes(n)).
 template <class Key, bool HAS_VAL>
 static hipError_t radix_sort_lsd(const Key *k_in, const uint32_t *v_in, Key *k_a, uint32_t *v_a, Key *k_b, uint32_t *v_b, uint32_t *v_final,
                                  size_t n, const unsigned *shifts, int n_shifts, const RadixWork &w, hipStream_t stream, int *last_in_b)
 {
     const uint32_t n_tiles = (uint32_t)((n + kRadixTile - 1) / kRadixTile);
+    if (n_shifts > (int)kRadixMaxPasses) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(w.hist, 0, radix_work_bytes(n) - 256, stream);  // histograms, tickets, tile status
+    if (e != hipSuccess) return e;
+    RadixShifts sh{};
+    sh.n = n_shifts;
+    for (int p = 0; p < n_shifts; p++) sh.s[p] = shifts[p];
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL((radix_hist_kernel<Key>), dim3(std::min<uint32_t>((uint32_t)((n + 2047) / 2048), (uint32_t)cus * 4u)), dim3(256), 0, stream,
+                       k_in, n, sh, w.hist);
     const Key *src_k = k_in;
     const uint32_t *src_v = v_in;
     for (int p = 0; p < n_shifts; p++) {
         Key *dst_k = (p & 1) ? k_b : k_a;
         uint32_t *dst_v = (p & 1) ? v_b : v_a;
         if (HAS_VAL && p == n_shifts - 1 && v_final) dst_v = v_final;
-        hipLaunchKernelGGL((radix_hist_kernel<Key>), dim3(n_tiles), dim3(256), 0, stream, src_k, n, shifts[p], w.counts, n_tiles);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, stream, w.counts, n_tiles, w.totals);
-        hipLaunchKernelGGL(radix_bases_kernel, dim3(1), dim3(256), 0, stream, w.totals, w.bases, n);
-        hipLaunchKernelGGL((radix_scatter_kernel<Key, HAS_VAL>), dim3(n_tiles), dim3(256), 0, stream, src_k, src_v, dst_k, dst_v, n, shifts[p],
-                           w.counts, w.bases, n_tiles, (HAS_VAL && p == 0 && v_in == nullptr) ? 1 : 0);
-        hipError_t e = hipGetLastError();
+        hipLaunchKernelGGL((radix_onesweep_kernel<Key, HAS_VAL>), dim3(n_tiles), dim3(256), 0, stream, src_k, src_v, dst_k, dst_v, n, shifts[p],
+                           w.hist + p * 256, w.ticket + p, w.status, (unsigned long long)(p + 1) << 56, (HAS_VAL && p == 0 && v_in == nullptr) ? 1 : 0);
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
         src_k = dst_k;
         src_v = dst_v;
