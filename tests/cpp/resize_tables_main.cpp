@@ -72,6 +72,18 @@ int main()
                         }
         }
     }
+    // Round 6: the letterbox path of small frames keeps the tables of EVERY crop-box size resident (csrc/api.cpp: box_table_set) so that the
+    // boxes never visit the host.  That route needs every size from 1 to 256 to fit the i8 split in both layouts, every size up to 64 to be
+    // one tile (the fused kernel finds a table by multiplication: 2 KB of operand per table), and the bias / precision of a size to be the same
+    // in both layouts (one blob entry per (size, layout)).
+    for (unsigned n = 1; n <= 256; n++) {
+        MfmaAxisTable hz, vt;
+        CHECK(build_mfma_axis_table(n, kMfmaLayoutHorizontal, hz) && build_mfma_axis_table(n, kMfmaLayoutVertical, vt), "box tables %u", n);
+        CHECK(hz.ok && vt.ok, "box size %u does not fit the i8 split: the device-side letterbox route would fall back to the host plan", n);
+        CHECK(hz.n_tiles == (int)((n + 63) / 64) && vt.n_tiles == hz.n_tiles && hz.precision == vt.precision && hz.precision >= 1 && hz.precision <= 15, "box shape %u", n);
+        CHECK(hz.operand.size() == (size_t)hz.n_tiles * 2048 && vt.operand.size() == hz.operand.size() && hz.bias.size() == 16 && hz.bias == vt.bias, "box sizes %u", n);
+        if (n <= 64) CHECK(hz.n_tiles == 1, "box size %u must be one tile", n);
+    }
     if (fails == 0) std::printf("resize tables ok\n");
     return fails ? 1 : 0;
 }

@@ -51,6 +51,29 @@ def test_every_lds_reuse_keeps_its_barriers(isa):
     assert not bad, bad
 
 
+@needs_hipcc
+def test_the_fused_letterbox_kernel_waits_for_its_table_dma(isa):
+    mod, text = isa
+    seen, bad = mod.check_fused_letterbox(text)
+    assert seen == 1 and not bad, bad
+    good = """_ZN3vdf38letterbox_resize_dct_hash_small_kernelEPKhjj:
+\tbuffer_load_dwordx4 v1, s[0:3], 0 offen lds
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+\tds_write_b32 v1, v2
+\ts_barrier
+\tbuffer_load_dwordx4 v1, s[0:3], 0 offen lds
+\tds_read_b128 v[4:7], v3
+\ts_endpgm
+.Lfunc_end0:
+"""
+    assert mod.check_fused_letterbox(good) == (1, [])
+    assert len(mod.check_fused_letterbox(good.replace("\ts_waitcnt vmcnt(0)\n", "\ts_nop 0\n"))[1]) == 1
+    moved = good.replace("\tds_write_b32 v1, v2\n", "\tbuffer_load_dwordx4 v1, s[0:3], 0 offen lds\n")  # a DMA between wait and barrier
+    assert len(mod.check_fused_letterbox(moved)[1]) == 1
+
+
 def test_the_reuse_check_sees_a_missing_barrier():
     mod = _mod()
     good = """_ZN3vdf31resize_mfma_frame_stream_kernelILi1ELi8ELi0ELb0EEEvv:

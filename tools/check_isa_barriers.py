@@ -175,6 +175,39 @@ def check_reuse_barriers(text):
     return seen, bad
 
 
+def check_fused_letterbox(text):
+    """letterbox_resize_dct_hash_small_kernel hands its box tables over by LDS-DMA (every wave brings a quarter of them): at the top of the
+    persistent loop every wave must wait for its own DMA (`s_waitcnt vmcnt(0)`, hand-written: the compiler knows nothing of the hand-over)
+    BEFORE the workgroup barrier behind which the tables are read, and no new DMA may be issued in between.
+    -> (kernels seen, list of reasons)"""
+    seen, bad = 0, []
+    for m in re.finditer(r"^(_ZN3vdf\d+letterbox_resize_dct_hash_small_kernel\w*):", text, flags=re.M):
+        seen += 1
+        body = text[m.end():text.index(".Lfunc_end", m.end())].split("\n")
+        events, in_asm = [], False
+        for raw in body:
+            line = raw.strip()
+            if line.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif line.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and "vmcnt(0)" in line:
+                events.append("wait")
+            elif line.startswith("s_barrier"):
+                events.append("barrier")
+            elif line.startswith("buffer_load") and line.endswith("lds"):
+                events.append("dma")
+        if "dma" not in events:
+            bad.append((m.group(1), "no LDS-DMA found: the table hand-over changed - update this check"))
+        elif "wait" not in events:
+            bad.append((m.group(1), "no explicit s_waitcnt vmcnt(0) in front of the hand-over barrier"))
+        else:
+            after = events[events.index("wait") + 1:]
+            if not after or after[0] != "barrier":
+                bad.append((m.group(1), f"the wait is followed by {after[:1]} instead of the hand-over barrier"))
+    return seen, bad
+
+
 def spills(text):
     """-> {kernel symbol: (vgpr spills, sgpr spills, scratch bytes)} from the code object metadata of the assembly (what
     `llvm-readelf --notes` shows for the shipped library): a spilled register in a stream kernel is a scratch round trip per use."""
@@ -216,7 +249,11 @@ if __name__ == "__main__":
     for k, plain, lds_only, want in badr:
         print(f"re-use barriers: {k}: {plain} s_barrier + {lds_only} LDS-only, expected at least {want[0]} + exactly {want[1]}")
     print(f"{nr} kernels with LDS re-use checked, {len(badr)} short of their barriers")
+    nf, badf = check_fused_letterbox(text)
+    for k, why in badf:
+        print(f"fused letterbox kernel: {why}: {k}")
+    print(f"{nf} fused letterbox kernel(s) checked, {len(badf)} bad")
     sp = {k: v for k, v in spills(text).items() if v[0] or v[2]}
     for k, v in sorted(sp.items()):
         print(f"spills: {k}: {v[0]} VGPRs, {v[1]} SGPRs, scratch {v[2]} B")
-    sys.exit(1 if bad or n == 0 or badw or nw == 0 or badr or nr == 0 else 0)
+    sys.exit(1 if bad or n == 0 or badw or nw == 0 or badr or nr == 0 or badf or nf == 0 else 0)

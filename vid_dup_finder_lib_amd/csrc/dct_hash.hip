@@ -2346,6 +2346,9 @@ __global__ __launch_bounds__(256) void letterbox_resize_dct_hash_small_kernel(
         by0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c[2]);
         bw = W - bx0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[1]);
         bh = H - by0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)c[3]);
+#ifdef VDF_ABL_IGNORE_BOX  // timing ablation (hashes wrong): the detect runs and reports, the resize takes the whole frame
+        bx0 = by0 = 0; bw = W; bh = H;
+#endif
     };
     // The tables of the current box (bw, bh) -> lb.tab[buf] / lb.tail[buf] by LDS-DMA: no registers, no wait here.  Wave 0 / 1 bring the
     // horizontal table's hi / lo half, wave 2 / 3 the vertical's; the first eight lanes of waves 0 and 2 the 128-byte tail (bias, precision).
