@@ -26,7 +26,7 @@ Named legs in the same line (sizes are flags, so tests run them small):
   dup_heavy        a duplicate-DENSE database (10 % of 1 M hashes in clusters of 2-200): what hits, suspect queue,
                    download and replay cost when the finder finds a lot (N = 1; also sharded over two slots of one GPU)
   cache_ingest     SURVEY 8f N1 at the scale it exists for: a synthetic 10 M-entry app cache (bincode bytes) -> vdf_cache_decode_mt ->
-                   vdf_search_cache_entries (PathBuf ranks, upload, Search::sort on the device, search, map), phase by phase (N = 1)
+                   vdf_search_cache_entries (paths + hashes up, Search::sort on the device - the PathBuf order included -, search, map), phase by phase (N = 1)
   windowed, valu_backend, refs_c5_shape, hash.* (N = 1), cpu_baseline (the oracle on host cores; N = 1)
 The line is kept short (what each leg runs is written down in DESIGN.md section 6, not repeated in every line) and ENDS with
 "summary" (at most 1.5 KB): "hash_summary" - BASELINE's metric is "pairs/s + frames/s", and whoever keeps only the tail of the line still
@@ -1274,7 +1274,7 @@ def synth_cache(n, seed=20250620, plant_every=1000):
 def leg_cache_ingest(args, vdf, eng, tol_int):
     """SURVEY 8f N1 at the scale the row exists for (the load it replaces: base_fs_cache.rs:167-223 -> app_fns.rs:428-482): the bytes of an
     app cache with --cache-entries entries -> vdf_cache_decode_mt (all host threads by the library's own choice, and ONE thread beside it)
-    -> vdf_search_cache_entries (PathBuf ranks on the host threads, upload, Search::sort on the device, search(), map back to entries).
+    -> vdf_search_cache_entries (path blob, durations and hashes up, Search::sort on the device from durations AND paths, search(), map back to entries).
     host_ms = everything but the search kernel's call: what a user waits for on top of the search itself."""
     import ctypes as C
 

@@ -441,16 +441,23 @@ int vdf_cache_metadata_path(const char *cache_path, size_t len, char *buf, size_
 int vdf_path_compare(const char *a, size_t len_a, const char *b, size_t len_b);
 int vdf_path_ranks(const char *paths, const uint64_t *path_offsets, size_t n, uint32_t *out_rank, int n_threads);
 
+/* Search::sort's order itself (search_algorithm.rs:55-61) for n entries given as HOST arrays: out_order[k] = index of the entry at
+ * position k of the stable order by (duration, PathBuf order of the path).  For plain paths (no empty, "." or ".." component, no NUL:
+ * what a directory walk produces) of at most 1024 bytes the path half runs on the device - an LSD radix sort over 8-byte words of the
+ * paths - otherwise through vdf_path_ranks on the host; *used_device (nullable) says which.  Same order either way. */
+int vdf_sort_order_paths(vdf_ctx *ctx, const uint32_t *durations, const uint64_t *path_offsets, const char *paths, size_t n,
+                         uint32_t *out_order, int *used_device);
+
 /* ---- from the entries of a decoded cache to MatchGroups in one call -----------------------------------
  * What the app does between loading its cache and printing groups (vid_dup_finder_app/src/app/app_fns.rs:428-482: fetch the
  * hashes of the --files paths and of the --with-refs paths, then search() or search_with_references()), on the SoA arrays of
- * vdf_cache_decode, with no per-entry host object: PathBuf ranks of the candidate paths (vdf_path_ranks) -> upload ->
- * Search::sort on the device (vdf_sort_order_device) -> gather -> search.
+ * vdf_cache_decode, with no per-entry host object: upload -> Search::sort on the device (paths included when they are plain:
+ * vdf_sort_order_paths; else PathBuf ranks from vdf_path_ranks + vdf_sort_order_device) -> gather -> search.
  * cand_idx (nullable = all n entries, n_cand ignored) and ref_idx select entries of the arrays; n_ref == 0 -> search(), else
  * search_with_references() with the references in ref_idx order.  Group members (and ref_index) are indices into the caller's
  * arrays (NOT into cand_idx / ref_idx), in the reference's order.  timing (nullable) receives the phases. */
 typedef struct vdf_cache_search_timing {
-    float rank_ms;    /* host: vdf_path_ranks over the candidates */
+    float rank_ms;    /* durations, path blob and offsets to the device + the plain-path check (host route: + vdf_path_ranks) */
     float upload_ms;  /* host wall: hashes, durations, ranks to the device(s) */
     float sort_ms;    /* device + host wall: Search::sort order, gather, order download */
     float search_ms;  /* the search call proper (vdf_ctx_last_search_timing has its phases) */

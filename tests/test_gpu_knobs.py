@@ -41,6 +41,7 @@ KNOBS = [
     ({"VDF_NO_SMALLCROP": "1"}, "mfma"),
     ({"VDF_NO_LB_FUSED": "1"}, "mfma"),
     ({"VDF_LB_HOST_PLAN": "1"}, "mfma"),
+    ({"VDF_NO_DEVICE_PATH_ORDER": "1"}, "mfma"),  # exercised by tests/test_gpu_path_order.py (the cache route on both roads)
     ({"VDF_NO_HIT_FILTER": "1"}, "mfma"),
     ({"VDF_CAND_CAPACITY": "64"}, "mfma"),
     ({"VDF_RESIZE_MODE": "4"}, "mfma"),

@@ -140,6 +140,7 @@ SIGNATURES = {
                                                             C.c_void_p]),
     "vdf_hash_frames_u8_letterbox": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vdf_sort_order_paths": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]),
     "vdf_search_self": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(VdfGroups)]),
     "vdf_search_refs": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_uint32, C.POINTER(VdfGroups)]),

@@ -270,6 +270,30 @@ def path_ranks(paths, n_threads: int = 0) -> np.ndarray:
     return out
 
 
+def sort_order_paths(engine, durations, paths):
+    """Search::sort's order (search_algorithm.rs:55-61: stable by (duration, PathBuf order of the path)) of entries given as host arrays
+    (vdf_sort_order_paths): the path half runs on the device when every path is plain, through the host's component comparator
+    otherwise.  -> (order [n] u32: order[k] = the entry at position k, used_device: bool).  paths: PathTable or a sequence of str / bytes."""
+    import ctypes as C
+
+    if isinstance(paths, PathTable):
+        blob, offs = paths.blob, np.ascontiguousarray(paths.offsets, dtype=np.uint64)
+        blob = np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, bytes) else np.ascontiguousarray(blob, dtype=np.uint8)
+    else:
+        enc = [p if isinstance(p, bytes) else os.fsencode(p) for p in paths]
+        offs = np.zeros(len(enc) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(e) for e in enc]) if enc else []
+        blob = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    n = len(offs) - 1
+    dur = np.ascontiguousarray(durations, dtype=np.uint32)
+    assert dur.shape == (n,)
+    out = np.zeros(n, np.uint32)
+    used = C.c_int(0)
+    keep = blob if blob.size else np.zeros(1, np.uint8)
+    engine._check(engine.lib.vdf_sort_order_paths(engine.ctx, dur.ctypes.data, offs.ctypes.data, keep.ctypes.data, n, out.ctypes.data, C.byref(used)))
+    return out, bool(used.value)
+
+
 def path_compare(a, b) -> int:
     a = a if isinstance(a, bytes) else os.fsencode(a)
     b = b if isinstance(b, bytes) else os.fsencode(b)

@@ -1204,6 +1204,7 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     ctx->rowcrop_all = std::getenv("VDF_ROWCROP_ALL") != nullptr;
     ctx->no_boxstream = std::getenv("VDF_NO_BOXSTREAM") != nullptr;
     ctx->no_smallcrop = std::getenv("VDF_NO_SMALLCROP") != nullptr;
+    ctx->no_device_path_order = std::getenv("VDF_NO_DEVICE_PATH_ORDER") != nullptr;
     ctx->lb_host_plan = std::getenv("VDF_LB_HOST_PLAN") != nullptr;
     ctx->no_lb_fused = std::getenv("VDF_NO_LB_FUSED") != nullptr;
     if (std::getenv("VDF_LB_NC16")) ctx->lb_side_strips = 16;

@@ -17,8 +17,11 @@ namespace {
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Scratch {  // device buffers of one call, released on every exit path
-    DevBuf all_h, sel, sel_h, sel_d, sel_rank, perm;
-    ~Scratch() { all_h.release(); sel.release(); sel_h.release(); sel_d.release(); sel_rank.release(); perm.release(); }
+    DevBuf all_h, sel, sel_h, sel_d, sel_rank, perm, blob, off, facts;
+    ~Scratch()
+    {
+        for (DevBuf *b : {&all_h, &sel, &sel_h, &sel_d, &sel_rank, &perm, &blob, &off, &facts}) b->release();
+    }
 };
 
 }  // namespace
@@ -79,21 +82,12 @@ static int search_cache_entries_impl(vdf_ctx *ctx, const uint64_t *hashes, const
     DeviceGuard restore_device;  // (destroyed after `drain`, which moves the calling thread over the devices)
     Drain drain{ctx};
 
-    // ---- PathBuf order of the candidates' paths: ranks over all n entries order any subset of them too (the cost is that of all n
-    // whatever the selection: a caller with a small selection of a huge cache may pass a compacted blob instead)
-    rank.resize(n);
-    int rc = vdf_path_ranks(paths, path_offsets, n, rank.data(), 0);
-    if (rc) return fail(ctx, rc, "path offsets are not ascending");
-    if (cand_idx) {
-        sel32.resize(nc); sel_dur.resize(nc); sel_rank.resize(nc);
-        for (size_t i = 0; i < nc; i++) {
-            const uint32_t e = (uint32_t)cand_idx[i];
-            sel32[i] = e; sel_dur[i] = durations[e]; sel_rank[i] = rank[e];
-        }
-    }
-    const double t_rank = now_ms();
-
-    // ---- upload to the first device; Search::sort there
+    // ---- Search::sort order of the candidates: (duration, PathBuf order of the path)  (search_algorithm.rs:55-61).
+    // Round 6: on the DEVICE when the paths are plain (sort_order.hip: an LSD radix sort over 8-byte words of the paths, then the stable
+    // duration sort) - the blob goes up once (0.55 GB for 10 M paths) instead of 0.2 - 0.3 s of sample sort on 32 host threads.  Paths
+    // that are not plain (an empty, "." or ".." component somewhere: nothing a directory walk produces) or longer than kMaxDevicePath
+    // bytes take the host's component comparator (vdf_path_ranks) and the rank-keyed device sort, as before.
+    constexpr uint32_t kMaxDevicePath = 1024;
     const int G = device_count(ctx);
     vdf_ctx *d0 = device_ctx(ctx, 0);
     VDF_HIP(ctx, hipSetDevice(d0->device));
@@ -103,23 +97,69 @@ static int search_cache_entries_impl(vdf_ctx *ctx, const uint64_t *hashes, const
         if (r && d0 != ctx) ctx->err = d0->err;
         return r;
     };
-    if ((rc = up(sc.all_h, hashes, n * VDF_HASH_WORDS * 8))) return rc;
+    for (size_t i = 0; i < n; i++)
+        if (path_offsets[i + 1] < path_offsets[i]) return fail(ctx, VDF_E_INVAL, "path offsets are not ascending");
+    int rc = VDF_OK;
+    if (cand_idx) {
+        sel32.resize(nc); sel_dur.resize(nc);
+        for (size_t i = 0; i < nc; i++) {
+            const uint32_t e = (uint32_t)cand_idx[i];
+            sel32[i] = e; sel_dur[i] = durations[e];
+        }
+        if ((rc = up(sc.sel, sel32.data(), nc * 4))) return rc;
+    }
     if ((rc = up(sc.sel_d, cand_idx ? sel_dur.data() : durations, nc * 4))) return rc;
-    if ((rc = up(sc.sel_rank, cand_idx ? sel_rank.data() : rank.data(), nc * 4))) return rc;
+    bool on_device = !ctx->no_device_path_order;
+    uint32_t facts[4] = {0, 0, 0, 0};  // not_plain, max_len, shared, pad
+    if (on_device) {
+        const size_t blob_bytes = (size_t)(path_offsets[n] - path_offsets[0]);
+        if ((rc = up(sc.blob, paths + path_offsets[0], std::max<size_t>(blob_bytes, 1)))) return rc;
+        if ((rc = up(sc.off, path_offsets, (n + 1) * 8))) return rc;
+        VDF_HIP(ctx, sc.facts.reserve(16));
+        // (the offsets are relative to `paths`; the uploaded blob starts at paths + path_offsets[0])
+        const char *d_blob = sc.blob.as<char>() - path_offsets[0];
+        VDF_HIP(ctx, vdf::launch_path_facts(d_blob, sc.off.as<unsigned long long>(), cand_idx ? sc.sel.as<uint32_t>() : nullptr, (uint32_t)nc,
+                                            sc.facts.p, s));
+        VDF_HIP(ctx, hipMemcpyAsync(facts, sc.facts.p, 16, hipMemcpyDeviceToHost, s));
+        VDF_HIP(ctx, hipStreamSynchronize(s));
+        on_device = facts[0] == 0 && facts[1] <= kMaxDevicePath;
+    }
+    if (!on_device) {
+        // PathBuf ranks over all n entries order any subset of them too (the cost is that of all n whatever the selection)
+        rank.resize(n);
+        rc = vdf_path_ranks(paths, path_offsets, n, rank.data(), 0);
+        if (rc) return fail(ctx, rc, "path offsets are not ascending");
+        if (cand_idx) {
+            sel_rank.resize(nc);
+            for (size_t i = 0; i < nc; i++) sel_rank[i] = rank[sel32[i]];
+        }
+    }
+    const double t_rank = now_ms();  // (device route: the uploads of blob, offsets and durations and the facts pass; host route: the ranks)
+
+    // ---- hashes up; the order
+    if ((rc = up(sc.all_h, hashes, n * VDF_HASH_WORDS * 8))) return rc;
     const uint64_t *d_src_h = sc.all_h.as<uint64_t>();
     if (cand_idx) {
-        if ((rc = up(sc.sel, sel32.data(), nc * 4))) return rc;
         VDF_HIP(ctx, sc.sel_h.reserve(nc * VDF_HASH_WORDS * 8));
         VDF_HIP(ctx, vdf::launch_gather_hashes(sc.all_h.as<uint64_t>(), nullptr, sc.sel.as<uint32_t>(), (uint32_t)nc, sc.sel_h.as<uint64_t>(),
                                                nullptr, s));
         d_src_h = sc.sel_h.as<uint64_t>();
     }
+    if (!on_device && (rc = up(sc.sel_rank, cand_idx ? sel_rank.data() : rank.data(), nc * 4))) return rc;
     VDF_HIP(ctx, hipStreamSynchronize(s));  // (the host vectors may go; and the phase is timed)
     const double t_up = now_ms();
     VDF_HIP(ctx, sc.perm.reserve(nc * 4));
-    VDF_HIP(ctx, d0->sort_scratch.reserve(vdf::sort_order_scratch_bytes((uint32_t)nc, true)));
-    VDF_HIP(ctx, vdf::launch_sort_order(sc.sel_d.as<uint32_t>(), sc.sel_rank.as<uint32_t>(), (uint32_t)nc, sc.perm.as<uint32_t>(),
-                                        d0->sort_scratch.p, d0->sort_scratch.cap, s));
+    if (on_device) {
+        const char *d_blob = sc.blob.as<char>() - path_offsets[0];
+        VDF_HIP(ctx, d0->sort_scratch.reserve(vdf::path_order_scratch_bytes((uint32_t)nc)));
+        VDF_HIP(ctx, vdf::launch_path_duration_order(d_blob, sc.off.as<unsigned long long>(), cand_idx ? sc.sel.as<uint32_t>() : nullptr,
+                                                     sc.sel_d.as<uint32_t>(), (uint32_t)nc, facts[2] / 8, (facts[1] + 7) / 8, sc.perm.as<uint32_t>(),
+                                                     d0->sort_scratch.p, d0->sort_scratch.cap, s));
+    } else {
+        VDF_HIP(ctx, d0->sort_scratch.reserve(vdf::sort_order_scratch_bytes((uint32_t)nc, true)));
+        VDF_HIP(ctx, vdf::launch_sort_order(sc.sel_d.as<uint32_t>(), sc.sel_rank.as<uint32_t>(), (uint32_t)nc, sc.perm.as<uint32_t>(),
+                                            d0->sort_scratch.p, d0->sort_scratch.cap, s));
+    }
     VDF_HIP(ctx, d0->up_hashes.reserve(nc * VDF_HASH_WORDS * 8));
     VDF_HIP(ctx, d0->up_dur.reserve(std::max<size_t>(nc * 4, 16)));
     VDF_HIP(ctx, vdf::launch_gather_hashes(d_src_h, sc.sel_d.as<uint32_t>(), sc.perm.as<uint32_t>(), (uint32_t)nc, d0->up_hashes.as<uint64_t>(),
@@ -185,4 +225,69 @@ static int search_cache_entries_impl(vdf_ctx *ctx, const uint64_t *hashes, const
         timing->total_ms = (float)(t_end - t0);
     }
     return VDF_OK;
+}
+
+// Search::sort's order of n entries from their durations and paths (host arrays in, host order out): the path half on the device when the
+// paths are plain, through the host's component comparator otherwise.  out_order[k] = index of the entry at position k.
+extern "C" int vdf_sort_order_paths(vdf_ctx *ctx, const uint32_t *durations, const uint64_t *path_offsets, const char *paths, size_t n,
+                                    uint32_t *out_order, int *used_device)
+{
+    if (!ctx) return VDF_E_INVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (used_device) *used_device = 0;
+    if (n == 0) return VDF_OK;
+    if (!durations || !path_offsets || !paths || !out_order) return fail(ctx, VDF_E_INVAL, "null pointer");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, VDF_E_INVAL, "more than 2^32-1 entries");
+    for (size_t i = 0; i < n; i++)
+        if (path_offsets[i + 1] < path_offsets[i]) return fail(ctx, VDF_E_INVAL, "path offsets are not ascending");
+    try {
+        std::vector<uint32_t> rank;
+        Scratch sc;
+        DeviceGuard restore_device;
+        vdf_ctx *d0 = device_ctx(ctx, 0);
+        VDF_HIP(ctx, hipSetDevice(d0->device));
+        hipStream_t s = d0->stream;
+        struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); (void)hipGetLastError(); } } drain{s};
+        auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+            int r = upload(d0, b, src, bytes, s);
+            if (r && d0 != ctx) ctx->err = d0->err;
+            return r;
+        };
+        int rc;
+        if ((rc = up(sc.sel_d, durations, n * 4))) return rc;
+        VDF_HIP(ctx, sc.perm.reserve(n * 4));
+        bool on_device = !ctx->no_device_path_order;
+        uint32_t facts[4] = {0, 0, 0, 0};
+        const char *d_blob = nullptr;
+        if (on_device) {
+            const size_t blob_bytes = (size_t)(path_offsets[n] - path_offsets[0]);
+            if ((rc = up(sc.blob, paths + path_offsets[0], std::max<size_t>(blob_bytes, 1)))) return rc;
+            if ((rc = up(sc.off, path_offsets, (n + 1) * 8))) return rc;
+            VDF_HIP(ctx, sc.facts.reserve(16));
+            d_blob = sc.blob.as<char>() - path_offsets[0];
+            VDF_HIP(ctx, vdf::launch_path_facts(d_blob, sc.off.as<unsigned long long>(), nullptr, (uint32_t)n, sc.facts.p, s));
+            VDF_HIP(ctx, hipMemcpyAsync(facts, sc.facts.p, 16, hipMemcpyDeviceToHost, s));
+            VDF_HIP(ctx, hipStreamSynchronize(s));
+            on_device = facts[0] == 0 && facts[1] <= 1024;
+        }
+        if (on_device) {
+            VDF_HIP(ctx, d0->sort_scratch.reserve(vdf::path_order_scratch_bytes((uint32_t)n)));
+            VDF_HIP(ctx, vdf::launch_path_duration_order(d_blob, sc.off.as<unsigned long long>(), nullptr, sc.sel_d.as<uint32_t>(), (uint32_t)n,
+                                                         facts[2] / 8, (facts[1] + 7) / 8, sc.perm.as<uint32_t>(), d0->sort_scratch.p,
+                                                         d0->sort_scratch.cap, s));
+        } else {
+            rank.resize(n);
+            if ((rc = vdf_path_ranks(paths, path_offsets, n, rank.data(), 0))) return fail(ctx, rc, "path offsets are not ascending");
+            if ((rc = up(sc.sel_rank, rank.data(), n * 4))) return rc;
+            VDF_HIP(ctx, d0->sort_scratch.reserve(vdf::sort_order_scratch_bytes((uint32_t)n, true)));
+            VDF_HIP(ctx, vdf::launch_sort_order(sc.sel_d.as<uint32_t>(), sc.sel_rank.as<uint32_t>(), (uint32_t)n, sc.perm.as<uint32_t>(),
+                                                d0->sort_scratch.p, d0->sort_scratch.cap, s));
+        }
+        VDF_HIP(ctx, hipMemcpyAsync(out_order, sc.perm.p, n * 4, hipMemcpyDeviceToHost, s));
+        VDF_HIP(ctx, hipStreamSynchronize(s));
+        if (used_device) *used_device = on_device ? 1 : 0;
+        return VDF_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, VDF_E_OOM, "host staging");
+    }
 }

@@ -289,6 +289,149 @@ hipError_t launch_gather_hashes(const uint64_t *hashes, const uint32_t *dur, con
     return hipGetLastError();
 }
 
+// ---- Search::sort's PATH half on the device (round 6) ----------------------------------------------------------------------------
+// PathBuf order of the paths of a decoded cache (blob + offsets, as vdf_cache_soa holds them), without ranks and without the host:
+// for PLAIN paths (path_order.cpp: is_plain - what a directory walk produces: no empty, "." or ".." component, no NUL byte)
+// std::path's component order is the byte order in which '/' sorts below every other byte and a path that ends sorts before one that
+// goes on.  That is an LSD radix sort over 8-byte words of the paths, last word first: byte b of a path becomes END 0 < '/' 1 <
+// bytes 0x01 .. 0x2E as b + 1 < bytes 0x30 .. 0xFF as they are (NUL does not occur, so the codes fit a byte), eight codes big-endian in a
+// u64 key; every round is the stable radix sort above over (key, entry).  Equal paths keep their input order.  The duration sort that
+// follows (stable, by the same machinery) makes it the (duration, path) order of search_algorithm.rs:55-61.
+struct PathFacts {           // filled by path_facts_kernel
+    uint32_t not_plain;      // some path is not plain (the caller falls back to the host's component comparator)
+    uint32_t max_len;        // longest path, bytes
+    uint32_t shared;         // leading bytes every path shares with the first one
+    uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void path_facts_kernel(const char *__restrict__ blob, const unsigned long long *__restrict__ off,
+                                                         const uint32_t *__restrict__ sel, uint32_t n, PathFacts *__restrict__ facts)
+{
+    const uint32_t first = sel ? sel[0] : 0u;
+    const char *p0 = blob + off[first];
+    const size_t l0 = (size_t)(off[first + 1] - off[first]);
+    uint32_t bad = 0, longest = 0, shared = 0xFFFFFFFFu;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t e = sel ? sel[i] : (uint32_t)i;
+        const char *s = blob + off[e];
+        const size_t len = (size_t)(off[e + 1] - off[e]);
+        longest = max(longest, (uint32_t)min(len, (size_t)0xFFFFFFFFu));
+        // is_plain (path_order.cpp), and the bytes shared with the first path
+        if (!(len == 0 || (len == 1 && s[0] == '/'))) {
+            if (s[len - 1] == '/') bad = 1;
+            size_t clen = 0, dots = 0;
+            for (size_t k = s[0] == '/' ? 1 : 0; k < len; k++) {
+                const char c = s[k];
+                if (c == '/') {
+                    if (clen == 0 || (dots == clen && clen <= 2)) bad = 1;
+                    clen = dots = 0;
+                } else {
+                    if (c == 0) bad = 1;
+                    clen++;
+                    dots += c == '.';
+                }
+            }
+            if (dots == clen && clen <= 2) bad = 1;
+        }
+        size_t m = 0;
+        const size_t lim = min(min(len, l0), (size_t)shared);
+        while (m < lim && s[m] == p0[m]) m++;
+        shared = (uint32_t)m;
+    }
+    if (bad) atomicOr(&facts->not_plain, 1u);
+    atomicMax(&facts->max_len, longest);
+    atomicMin(&facts->shared, shared);
+}
+
+// key of word `word` (bytes 8 word .. 8 word + 7) of the path of the candidate at position pos[i] (entry sel[pos[i]], or pos[i] itself)
+__global__ __launch_bounds__(256) void path_keys_kernel(const char *__restrict__ blob, const unsigned long long *__restrict__ off,
+                                                        const uint32_t *__restrict__ sel, const uint32_t *__restrict__ pos, uint32_t n,
+                                                        uint32_t word, uint64_t *__restrict__ keys)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t e = sel ? sel[pos[i]] : pos[i];
+        const unsigned long long o = off[e];
+        const size_t len = (size_t)(off[e + 1] - o);
+        const unsigned char *s = reinterpret_cast<const unsigned char *>(blob + o);
+        uint64_t key = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const size_t at = (size_t)word * 8 + j;
+            uint32_t code = 0;  // END
+            if (at < len) {
+                const uint32_t b = s[at];
+                code = b == '/' ? 1u : b < '/' ? b + 1u : b;
+            }
+            key = (key << 8) | code;
+        }
+        keys[i] = key;
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_or_copy_kernel(const uint32_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src ? src[i] : (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n,
+                                                         uint32_t *__restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[idx[i]];
+}
+
+size_t path_order_scratch_bytes(uint32_t n)
+{
+    const size_t a = 255, kb = ((size_t)n * 8 + a) & ~a, vb = ((size_t)n * 4 + a) & ~a;
+    return 2 * kb + 3 * vb + 256 + radix_work_bytes(n) + 256;
+}
+
+hipError_t launch_path_facts(const char *d_blob, const unsigned long long *d_off, const uint32_t *d_sel, uint32_t n, void *d_facts16, hipStream_t stream)
+{
+    PathFacts init{0u, 0u, 0xFFFFFFFFu, 0u};
+    hipError_t e = hipMemcpyAsync(d_facts16, &init, sizeof init, hipMemcpyHostToDevice, stream);  // (16 bytes from the stack: copied before the call returns)
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(path_facts_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 8192u)), dim3(256), 0, stream, d_blob, d_off, d_sel, n,
+                       static_cast<PathFacts *>(d_facts16));
+    return hipGetLastError();
+}
+
+// order_out[k] = which of the n candidates (candidate c = entry d_sel[c], or entry c when d_sel is null; duration d_dur[c]) stands at
+// position k of the stable order by (duration, path).  Paths must be plain, at most 8 * n_words bytes long, and share their first
+// 8 * first_word bytes.
+hipError_t launch_path_duration_order(const char *d_blob, const unsigned long long *d_off, const uint32_t *d_sel, const uint32_t *d_dur, uint32_t n,
+                                      uint32_t first_word, uint32_t n_words, uint32_t *order_out, void *scratch, size_t scratch_bytes,
+                                      hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (scratch_bytes < path_order_scratch_bytes(n)) return hipErrorInvalidValue;
+    const size_t a = 255, kb = ((size_t)n * 8 + a) & ~a, vb = ((size_t)n * 4 + a) & ~a;
+    char *p = static_cast<char *>(scratch);
+    uint64_t *k_in = reinterpret_cast<uint64_t *>(p); p += kb;   // this round's keys, in the current order
+    uint64_t *k_out = reinterpret_cast<uint64_t *>(p); p += kb;  // where the passes write keys (both buffers alternate inside a round)
+    uint32_t *v[3];
+    for (auto &q : v) { q = reinterpret_cast<uint32_t *>(p); p += vb; }
+    p += 256;
+    const RadixWork w = radix_work(p, n);
+    const dim3 grid(std::min<uint32_t>((n + 255) / 256, 16384u));
+    unsigned shifts[8];
+    for (unsigned b = 0; b < 8; b++) shifts[b] = 8 * b;
+    // v[cur] holds the entries in the current order
+    int cur = 0;
+    hipLaunchKernelGGL(iota_or_copy_kernel, grid, dim3(256), 0, stream, (const uint32_t *)nullptr, n, v[0]);
+    for (uint32_t word = n_words; word-- > first_word;) {
+        hipLaunchKernelGGL(path_keys_kernel, grid, dim3(256), 0, stream, d_blob, d_off, d_sel, v[cur], n, word, k_in);
+        // eight passes: pass 0 reads (k_in, v[cur]) and writes (k_out, A); pass 1 (k_out, A) -> (k_in, B); ... an even count ends in (k_in, B)
+        uint32_t *A = v[(cur + 1) % 3], *B = v[(cur + 2) % 3];
+        hipError_t e = radix_sort_lsd<uint64_t, true>(k_in, v[cur], k_out, A, k_in, B, nullptr, n, shifts, 8, w, stream, nullptr);
+        if (e != hipSuccess) return e;
+        cur = (cur + 2) % 3;
+    }
+    // stable by duration: keys = the durations in the current (path) order
+    uint32_t *dur_in = reinterpret_cast<uint32_t *>(k_in), *dk_a = reinterpret_cast<uint32_t *>(k_out), *dk_b = dk_a + n;
+    hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, stream, d_dur, v[cur], n, dur_in);
+    return radix_sort_lsd<uint32_t, true>(dur_in, v[cur], dk_a, v[(cur + 1) % 3], dk_b, v[(cur + 2) % 3], order_out, n, shifts, 4, w, stream, nullptr);
+}
+
 // ---- hit lists into (row, col) order on the device ---------------------------------------------------------------
 // Dense near-duplicates produce 1e6 - 1e7 thresholded pairs per search; the host replay (search_algorithm.rs:131-170) and the
 // reference grouping want them in (row, col) order, and a host radix sort of 1e7 pairs costs as much as the search kernel.

@@ -161,6 +161,7 @@ struct vdf_ctx {
     std::map<uint32_t, DeviceAxisTable *> axis_tables;
     std::map<uint64_t, DeviceMfmaTable *> mfma_tables;  // key = in_size * 4 + layout (resize_tables.h)
     std::map<uint64_t, BoxTableSet *> box_tables;       // key = w << 32 | h
+    bool no_device_path_order = false;  // VDF_NO_DEVICE_PATH_ORDER: vdf_search_cache_entries orders paths on the host (vdf_path_ranks), as before round 6
     bool lb_host_plan = false;     // VDF_LB_HOST_PLAN: small frames' boxes visit the host between detect and hash (as before round 6: A/B runs)
     bool no_lb_fused = false;      // VDF_NO_LB_FUSED: frames of at most 64 x 64 take detect kernels + cropped kernel instead of the fused kernel
     int hash_no_persistent = 0, hash_wgs_per_cu = 3;

@@ -188,6 +188,13 @@ hipError_t launch_resize_mfma_cropped(const uint8_t *frames, size_t n_clips, uin
 size_t sort_order_scratch_bytes(uint32_t n, bool with_rank);
 hipError_t launch_sort_order(const uint32_t *dur, const uint32_t *rank, uint32_t n, uint32_t *perm_out, void *scratch,
                              size_t scratch_bytes, hipStream_t stream);
+// Search::sort's order of cache entries computed from their PATHS on the device (sort_order.hip): facts first (are the paths plain, how
+// long, what do they share: 16 bytes {not_plain, max_len, shared, pad} at d_facts16), then the stable order by (duration, path).
+hipError_t launch_path_facts(const char *d_blob, const unsigned long long *d_off, const uint32_t *d_sel, uint32_t n, void *d_facts16, hipStream_t stream);
+size_t path_order_scratch_bytes(uint32_t n);
+hipError_t launch_path_duration_order(const char *d_blob, const unsigned long long *d_off, const uint32_t *d_sel, const uint32_t *d_dur, uint32_t n,
+                                      uint32_t first_word, uint32_t n_words, uint32_t *order_out, void *scratch, size_t scratch_bytes,
+                                      hipStream_t stream);
 // hashes_out[k] = hashes[perm[k]], dur_out[k] = dur[perm[k]] (dur / dur_out nullable)
 // hit list into (row, col) order, in place on the device; rows < 2^row_bits
 size_t sort_hits_scratch_bytes(size_t n);
