@@ -119,8 +119,12 @@ def _worker(rank, world, port, capacity, out_dir):
     words, dur = hg.planted_set(rng, 700, n_clusters=30, max_copies=10, max_flips=200, durations="windowed")
     w, d, _ = hg.sort_by_duration(words, dur)
     # uneven shards in rank order; the all-gather must hand every rank the same full, ordered database
-    cut = 301
-    lo, hi = (0, cut) if rank == 0 else (cut, len(d))
+    if world == 2:
+        cut = 301
+        lo, hi = (0, cut) if rank == 0 else (cut, len(d))
+    else:  # eight ranks: uneven cuts, one EMPTY shard (a rank that hashed nothing)
+        cuts = [0, 90, 90, 301, 340, 512, 600, 689, len(d)]
+        lo, hi = cuts[rank], cuts[rank + 1]
     fw, fd = vd.all_gather_database(torch.from_numpy(w[lo:hi].view(np.int64)), torch.from_numpy(d[lo:hi].view(np.int32)))
     assert np.array_equal(fw.numpy().view(np.uint64), w) and np.array_equal(fd.numpy().view(np.uint32), d)
 
@@ -190,6 +194,27 @@ def test_two_rank_search_matches_oracle(tmp_path, capacity):
     f0, f1 = np.load(tmp_path / "filter_0.npy"), np.load(tmp_path / "filter_1.npy")
     if capacity >= 1000:
         assert f0[0] > 0 and f1[0] > 0 and f0[1] == 1 and f1[1] == 1
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("capacity", [1 << 20, 20])
+def test_eight_rank_search_matches_oracle(tmp_path, capacity):
+    """G = 8 on the CPU: the orchestration an 8-GPU node runs under torch.distributed (all-gather of eight uneven shards with an empty one,
+    row tiles dealt over eight ranks, hit gather / merge on rank 0, the overflow protocol's MIN all-reduce and bitmap broadcast, the replay
+    filter's agree / OR-of-bitmaps over eight ranks, references split eight ways)."""
+    import pickle
+
+    from oracle import vdf_oracle as orc
+
+    mp.spawn(_worker, args=(8, _free_port(), capacity, str(tmp_path)), nprocs=8, join=True)
+    res = pickle.load(open(tmp_path / "res.pkl", "rb"))
+    assert res["groups"] == orc.search_self_sorted(res["w"], res["d"], 350)
+    assert res["refs"] == orc.search_refs_sorted(res["w"], res["d"], res["rw"], res["rd"], 300)
+    calls = int(np.load(tmp_path / "calls.npy")[0])
+    assert (calls > 1) == (capacity < 1000)
+    if capacity >= 1000:
+        f = [np.load(tmp_path / f"filter_{r}.npy") for r in range(8)]
+        assert all(x[1] == 1 for x in f) and sum(int(x[0]) for x in f) > 0  # every rank took part in ONE filtered launch; hits were dropped
 
 
 def test_split_range_is_contiguous_and_complete():
