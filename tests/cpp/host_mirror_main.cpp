@@ -47,6 +47,27 @@ static int selftest()
     assert(PathKey("a/b") < PathKey("a.b"));               // component-wise, not bytewise
     assert(PathKey("a//b/") == PathKey("a/b") && PathKey("a/./b") == PathKey("a/b"));
     assert(PathKey("/a") < PathKey("a") && PathKey("./a") < PathKey("../a") && PathKey("../a") < PathKey("a"));
+    // crop.rs:204-271 (the reference's as_view_args / from_topleft_and_dims cases) and the per-edge minimum of :53-68
+    using vdf::Crop;
+    using A4 = std::array<uint32_t, 4>;
+    assert((Crop::from_edge_offsets({100, 100}, 0, 0, 0, 0).as_view_args() == A4{0, 0, 100, 100}));
+    assert((Crop::from_edge_offsets({100, 100}, 1, 0, 0, 0).as_view_args() == A4{1, 0, 99, 100}));
+    assert((Crop::from_edge_offsets({100, 100}, 0, 1, 0, 0).as_view_args() == A4{0, 0, 99, 100}));
+    assert((Crop::from_edge_offsets({100, 100}, 0, 0, 1, 0).as_view_args() == A4{0, 1, 100, 99}));
+    assert((Crop::from_edge_offsets({100, 100}, 0, 0, 0, 1).as_view_args() == A4{0, 0, 100, 99}));
+    assert((Crop::from_edge_offsets({100, 100}, 25, 25, 25, 25).as_view_args() == A4{25, 25, 50, 50}));
+    assert((Crop::from_edge_offsets({768, 432}, 96, 96, 0, 0).as_view_args() == A4{96, 0, 576, 432}));
+    assert((Crop::from_topleft_and_dims({100, 100}, 11, 12, 13, 14).as_view_args() == A4{11, 12, 13, 14}));
+    assert(Crop::from_edge_offsets({3, 3}, 2, 0, 2, 0) == Crop::from_topleft_and_dims({3, 3}, 2, 2, 1, 1));
+    assert(Crop::from_edge_offsets({100, 80}, 10, 0, 5, 7).unite(Crop::from_edge_offsets({100, 80}, 3, 4, 9, 2)) == Crop::from_edge_offsets({100, 80}, 3, 0, 5, 2));
+    {
+        const uint32_t row[4] = {1, 1, 1, 2};  // video_frames_gray.rs:444-459 as the C ABI returns it
+        const Crop c = Crop::from_abi({5, 6}, row);
+        assert(c.width() == 3 && c.height() == 3 && c.area() == 9 && !c.is_uncropped());
+    }
+    bool none_left = false;
+    try { Crop::from_edge_offsets({100, 100}, 50, 50, 50, 50); } catch (const std::invalid_argument &) { none_left = true; }
+    assert(none_left);
     // matches/match_group.rs
     bool threw = false;
     try { vdf::MatchGroup::make({"a"}); } catch (const vdf::TooFewEntries &) { threw = true; }

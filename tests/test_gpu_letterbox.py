@@ -168,6 +168,27 @@ def test_gen_hashes_mirrors_the_builder_default(engine):
         vdf.gen_hashes(frames[:, :10], ["p"] * 6, [0] * 6, engine=engine)
 
 
+def test_cropdetect_letterbox_mirror_returns_crops(engine):
+    """api.cropdetect_letterbox: the reference's function (video_frames_gray.rs:201-210) and return type (crop.rs) for a batch."""
+    import vid_dup_finder_lib_amd as vdf
+
+    pix = [0, 0, 0, 0, 0, 0, 255, 255, 255, 0, 0, 255, 255, 255, 0, 0, 255, 255, 255, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    kat = np.tile(np.array(pix, np.uint8).reshape(1, 1, 6, 5), (1, 16, 1, 1))
+    (c,) = vdf.cropdetect_letterbox(kat, engine=engine)
+    assert c == vdf.Crop.from_edge_offsets((5, 6), 1, 1, 1, 2) and c.as_view_args() == (1, 1, 3, 3)  # video_frames_gray.rs:444-459
+    rng = np.random.default_rng(12)
+    frames = _letterboxed(rng, 10, 48, 64)
+    crops = vdf.cropdetect_letterbox(frames, engine=engine)
+    for i, c in enumerate(crops):
+        l, r, t, b = (int(v) for v in orc.cropdetect_letterbox(frames[i]))
+        assert c == vdf.Crop.from_edge_offsets((64, 48), l, r, t, b)
+        x, y, bw, bh = c.as_view_args()  # the box's view is what the reference crops out and hashes (video_hash_builder.rs:197-201)
+        rc, want, _ = orc.hash_clip(np.ascontiguousarray(frames[i][:, y:y + bh, x:x + bw]), want_coefs=True)
+        assert rc == 0 and np.array_equal(engine.hash_frames_letterbox(frames[i:i + 1])[0][0], want)
+    with pytest.raises(vdf.NotEnoughFrames):
+        vdf.cropdetect_letterbox(frames[:, :10], engine=engine)
+
+
 @pytest.mark.parametrize("base,pad_f,pad_c", [(5, 29, 77), (4, 28, 76)])
 @pytest.mark.parametrize("h,w", [(64, 64), (90, 160), (270, 480), (360, 640)])
 def test_letterbox_strided_misaligned_device_buffers(engine, h, w, base, pad_f, pad_c):

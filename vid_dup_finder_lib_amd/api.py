@@ -20,7 +20,7 @@ from . import _capi
 from ._capi import DEFAULT_SEARCH_TOLERANCE, HASH_BITS, HASH_WORDS, TOLERANCE_SCALING_FACTOR, VdfError
 from .engine import Engine, hamming_distance_words, tolerance_int
 
-__all__ = ["Cropdetect", "gen_hashes", "VideoHash", "MatchGroup", "Error", "NotEnoughFrames", "NotVideo", "VidProc", "TooFewEntries", "search",
+__all__ = ["Crop", "Cropdetect", "cropdetect_letterbox", "gen_hashes", "VideoHash", "MatchGroup", "Error", "NotEnoughFrames", "NotVideo", "VidProc", "TooFewEntries", "search",
            "search_with_references", "default_engine", "hash_frame_stacks", "rust_path_key", "sort_order",
            "DEFAULT_SEARCH_TOLERANCE", "TOLERANCE_SCALING_FACTOR"]
 
@@ -51,6 +51,110 @@ class Cropdetect(enum.Enum):
     NONE = "none"
     LETTERBOX = "letterbox"
     MOTION = "motion"
+
+
+class Crop:
+    """The crop box of a frame as edge offsets (vid_dup_finder_common/src/crop.rs:3-10): what the letterbox detection yields and
+    what crop_resize_buf takes.  On the C ABI a box is the four u32 {left, right, top, bottom} (`out_crops`); this is its host-side
+    type with the reference's constructors, checks and accessors.  Ordered like the derive: orig_res, left, right, top, bottom."""
+
+    __slots__ = ("orig_res", "left", "right", "top", "bottom")
+    _U32 = 0xFFFFFFFF
+
+    def __init__(self, orig_res, left: int, right: int, top: int, bottom: int):
+        self.orig_res = (int(orig_res[0]), int(orig_res[1]))
+        self.left, self.right, self.top, self.bottom = int(left), int(right), int(top), int(bottom)
+
+    @classmethod
+    def from_edge_offsets(cls, orig_res, left: int, right: int, top: int, bottom: int) -> "Crop":
+        """crop.rs:13-30: a box that leaves no pixel is a panic there, an AssertionError here."""
+        assert left + right < orig_res[0], "crop box leaves no columns"
+        assert top + bottom < orig_res[1], "crop box leaves no rows"
+        return cls(orig_res, left, right, top, bottom)
+
+    @classmethod
+    def from_topleft_and_dims(cls, orig_res, x: int, y: int, width: int, height: int) -> "Crop":
+        """crop.rs:32-50 (u32 arithmetic: a box that sticks out of the frame underflows there; refused here)."""
+        right, bottom = orig_res[0] - width - x, orig_res[1] - height - y
+        if right < 0 or bottom < 0:
+            raise OverflowError("box outside the frame")
+        return cls(orig_res, x, right, y, bottom)
+
+    @classmethod
+    def from_abi(cls, orig_res, box) -> "Crop":
+        """One row {left, right, top, bottom} of the C ABI's `out_crops`."""
+        return cls.from_edge_offsets(orig_res, int(box[0]), int(box[1]), int(box[2]), int(box[3]))
+
+    @classmethod
+    def default(cls) -> "Crop":
+        """crop.rs:183-194: an 'enormous' crop to start a fold of unions with."""
+        return cls((cls._U32, cls._U32), cls._U32 // 8, cls._U32 // 8, cls._U32 // 8, cls._U32 // 8)
+
+    def union(self, other: "Crop") -> "Crop":
+        """crop.rs:53-68: per-edge minimum (what unites the crops of the probed frames; the resolutions are not compared)."""
+        return Crop.from_edge_offsets(self.orig_res, min(self.left, other.left), min(self.right, other.right),
+                                      min(self.top, other.top), min(self.bottom, other.bottom))
+
+    def as_view_args(self):
+        """crop.rs:92-103: (x, y, width, height) of the box - the arguments of crop_resize_buf's .crop()."""
+        w, h = self.orig_res[0] - (self.left + self.right), self.orig_res[1] - (self.top + self.bottom)
+        if w < 0 or h < 0:
+            raise OverflowError("crop offsets exceed the frame")  # checked_sub(..).unwrap()
+        return (self.left, self.top, w, h)
+
+    def as_abi(self) -> np.ndarray:
+        return np.array([self.left, self.right, self.top, self.bottom], np.uint32)
+
+    def width(self) -> int:
+        return self.orig_res[0] - (self.left + self.right)
+
+    def height(self) -> int:
+        return self.orig_res[1] - (self.top + self.bottom)
+
+    def area(self) -> int:
+        return self.width() * self.height()
+
+    def aspect_ratio(self) -> float:
+        return float(self.width()) / float(self.height())
+
+    def enumerate_coords(self) -> Iterator:
+        """crop.rs:121-135: the box's (x, y), x outermost."""
+        for x in range(self.left, self.orig_res[0] - self.right):
+            for y in range(self.top, self.orig_res[1] - self.bottom):
+                yield (x, y)
+
+    def enumerate_coords_excluded(self) -> Iterator:
+        """crop.rs:137-161: the (x, y) outside the box, the eight surrounding regions clockwise from the top left."""
+        xs = (0, self.left, self.orig_res[0] - self.right, self.orig_res[0])
+        ys = (0, self.top, self.orig_res[1] - self.bottom, self.orig_res[1])
+        for xi, yi in ((0, 0), (1, 0), (2, 0), (2, 1), (0, 2), (1, 2), (2, 2), (0, 1)):
+            for x in range(xs[xi], xs[xi + 1]):
+                for y in range(ys[yi], ys[yi + 1]):
+                    yield (x, y)
+
+    def eroded(self) -> Optional["Crop"]:
+        """crop.rs:163-176: one pixel more off every edge, None when nothing would be left."""
+        if self.left + self.right + 2 >= self.orig_res[0] or self.top + self.bottom + 2 >= self.orig_res[1]:
+            return None
+        return Crop(self.orig_res, self.left + 1, self.right + 1, self.top + 1, self.bottom + 1)
+
+    def is_uncropped(self) -> bool:
+        return self.left == 0 and self.right == 0 and self.top == 0 and self.bottom == 0
+
+    def _key(self):
+        return (self.orig_res, self.left, self.right, self.top, self.bottom)
+
+    def __eq__(self, other):
+        return isinstance(other, Crop) and self._key() == other._key()
+
+    def __lt__(self, other):
+        return self._key() < other._key()
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __repr__(self):
+        return f"Crop(orig_res={self.orig_res}, left={self.left}, right={self.right}, top={self.top}, bottom={self.bottom})"
 
 
 class TooFewEntries(Exception):
@@ -328,3 +432,18 @@ def gen_hashes(frames: np.ndarray, src_paths: Sequence, durations: Sequence[int]
             raise VidProc(str(e)) from e
         raise
     return [VideoHash(words[i], src_paths[i], durations[i]) for i in range(len(words))]
+
+
+def cropdetect_letterbox(frames: np.ndarray, engine: Optional[Engine] = None) -> List[Crop]:
+    """cropdetect_letterbox (vid_dup_finder_common/src/video_frames_gray.rs:201-210) for a batch of clips on the GPU: frames
+    [n_clips, n_frames >= 16, H, W] u8 -> the union (crop.rs:53-68) of the letterbox crops of frames 0 and 8 of each clip."""
+    try:
+        _words, crops = (engine or default_engine()).hash_frames_letterbox(frames)
+    except VdfError as e:
+        if e.code == _capi.VDF_E_NOT_ENOUGH_FRAMES:
+            raise NotEnoughFrames() from e
+        if e.code == _capi.VDF_E_BAD_DIMS:
+            raise VidProc(str(e)) from e
+        raise
+    h, w = int(frames.shape[2]), int(frames.shape[3])
+    return [Crop.from_abi((w, h), c) for c in np.asarray(crops).reshape(-1, 4)]

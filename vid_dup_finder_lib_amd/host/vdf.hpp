@@ -19,6 +19,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -98,6 +99,48 @@ struct PathKey {
     }
     bool operator<(const PathKey &o) const { return comps < o.comps; }
     bool operator==(const PathKey &o) const { return comps == o.comps; }
+};
+
+// ---- Crop (vid_dup_finder_common/src/crop.rs:3-10) ---------------------------------------------------------------
+// The crop box of a frame as edge offsets: what the letterbox detection yields and crop_resize_buf takes; one row {left, right, top,
+// bottom} of the C ABI's out_crops.  Member order = the derive's comparison order.
+struct Crop {
+    std::pair<uint32_t, uint32_t> orig_res{0, 0};
+    uint32_t left = 0, right = 0, top = 0, bottom = 0;
+
+    // crop.rs:13-30 (the reference asserts; a box that leaves no pixel throws here)
+    static Crop from_edge_offsets(std::pair<uint32_t, uint32_t> res, uint32_t l, uint32_t r, uint32_t t, uint32_t b)
+    {
+        if ((uint64_t)l + r >= res.first || (uint64_t)t + b >= res.second) throw std::invalid_argument("crop box leaves no pixels");
+        return Crop{res, l, r, t, b};
+    }
+    // crop.rs:32-50
+    static Crop from_topleft_and_dims(std::pair<uint32_t, uint32_t> res, uint32_t x, uint32_t y, uint32_t w, uint32_t h)
+    {
+        if ((uint64_t)x + w > res.first || (uint64_t)y + h > res.second) throw std::invalid_argument("box outside the frame");
+        return Crop{res, x, res.first - w - x, y, res.second - h - y};
+    }
+    static Crop from_abi(std::pair<uint32_t, uint32_t> res, const uint32_t *box) { return from_edge_offsets(res, box[0], box[1], box[2], box[3]); }
+    // crop.rs:53-68: per-edge minimum (unites the crops of the probed frames)
+    Crop unite(const Crop &o) const
+    {
+        return from_edge_offsets(orig_res, std::min(left, o.left), std::min(right, o.right), std::min(top, o.top), std::min(bottom, o.bottom));
+    }
+    // crop.rs:92-103: {x, y, width, height}
+    std::array<uint32_t, 4> as_view_args() const
+    {
+        if ((uint64_t)left + right > orig_res.first || (uint64_t)top + bottom > orig_res.second) throw std::overflow_error("crop offsets exceed the frame");
+        return {left, top, orig_res.first - (left + right), orig_res.second - (top + bottom)};
+    }
+    uint32_t width() const { return orig_res.first - (left + right); }
+    uint32_t height() const { return orig_res.second - (top + bottom); }
+    uint32_t area() const { return width() * height(); }
+    bool is_uncropped() const { return left == 0 && right == 0 && top == 0 && bottom == 0; }
+    bool operator==(const Crop &o) const { return orig_res == o.orig_res && left == o.left && right == o.right && top == o.top && bottom == o.bottom; }
+    bool operator<(const Crop &o) const
+    {
+        return std::tie(orig_res, left, right, top, bottom) < std::tie(o.orig_res, o.left, o.right, o.top, o.bottom);
+    }
 };
 
 // ---- VideoHash (video_hash.rs:26-32) ----------------------------------------------------------------------
