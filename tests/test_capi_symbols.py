@@ -176,6 +176,17 @@ def test_host_helpers_match_oracle():
     assert ve.count_pairs_refs(dur, refs) == want
 
 
+def test_informational_getters_answer_without_a_gpu():
+    from vid_dup_finder_lib_amd import _capi
+
+    lib = _capi.load()
+    ver = lib.vdf_version()
+    assert isinstance(ver, bytes) and ver and all(32 <= c < 127 for c in ver)
+    assert lib.vdf_row_tile_size() in (256, 512, 1024)  # rows dealt to a shard at a time (vdf.h: vdf_search_self_device)
+    assert lib.vdf_live_device_bytes() == 0 and lib.vdf_live_pinned_bytes() == 0  # nothing is held before a context exists
+    assert lib.vdf_ctx_device(None) == -1 and lib.vdf_ctx_device_count(None) <= 0 and lib.vdf_ctx_rccl_ranks(None) <= 0
+
+
 def _adjacency(words, dur, tol, lo_fn):
     """All thresholded pairs inside the duration windows, by numpy (test-side stand-in for the kernel)."""
     n = len(dur)

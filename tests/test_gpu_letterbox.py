@@ -734,7 +734,7 @@ def test_contexts_give_their_device_memory_back():
     d = torch.from_numpy(frames).cuda()
     out = torch.zeros((n, 16), dtype=torch.int64, device="cuda")
     words = rng.integers(0, 2**63, size=(5000, 16), dtype=np.int64).astype(np.uint64)
-    before = lib.vdf_live_device_bytes()
+    before, pinned_before = lib.vdf_live_device_bytes(), lib.vdf_live_pinned_bytes()
     for _ in range(3):
         eng = vdf.Engine(0)
         try:
@@ -743,10 +743,11 @@ def test_contexts_give_their_device_memory_back():
             eng.search_self_sorted(words, np.zeros(len(words), np.uint32), 350)
             eng.search_refs_sorted(words, np.zeros(len(words), np.uint32), words[:100], np.zeros(100, np.uint32), 350)
             torch.cuda.synchronize()
-            assert lib.vdf_live_device_bytes() > before
+            assert lib.vdf_live_device_bytes() > before and lib.vdf_live_pinned_bytes() > pinned_before
+            assert lib.vdf_ctx_device(eng.ctx) == 0
         finally:
             eng.close()
-        assert lib.vdf_live_device_bytes() == before
+        assert lib.vdf_live_device_bytes() == before and lib.vdf_live_pinned_bytes() == pinned_before
     eng = vdf.Engine(0)  # a batching queue: two slots per GPU with private contexts
     try:
         from vid_dup_finder_lib_amd.engine import HashQueue
