@@ -176,6 +176,21 @@ def test_host_helpers_match_oracle():
     assert ve.count_pairs_refs(dur, refs) == want
 
 
+def test_a_c99_caller_compiles_against_the_header_and_runs(tmp_path):
+    """The boundary is a C ABI: the header must be C (cgo, bindgen and ctypes read it as C, not C++).  tests/cpp/c_caller.c is built with
+    -std=c99 -pedantic -Werror against libvdf_hip.so and exercises the host-only entry points (and vdf_ctx_create's loud refusal
+    without a GPU)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "vid_dup_finder_lib_amd")
+    exe = str(tmp_path / "c_caller")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(root, "tests", "cpp", "c_caller.c"),
+                           "-L" + lib, "-lvdf_hip", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "c caller ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_informational_getters_answer_without_a_gpu():
     from vid_dup_finder_lib_amd import _capi
 
