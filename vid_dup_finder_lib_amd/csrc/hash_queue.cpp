@@ -12,8 +12,20 @@
 // free slot starts collecting, so new arrivals copy their frames in - and may even start their own batch - while the
 // previous batch is still on the GPU (at 1080p a clip is 33 MB: the staging copies are the long part).  All clips of a
 // queue have the same frame size (one queue per resolution).
+//
+// Who wakes whom (round 6; one mutex, but every wait has its own condition variable): the first form had ONE condition variable
+// for everything and every joiner notified all of it, so with T callers each batch cost ~max_batch wake-ups of ~T threads that
+// re-took the mutex to find nothing had changed for them - 64 callers at 1080p got 26 GB/s where 16 got the link's 57, and
+// 64 x 64 clips 27 k clips/s (tools/bench_hash_queue.cpp, profiles/r06_hash_queue.txt).  Now
+//   * arrivals that find no collecting slot sleep on the queue's cv_free; a slot that reopens wakes at most max_batch of them;
+//   * a slot's leader sleeps on the slot's cv_leader; a joiner wakes it only when its join fills the batch or its copy is the
+//     last one the closed batch waits for;
+//   * joiners sleep on the slot's cv_done; the leader wakes them once, when the results are in.
+// VDF_QUEUE_SLOTS (read when a queue is made): slots per GPU, default 2; more slots keep more batches in flight when there are
+// many more callers than max_batch (each slot pins max_batch clips of staging).
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -34,6 +46,8 @@ struct Slot {
     uint32_t count = 0, ready = 0, remaining = 0;
     uint64_t gen = 0, done_gen = ~0ull;
     int batch_rc = VDF_OK;
+    std::condition_variable cv_leader;  // the leader: the batch is full / every joined copy has finished
+    std::condition_variable cv_done;    // the joiners: the batch's results are in
 };
 
 }  // namespace
@@ -45,7 +59,8 @@ struct vdf_hash_queue {
     std::vector<Slot> slots;
     size_t cur = 0;  // the slot new arrivals join
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv_free;  // arrivals: some slot collects again
+    uint32_t waiting_free = 0;        // ... how many sleep there
     uint64_t n_batches = 0, n_clips = 0;
     uint32_t in_flight = 0, in_flight_max = 0;
 };
@@ -72,7 +87,12 @@ int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_bat
     q->w = w; q->h = h; q->max_batch = max_batch; q->max_wait_us = max_wait_us; q->letterbox = letterbox;
     q->clip_bytes = (size_t)w * h * VDF_DCT_SIZE;
     const int n_dev = vdf_ctx_device_count(ctx);
-    q->slots.resize((size_t)(2 * n_dev));
+    int per_gpu = 2;
+    if (const char *e = std::getenv("VDF_QUEUE_SLOTS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 16) per_gpu = v;
+    }
+    q->slots = std::vector<Slot>((size_t)(per_gpu * n_dev));
     vdf_impl::DeviceGuard restore_device;  // the loop below visits every device of the context on the caller's thread
     for (size_t k = 0; k < q->slots.size(); k++) {
         Slot &s = q->slots[k];
@@ -100,29 +120,35 @@ int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *ou
     if (!q || !frames || !out_hash) return VDF_E_INVAL;
     std::unique_lock<std::mutex> lk(q->mu);
     // join the collecting slot; if it has closed (or is full), the next slot that is free to collect takes over
-    Slot *sp = nullptr;
-    q->cv.wait(lk, [&] {
+    auto collecting = [&]() -> Slot * {
         for (size_t i = 0; i < q->slots.size(); i++) {
             const size_t k = (q->cur + i) % q->slots.size();
             Slot &c = q->slots[k];
-            if (c.state == Slot::COLLECTING && c.count < q->max_batch) { q->cur = k; sp = &c; return true; }
+            if (c.state == Slot::COLLECTING && c.count < q->max_batch) { q->cur = k; return &c; }
         }
-        return false;
-    });
+        return nullptr;
+    };
+    Slot *sp = collecting();
+    while (!sp) {
+        q->waiting_free++;
+        q->cv_free.wait(lk);
+        q->waiting_free--;
+        sp = collecting();
+    }
     Slot &s = *sp;
     const uint32_t my = s.count++;
     const uint64_t my_gen = s.gen;
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(q->max_wait_us);
+    if (my != 0 && s.count == q->max_batch) s.cv_leader.notify_one();  // this join fills the batch: the leader need not wait for its deadline
     lk.unlock();
     std::memcpy(s.staging + (size_t)my * q->clip_bytes, frames, q->clip_bytes);  // outside the lock: callers copy in parallel
     lk.lock();
     s.ready++;
     if (my == 0) {
         // leader: give others until the deadline (counted from the first arrival) or until the batch is full
-        q->cv.wait_until(lk, deadline, [&] { return s.count == q->max_batch; });
+        while (s.count < q->max_batch && s.cv_leader.wait_until(lk, deadline) != std::cv_status::timeout) {}
         s.state = Slot::RUNNING;                                   // no more joins here; arrivals move on to the next slot
-        q->cv.notify_all();
-        q->cv.wait(lk, [&] { return s.ready == s.count; });        // every joined caller has finished its copy
+        while (s.ready < s.count) s.cv_leader.wait(lk);            // every joined caller has finished its copy
         const uint32_t n = s.count;
         q->in_flight++;
         if (q->in_flight > q->in_flight_max) q->in_flight_max = q->in_flight;
@@ -143,10 +169,10 @@ int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *ou
         s.state = Slot::DRAINING;
         q->n_batches++;
         q->n_clips += n;
-        q->cv.notify_all();
+        s.cv_done.notify_all();
     } else {
-        q->cv.notify_all();                                        // the leader may be waiting for count / ready
-        q->cv.wait(lk, [&] { return s.done_gen == my_gen && s.state == Slot::DRAINING; });
+        if (s.state == Slot::RUNNING && s.ready == s.count) s.cv_leader.notify_one();  // the closed batch was waiting for this copy
+        while (!(s.done_gen == my_gen && s.state == Slot::DRAINING)) s.cv_done.wait(lk);
     }
     const int rc = s.batch_rc;
     if (rc == VDF_OK) {
@@ -158,7 +184,11 @@ int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *ou
         s.ready = 0;
         s.gen++;
         s.state = Slot::COLLECTING;
-        q->cv.notify_all();
+        // as many sleepers as the slot has room for (each takes the mutex in turn; the rest sleep on)
+        const uint32_t wake = q->waiting_free < q->max_batch ? q->waiting_free : q->max_batch;
+        if (wake >= q->waiting_free) q->cv_free.notify_all();
+        else
+            for (uint32_t i = 0; i < wake; i++) q->cv_free.notify_one();
     }
     return rc;
 }
