@@ -151,3 +151,45 @@ def test_queue_on_a_multi_gpu_context_spreads_its_slots():
         q.close()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("slots", ["1", "4"])
+def test_queue_slots_knob_and_many_more_callers_than_a_batch(engine, monkeypatch, slots):
+    """VDF_QUEUE_SLOTS (read when a queue is made): one slot (every batch waits for the one before) and four; 48 callers against
+    batches of 4, so most of them sleep for a free slot at any time (the wake-ups of round 6: a reopening slot wakes as many
+    sleepers as it has room for) - every clip against the oracle, letterbox boxes included, and a large frame size that crosses
+    the link in several pieces."""
+    from vid_dup_finder_lib_amd.engine import HashQueue
+
+    monkeypatch.setenv("VDF_QUEUE_SLOTS", slots)
+    rng = np.random.default_rng(int(slots))
+    for (h, w, n, letterbox) in ((40, 56, 240, True), (360, 640, 48, False)):
+        frames = rng.integers(40, 220, size=(n, 16, h, w), dtype=np.uint8)
+        if letterbox:
+            frames[::2, :, :6, :] = 20
+            frames[1::3, :, :, :9] = 200
+            o_hash, o_crop = _oracle_letterbox(frames)
+        else:
+            o_hash, o_crop = orc.hash_clips(frames), [(0, 0, 0, 0)] * n
+        q = HashQueue(engine, w, h, max_batch=4, max_wait_us=300, letterbox=letterbox)
+        got, errs = [None] * n, []
+
+        def worker(ids):
+            try:
+                for i in ids:
+                    got[i] = q.submit(frames[i])
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        threads = [threading.Thread(target=worker, args=(range(t, n, 48),)) for t in range(48)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=180)
+        assert not errs and all(g is not None for g in got)
+        for i in range(n):
+            assert np.array_equal(got[i][0], o_hash[i]) and got[i][1] == o_crop[i], (h, w, i)
+        n_batches, n_clips = q.stats()
+        assert n_clips == n and n_batches >= n // 4
+        assert q.in_flight_max() <= int(slots)
+        q.close()

@@ -44,6 +44,8 @@ KNOBS = [
     ({"VDF_NO_DEVICE_PATH_ORDER": "1"}, "mfma"),  # exercised by tests/test_gpu_path_order.py (the cache route on both roads)
     ({"VDF_NO_HIT_FILTER": "1"}, "mfma"),
     ({"VDF_CAND_CAPACITY": "64"}, "mfma"),
+    ({"VDF_SPIN_WAIT": "1"}, "mfma"),        # the host hashing path's waits spin (round 6: they sleep after a short poll)
+    ({"VDF_NO_LINK_TURNS": "1"}, "mfma"),    # bulk host-to-device transfers without the per-GPU turn (hash_host.cpp)
     ({"VDF_RESIZE_MODE": "4"}, "mfma"),
 ]
 

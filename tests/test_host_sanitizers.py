@@ -36,3 +36,20 @@ def test_mt_decoder_sidecar_parser_and_path_ranker_are_clean_under_asan_ubsan(tm
 def test_mt_decoder_and_path_ranker_are_clean_under_tsan(tmp_path):
     """The same driver under ThreadSanitizer: the decoder's ranges and the ranker's sample sort share arrays between threads."""
     _build_and_run_mt(tmp_path, ["-fsanitize=thread"], "host_sanitize_mt_tsan")
+
+
+def test_batching_queue_logic_is_clean_under_tsan(tmp_path):
+    """csrc/hash_queue.cpp itself (one mutex, a condition variable per kind of wait - round 6) with the GPU behind it replaced by
+    stand-ins (tests/cpp/queue_tsan_main.cpp): 48 callers against batches of 4, one to four slots, batches that never fill, a
+    single caller.  A lost wake-up is a hang (the timeout), a wrong hand-over a wrong checksum, an unlocked access a TSan report."""
+    import pytest
+
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("HIP headers not installed")
+    exe = str(tmp_path / "queue_tsan")
+    csrc = os.path.join(ROOT, "vid_dup_finder_lib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-DVDF_QUEUE_SYSTEM_CLOCK", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-o", exe, os.path.join(ROOT, "tests", "cpp", "queue_tsan_main.cpp"),
+                           os.path.join(csrc, "hash_queue.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "queue tsan ok" in out.stdout and "ThreadSanitizer" not in out.stderr, (out.stdout[-1500:], out.stderr[-3000:])

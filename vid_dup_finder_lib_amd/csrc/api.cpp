@@ -50,6 +50,7 @@ vdf_ctx::~vdf_ctx()
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_mid) (void)hipEventDestroy(ev_mid);
+    if (ev_wait) (void)hipEventDestroy(ev_wait);
     for (hipEvent_t e : ev_copy) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_done) if (e) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -408,6 +409,26 @@ int upload(vdf_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, hipStream_t
 {
     VDF_HIP(ctx, buf.reserve(std::max<size_t>(bytes, 16)));
     if (bytes) VDF_HIP(ctx, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, stream));
+    return VDF_OK;
+}
+
+std::mutex &link_mutex(int device)
+{
+    static std::mutex m[64];
+    return m[(unsigned)device % 64u];
+}
+
+int wait_event(vdf_ctx *ctx, hipEvent_t ev)
+{
+    if (!ctx->spin_wait) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(50);
+        do {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) return VDF_OK;
+            if (q != hipErrorNotReady) return fail_hip(ctx, q, "hipEventQuery");
+        } while (std::chrono::steady_clock::now() < until);
+    }
+    VDF_HIP(ctx, hipEventSynchronize(ev));
     return VDF_OK;
 }
 
@@ -1101,7 +1122,8 @@ int letterbox_hash_device_locked(vdf_ctx *ctx, const uint8_t *d_frames, size_t n
     if (!ctx->pin_crops.reserve(n_clips * 16)) return fail(ctx, VDF_E_OOM, "host staging for the crop boxes");
     uint32_t *crops = ctx->pin_crops.as<uint32_t>();
     VDF_HIP(ctx, hipMemcpyAsync(crops, d_crops, n_clips * 16, hipMemcpyDeviceToHost, stream));
-    VDF_HIP(ctx, hipStreamSynchronize(stream));
+    VDF_HIP(ctx, hipEventRecord(ctx->ev_wait, stream));
+    if (int rcw = wait_event(ctx, ctx->ev_wait)) return rcw;  // (behind the frames' upload when they come from the host: milliseconds)
     if (out_crops) std::memcpy(out_crops, crops, n_clips * 16);
     return hash_cropped_locked(ctx, d_frames, n_clips, frames_per_clip, w, h, frame_stride, clip_stride, crops, d_out, d_dc, stream);
 }
@@ -1159,14 +1181,16 @@ int create_single(int device_id, vdf_ctx **out, std::string *err)
     vdf_ctx *ctx = new (std::nothrow) vdf_ctx();
     if (!ctx) return VDF_E_OOM;
     ctx->device = device_id;
+    ctx->spin_wait = std::getenv("VDF_SPIN_WAIT") != nullptr;
+    ctx->no_link_turns = std::getenv("VDF_NO_LINK_TURNS") != nullptr;
+    const unsigned wait_flags = hipEventDisableTiming | (ctx->spin_wait ? 0u : (unsigned)hipEventBlockingSync);
     bool ok = hipSetDevice(device_id) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
-              hipEventCreate(&ctx->ev_mid) == hipSuccess;
+              hipEventCreate(&ctx->ev_mid) == hipSuccess && hipEventCreateWithFlags(&ctx->ev_wait, wait_flags) == hipSuccess;
     for (int i = 0; ok && i < 2; i++)
-        ok = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming) == hipSuccess;
+        ok = hipEventCreateWithFlags(&ctx->ev_copy[i], wait_flags) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_done[i], wait_flags) == hipSuccess;
     if (!ok) {
         *err = std::string("context setup failed: ") + hipGetErrorString(hipGetLastError());
         delete ctx;

@@ -113,7 +113,11 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
     for (int i = 0; i < 2; i++)  // full-size chunks from the first call on: pinning memory is slow, do it once
         if (!ctx->pin[i].reserve(std::max(kChunkBytes, chunk * cbytes))) return fail(ctx, VDF_E_OOM, "pinned staging buffer");
     CopyPool *pool = pool_of(ctx);
-    hipStream_t s = ctx->stream, cs = ctx->copy_stream;
+    hipStream_t s = ctx->stream, cs = s;
+    if (n_batches > 1 && !ctx->one_stream) {  // the next batch's frames cross the link under this batch's kernels: a stream of their own
+        if (!ctx->copy_stream) VDF_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        cs = ctx->copy_stream;
+    }
 
     auto copy_out = [&](size_t b) {  // results of batch b: pinned -> caller arrays (its ev_done has been waited for)
         const size_t c0 = b * batch, nb = std::min(batch, n_clips - c0);
@@ -126,11 +130,18 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
         const size_t c0 = b * batch, nb = std::min(batch, n_clips - c0);
         const int slot = (int)(b & 1);
         if (b >= 2) {  // the slot's previous batch (b - 2): kernels done, results landed in pinned memory
-            VDF_HIP(ctx, hipEventSynchronize(ctx->ev_done[slot]));
+            if (int rcw = wait_event(ctx, ctx->ev_done[slot])) return rcw;
             copy_out(b - 2);
         }
         // stage the batch chunk by chunk: threads fill pinned chunk p while the DMA of the other chunk is in flight
+        // Turns on the link: contexts that feed one GPU from the host at the same time (the batching queue's slots) had their transfers
+        // interleaved piece by piece by the copy engine - both batches arrive late and together, their callers then refill the staging
+        // together with the link idle, and the pattern holds itself: 38 - 42 GB/s where batches taking turns reach the link's 55 - 57
+        // (tools/bench_two_ctx.cpp, tools/bench_hash_queue.cpp).  A bulk transfer therefore holds the device's link mutex until its
+        // frames are over; a batch below 1 MB is not worth a turn.
+        std::unique_lock<std::mutex> turn(link_mutex(ctx->device), std::defer_lock);
         if (direct_env && packed) {
+            if (!ctx->no_link_turns && nb * cbytes >= (1u << 20)) turn.lock();
             VDF_HIP(ctx, hipMemcpyAsync(d_frames[slot]->p, frames + c0 * clip_stride, nb * cbytes, hipMemcpyHostToDevice, cs));
             VDF_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cs));
             chunk_counter = 1;
@@ -138,7 +149,8 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
         for (size_t q0 = 0; q0 < nb; q0 += chunk, chunk_counter++) {
             const size_t nq = std::min(chunk, nb - q0);
             const int p = (int)(chunk_counter & 1);
-            if (chunk_counter >= 2) VDF_HIP(ctx, hipEventSynchronize(ctx->ev_copy[p]));  // the DMA that last read this chunk
+            if (chunk_counter >= 2)  // the DMA that last read this chunk
+                if (int rcw = wait_event(ctx, ctx->ev_copy[p])) return rcw;
             uint8_t *dst = ctx->pin[p].as<uint8_t>();
             const uint8_t *src = frames + (c0 + q0) * clip_stride;
             if (packed) {
@@ -162,6 +174,13 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
         VDF_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_copy[(chunk_counter - 1) & 1], 0));
         uint32_t *dc = out_dontcare ? d_dc[slot]->as<uint32_t>() : nullptr;
         int rc;
+        auto end_turn = [&]() -> int {  // the frames are over: the link is the next context's
+            if (!turn.owns_lock()) return VDF_OK;
+            const int rcw = wait_event(ctx, ctx->ev_copy[0]);
+            turn.unlock();
+            return rcw;
+        };
+        if (letterbox && (rc = end_turn())) return rc;  // (the letterbox call waits for its detect pass, i.e. for the frames, anyway)
         if (letterbox)
             rc = letterbox_hash_device_locked(ctx, d_frames[slot]->as<uint8_t>(), nb, VDF_DCT_SIZE, w, h, fbytes, cbytes,
                                               d_hash[slot]->as<uint64_t>(), dc, out_crops ? out_crops + 4 * c0 : nullptr, s);
@@ -173,11 +192,12 @@ int hash_host_locked(vdf_ctx *ctx, const uint8_t *frames, size_t n_clips, uint32
         VDF_HIP(ctx, hipMemcpyAsync(po, d_hash[slot]->p, nb * VDF_HASH_WORDS * 8, hipMemcpyDeviceToHost, s));
         if (dc) VDF_HIP(ctx, hipMemcpyAsync(po + batch * VDF_HASH_WORDS * 8, dc, nb * 4, hipMemcpyDeviceToHost, s));
         VDF_HIP(ctx, hipEventRecord(ctx->ev_done[slot], s));
+        if ((rc = end_turn())) return rc;  // (behind the kernels' launches: they start the moment the frames are in)
         // the next batch's DMA into the other device buffer must not overtake the kernels that still read it
         if (b + 1 < n_batches && b >= 1) VDF_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_done[(b + 1) & 1], 0));
     }
     for (size_t b = n_batches >= 2 ? n_batches - 2 : 0; b < n_batches; b++) {
-        VDF_HIP(ctx, hipEventSynchronize(ctx->ev_done[b & 1]));
+        if (int rcw = wait_event(ctx, ctx->ev_done[b & 1])) return rcw;
         copy_out(b);
     }
     return VDF_OK;

@@ -36,6 +36,15 @@
 
 namespace {
 
+// The leader's deadline runs on the steady clock.  (-DVDF_QUEUE_SYSTEM_CLOCK: tests/test_host_sanitizers.py builds this file under
+// ThreadSanitizer, whose runtime in gcc 11 does not know pthread_cond_clockwait - the steady-clock wait - and then misses the mutex
+// hand-over inside it; the system-clock wait is one it knows.)
+#ifdef VDF_QUEUE_SYSTEM_CLOCK
+using QueueClock = std::chrono::system_clock;
+#else
+using QueueClock = std::chrono::steady_clock;
+#endif
+
 struct Slot {
     vdf_ctx *ctx = nullptr;      // private context of this slot
     uint8_t *staging = nullptr;  // pinned host memory, max_batch clips of 16 frames
@@ -99,6 +108,7 @@ int vdf_hash_queue_create(vdf_ctx *ctx, uint32_t w, uint32_t h, uint32_t max_bat
         const int dev = vdf_ctx_device_at(ctx, (int)(k % (size_t)n_dev));
         int rc = vdf_ctx_create(dev, &s.ctx);
         if (rc) { vdf_hash_queue_destroy(q); return rc; }
+        s.ctx->one_stream = true;  // one stream per slot: the slots' streams and the parent's fit HIP's four hardware queues (vdf_ctx.h)
         (void)hipSetDevice(dev);
         if (hipHostMalloc((void **)&s.staging, q->clip_bytes * max_batch, hipHostMallocDefault) == hipSuccess) {
             s.pinned = true;
@@ -138,7 +148,7 @@ int vdf_hash_queue_submit(vdf_hash_queue *q, const uint8_t *frames, uint64_t *ou
     Slot &s = *sp;
     const uint32_t my = s.count++;
     const uint64_t my_gen = s.gen;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(q->max_wait_us);
+    const auto deadline = QueueClock::now() + std::chrono::microseconds(q->max_wait_us);
     if (my != 0 && s.count == q->max_batch) s.cv_leader.notify_one();  // this join fills the batch: the leader need not wait for its deadline
     lk.unlock();
     std::memcpy(s.staging + (size_t)my * q->clip_bytes, frames, q->clip_bytes);  // outside the lock: callers copy in parallel

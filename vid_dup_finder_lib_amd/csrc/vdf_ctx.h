@@ -127,7 +127,12 @@ struct ExpOwner {
 struct vdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;  // H2D staging of the next batch under the current batch's kernels (hash path)
+    // H2D staging of the next batch under the current batch's kernels (hash path).  Made by the first call that has more than one
+    // batch: HIP spreads a process's streams over FOUR hardware queues per GPU by default (GPU_MAX_HW_QUEUES), and streams that share one
+    // wait for each other - with two streams per context, the batching queue's two slots and their parent context were six, and a slot's
+    // detect kernels sat behind the other slot's 265 MB of frames (profiles/r06_hash_queue.txt).
+    hipStream_t copy_stream = nullptr;
+    bool one_stream = false;  // the batching queue's slot contexts: transfers on `stream` even in a call of several batches
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     std::mutex mu;
@@ -136,6 +141,9 @@ struct vdf_ctx {
     vdf_search_stats stats{};
     vdf_search_timing timing{};
     hipEvent_t ev_mid = nullptr;  // between the distance kernel and the suspect resolution
+    hipEvent_t ev_wait = nullptr; // waits of a millisecond and more in the hashing calls (wait_event: a short poll, then the thread sleeps)
+    bool spin_wait = false;       // VDF_SPIN_WAIT: those waits spin like every other (as before round 6: A/B runs)
+    bool no_link_turns = false;   // VDF_NO_LINK_TURNS: bulk host-to-device transfers of different contexts may interleave (as before round 6: A/B runs)
     uint32_t tile_rows = 256 * vdf::kDefaultRowsPerLane;
     uint32_t chunk_cols = vdf::kDefaultChunkCols;
     // search scratch
@@ -242,6 +250,12 @@ inline bool hit_less(const vdf_hit &a, const vdf_hit &b) { return a.row != b.row
 // ---- single-device building blocks (api.cpp); the caller holds the lock of the context it passes -----------------
 int create_single(int device_id, vdf_ctx **out, std::string *err);
 int upload(vdf_ctx *ctx, DevBuf &buf, const void *src, size_t bytes, hipStream_t stream);
+// Waits for an event of the hashing calls' bulk phases (frames crossing the PCIe link, the detect pass of a large batch): polls for
+// ~50 us, then sleeps until the event's interrupt (ev_copy / ev_done / ev_wait are created with hipEventBlockingSync).  A spinning
+// hipEventSynchronize / hipStreamSynchronize holds a core for the whole transfer - two cores per GPU under the batching queue - which
+// the callers' decoders and staging copies need (measured under a 16-CPU quota: tools/bench_hash_queue.cpp, profiles/r06_hash_queue.txt).
+int wait_event(vdf_ctx *ctx, hipEvent_t ev);
+std::mutex &link_mutex(int device);  // one per GPU of the process: whose bulk host-to-device transfer has the PCIe link (hash_host.cpp)
 // windows + tiles, distance kernel, hit download (sorted by (row, col)); mode 0 = self, 1 = references
 // replay_only: the hits feed nothing but the greedy replay of search(), so hits that provably cannot matter to it may be
 // dropped on the device (then *n_hits_out = the number kept; stats.n_hits still counts every thresholded pair)
