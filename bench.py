@@ -407,9 +407,40 @@ def summary_object(out):
     lb = (out.get("hash") or {}).get("letterbox_64x64")
     if isinstance(lb, dict):
         s["letterbox_64x64_ms"] = {k: round(v["ms_per_step"], 4) for k, v in lb.items() if isinstance(v, dict) and "ms_per_step" in v}
+    hq = (out.get("hash") or {}).get("host_queue_1080p")
+    if isinstance(hq, dict):
+        s["host_queue_1080p_link_GB_per_s"] = {k: v.get("link_GB_per_s", v.get("error")) for k, v in hq.items() if isinstance(v, dict)}
     if isinstance((out.get("roofline") or {}).get("clock"), dict):
         s["clock"] = out["roofline"]["clock"]
     return s
+
+
+def host_queue_leg(seconds=1.5):
+    """SURVEY 8f N2 as the app would drive it: compiled caller threads, each with one decoded 1080p clip in pageable memory, submitting to
+    vdf_hash_queue in a loop (tools/bench_hash_queue.cpp, built here if missing) - run as a CHILD process (bench.py's own threads would be
+    bound by the GIL, and this process never execs).  frames cross the PCIe link: reported in GB/s of that link, never part of `value`."""
+    import re
+    import subprocess
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe, src, lib = os.path.join(root, "tools", "bench_hash_queue"), os.path.join(root, "tools", "bench_hash_queue.cpp"), os.path.join(root, "vid_dup_finder_lib_amd")
+    out = {}
+    try:
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src, "-L" + lib, "-lvdf_hip", "-Wl,-rpath," + lib,
+                                   "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        for name, lb in (("letterbox", 1), ("plain", 0)):
+            r = subprocess.run([exe, "1920", "1080", "32", "16", "2000", str(lb), str(seconds)], capture_output=True, text=True, timeout=90)
+            m = re.search(r"queue (\d+) clips/s = ([\d.]+) GB/s .*?(\d+) wrong\) \| batch call of \d+ clips: (\d+) clips/s = ([\d.]+) GB/s", r.stdout)
+            if r.returncode != 0 or not m:
+                out[name] = {"error": (r.stderr or r.stdout)[-200:]}
+                continue
+            out[name] = {"clips_per_s": int(m.group(1)), "link_GB_per_s": float(m.group(2)), "wrong": int(m.group(3)),
+                         "batch_call_link_GB_per_s": float(m.group(5))}
+        out.update({"w": 1920, "h": 1080, "caller_threads": 32, "max_batch": 16, "max_wait_us": 2000})
+    except Exception as e:  # no compiler, no time: the leg is informational
+        out["error"] = repr(e)[:200]
+    return out
 
 
 def hash_summary(hash_leg):
@@ -687,6 +718,7 @@ def main():
     ap.add_argument("--cache-entries", type=int, default=10_000_000,
                     help="entries of the synthetic app cache of the cache_ingest leg (0 = skip; --gpus 1 only)")
     ap.add_argument("--no-valu", dest="valu_leg", action="store_false", help="skip the XOR+popcount backend leg")
+    ap.add_argument("--no-host-queue", dest="host_queue", action="store_false", help="skip the batching-queue leg (a child process with compiled callers)")
     ap.add_argument("--no-refs", dest="refs_leg", action="store_false", help="skip the search_with_references leg")
     ap.add_argument("--no-single-process-leg", dest="sp_leg", action="store_false",
                     help="N > 1: do not run the C ABI's single-process form after the ranks")
@@ -1077,6 +1109,9 @@ def main():
             letterbox_leg(args.hash_hd_clips, 1920, 1080)
             # the headline's own frame shape with bars: boxes of small frames take one workgroup per clip with the DCT fused (round 5)
             letterbox_leg(min(args.hash_clips, 20000), 64, 64, key="letterbox_64x64", names=("no_bars", "top_bottom_bars", "side_bars"))
+            if args.host_queue:
+                torch.cuda.synchronize()
+                hash_leg["host_queue_1080p"] = host_queue_leg()
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(words, tol_int)

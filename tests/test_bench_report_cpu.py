@@ -70,6 +70,8 @@ def test_search_roofline_and_headline_assemble(backend, tmp_path, monkeypatch):
                                 "unit": "GB/s", "frac": 0.7875, "traffic": None, "traffic_source": "x",
                                 "clock": {"sclk_mhz_median": 2390.0, "power_w_median": 900.1, "samples": 120}},
                    "letterbox_64x64": lb,
+                   "host_queue_1080p": {"letterbox": {"clips_per_s": 1600, "link_GB_per_s": 53.1, "wrong": 0, "batch_call_link_GB_per_s": 56.0},
+                                        "plain": {"error": "no compiler"}, "w": 1920, "h": 1080, "caller_threads": 32},
                    "full_hd": {"blah": "x" * 3000},
                    "cpu_baseline": {"value": 6e5, "unit": "frames/s", "cores": 256, "kind": "port",
                                     "sample": "oracle from_frames over a 256-thread pool, 24576 clips of 16x64x64 (single thread: 384 clips)"}}
@@ -80,7 +82,8 @@ def test_search_roofline_and_headline_assemble(backend, tmp_path, monkeypatch):
     assert list(d)[-1] == "summary" and "hash_summary" not in d
     sm = d["summary"]
     assert len(json.dumps(sm)) <= bench.SUMMARY_MAX_BYTES == 1536 and line.endswith(json.dumps(sm) + "}")
-    assert set(sm) == {"hash_summary", "ten_million", "c5_end_to_end", "cache_ingest", "letterbox_64x64_ms", "clock"}
+    assert set(sm) == {"hash_summary", "ten_million", "c5_end_to_end", "cache_ingest", "letterbox_64x64_ms", "host_queue_1080p_link_GB_per_s", "clock"}
+    assert sm["host_queue_1080p_link_GB_per_s"] == {"letterbox": 53.1, "plain": "no compiler"}  # SURVEY 8f N2 through compiled callers (a child process)
     hs = sm["hash_summary"]
     assert hs["value"] == 1.5e9 and hs["roofline"]["frac"] == 0.7875 and hs["cpu_baseline"]["cores"] == 256 and hs["unit"] == "frames/s"
     assert hs["roofline"]["clock"]["sclk_mhz_median"] == 2390.0 and sm["clock"]["power_w_median"] == 1390.5

@@ -57,6 +57,9 @@ def test_bench_emits_the_contract_line(backend):
     assert sm["ten_million"]["ms"] == t["ms_per_step"] and sm["ten_million"]["planted_found"] == t["match_groups"]
     assert sm["c5_end_to_end"]["ms_per_step"] == d["c5_end_to_end"]["ms_per_step"] and sm["cache_ingest"]["host_ms"] == d["cache_ingest"]["host_ms"]
     assert set(sm["letterbox_64x64_ms"]) == {"no_bars", "top_bottom_bars", "side_bars"}
+    hq = d["hash"]["host_queue_1080p"]  # compiled caller threads through vdf_hash_queue (a child process), GB/s of the PCIe link
+    assert hq["letterbox"]["wrong"] == 0 and hq["plain"]["wrong"] == 0 and hq["plain"]["link_GB_per_s"] > 10 and hq["caller_threads"] == 32
+    assert set(sm["host_queue_1080p_link_GB_per_s"]) == {"letterbox", "plain"}
     # the GPU's clock and power while the timed steps ran (sysfs; null where the box does not show them)
     for ck in (d["roofline"]["clock"], d["hash"]["roofline"]["clock"]):
         assert set(ck) == {"sclk_mhz_median", "power_w_median", "samples"}

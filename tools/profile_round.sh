@@ -8,7 +8,7 @@ O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
 sha256sum $R/vid_dup_finder_lib_amd/libvdf_hip.so > $O/lib_sha256.txt   # which binary these counters belong to (bench.py: read_traffic)
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-windowed --c4-hashes 0 --c5-cands 0 --cache-entries 0 --no-valu --no-refs"  # headline + dup_heavy + hash legs
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-queue --no-windowed --c4-hashes 0 --c5-cands 0 --cache-entries 0 --no-valu --no-refs"  # headline + dup_heavy + hash legs
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B > $O/bench_under_profiler.json 2> /dev/null
 B1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --hash-clips 0 --no-windowed --c4-hashes 0 --c5-cands 0 --dup-heavy 0 --cache-entries 0 --no-valu --no-refs"
 H1="python3 $R/tools/bench_hash.py --steps 1"
