@@ -22,7 +22,8 @@
 //     last one the closed batch waits for;
 //   * joiners sleep on the slot's cv_done; the leader wakes them once, when the results are in.
 // VDF_QUEUE_SLOTS (read when a queue is made): slots per GPU, default 2; more slots keep more batches in flight when there are
-// many more callers than max_batch (each slot pins max_batch clips of staging).
+// many more callers than max_batch (each slot pins max_batch clips of staging; beyond three slots per GPU the slots' streams and the
+// parent's outnumber HIP's four default hardware queues again - GPU_MAX_HW_QUEUES raises those).
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
