@@ -1,5 +1,5 @@
 """CPU check behind tests/test_gpu_knobs.py: every environment switch the library reads (getenv("VDF_...") anywhere in csrc/) is exercised by
-a test, and the library reads its switches in ONE place per context (create_single / vdf_ctx_create_multi) - never per call: getenv is not
+a test, and the library reads its switches in ONE place per object (create_single / vdf_ctx_create_multi; vdf_hash_queue_create) - never per call: getenv is not
 safe against a concurrent setenv, and a launcher must see the value its caller decided by."""
 import glob
 import os
@@ -29,7 +29,10 @@ def test_switches_are_read_once_per_context():
         n = len(re.findall(r"getenv\(", open(p).read()))
         if n:
             where[os.path.basename(p)] = n
-    assert set(where) == {"api.cpp", "multi.cpp"}, where  # create_single and vdf_ctx_create_multi
+    # create_single and vdf_ctx_create_multi; the batching queue reads its one switch (VDF_QUEUE_SLOTS) when a QUEUE is made
+    assert set(where) == {"api.cpp", "multi.cpp", "hash_queue.cpp"} and where["hash_queue.cpp"] == 1, where
+    hq = open(os.path.join(CSRC, "hash_queue.cpp")).read()
+    assert "getenv(" in hq[hq.index("int vdf_hash_queue_create("):hq.index("int vdf_hash_queue_submit(")]  # ... and nowhere near a submission
     api = open(os.path.join(CSRC, "api.cpp")).read()
     body = api[api.index("int create_single("):api.index("// search() over a sorted database that is already resident")]
     assert len(re.findall(r"getenv\(", body)) == where["api.cpp"]  # all of them inside create_single
