@@ -33,10 +33,20 @@ int main(int argc, char **argv)
         std::mt19937_64 rng(1000 + t);
         uint64_t *p = reinterpret_cast<uint64_t *>(clips[t].data());
         for (size_t i = 0; i < clip / 8; i++) p[i] = rng();
+        if (letterbox && t % 2 == 1 && h >= 16)  // every other caller's clip has top / bottom bars: the queue's batches mix box shapes
+            for (int f = 0; f < 16; f++) {
+                std::memset(clips[t].data() + (size_t)f * w * h, 16, (size_t)w * (h / 8));
+                std::memset(clips[t].data() + (size_t)f * w * h + (size_t)w * (h - h / 9), 17, (size_t)w * (h / 9));
+            }
     }
     std::vector<uint64_t> want((size_t)T * VDF_HASH_WORDS);
-    for (int t = 0; t < T; t++)
-        if (vdf_hash_frames_u8(ctx, clips[t].data(), 1, 16, w, h, (size_t)w * h, clip, &want[(size_t)t * VDF_HASH_WORDS], nullptr) != VDF_OK) return 1;
+    std::vector<uint32_t> want_crop((size_t)T * 4, 0u);
+    for (int t = 0; t < T; t++) {
+        const int rc = letterbox ? vdf_hash_frames_u8_letterbox(ctx, clips[t].data(), 1, 16, w, h, (size_t)w * h, clip, &want[(size_t)t * VDF_HASH_WORDS],
+                                                                &want_crop[(size_t)t * 4], nullptr)
+                                 : vdf_hash_frames_u8(ctx, clips[t].data(), 1, 16, w, h, (size_t)w * h, clip, &want[(size_t)t * VDF_HASH_WORDS], nullptr);
+        if (rc != VDF_OK) return 1;
+    }
     std::atomic<bool> stop{false};
     std::atomic<uint64_t> done{0}, wrong{0};
     auto worker = [&](int t) {
@@ -44,7 +54,7 @@ int main(int argc, char **argv)
         uint32_t crop[4];
         while (!stop.load(std::memory_order_relaxed)) {
             if (vdf_hash_queue_submit(q, clips[t].data(), out, crop) != VDF_OK) { wrong++; break; }
-            if (!letterbox && std::memcmp(out, &want[(size_t)t * VDF_HASH_WORDS], sizeof out) != 0) wrong++;
+            if (std::memcmp(out, &want[(size_t)t * VDF_HASH_WORDS], sizeof out) != 0 || std::memcmp(crop, &want_crop[(size_t)t * 4], sizeof crop) != 0) wrong++;
             done++;
         }
     };
