@@ -135,7 +135,7 @@ def cpu_baseline(words, tol_int, target_seconds=12.0):
     pairs = n * (n - 1) / 2
     out = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
            "sample": f"oracle search_self, single thread, first {n} of the same hashes ({pairs:.3g} pairs, {dt:.1f} s)"}
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, visible, quota = host_cpus()
     rows_per = 64
     n_cols = int(min(len(words), 100_000))
     cw, cd = words[:n_cols], np.zeros(n_cols, np.uint32)
@@ -150,10 +150,32 @@ def cpu_baseline(words, tol_int, target_seconds=12.0):
             list(ex.map(block, range(n_rows, n_rows + cores * rows_per, rows_per)))
             n_rows += cores * rows_per
     dta = time.perf_counter() - t0
-    out["all_cores"] = {"value": n_rows * n_cols / dta, "unit": "pairs/s", "cores": cores, "in_reference": False,
+    out["all_cores"] = {"value": n_rows * n_cols / dta, "unit": "pairs/s", "cores": cores, "hardware_threads_visible": visible, "cpu_quota": quota, "in_reference": False,
                         "sample": f"oracle search_one loop, {n_rows} target rows x {n_cols} candidates over a {cores}-thread pool "
                                   f"({dta:.1f} s); the reference's search is single-threaded"}
     return out
+
+
+def host_cpus():
+    """(threads to use, visible hardware threads, cgroup quota in CPUs or None): a container may see every hardware thread of its host and
+    still be allowed a fraction of them (cgroup v2 cpu.max / v1 cfs quota) - the GPU boxes of this pool show 256 threads under a 16-CPU
+    quota, and 256 threads then only take turns on 16 cores' worth of time.  `cores` of a CPU baseline is what really ran in parallel."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    use = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    return use, visible, quota
 
 
 def cpu_baseline_hash(clips_per_thread=96):
@@ -161,7 +183,8 @@ def cpu_baseline_hash(clips_per_thread=96):
 
     from oracle import vdf_oracle as orc
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, visible, quota = host_cpus()
+    clips_per_thread = max(clips_per_thread, 24576 // max(cores, 1))  # (the same sample - 24 576 clips - whatever the core count)
     n_clips = cores * clips_per_thread
     rng = np.random.default_rng(20250617)
     frames = rng.integers(0, 256, size=(n_clips, 16, 64, 64), dtype=np.uint8)
@@ -175,7 +198,7 @@ def cpu_baseline_hash(clips_per_thread=96):
     t1 = time.perf_counter()
     orc.hash_clips(frames[:n1])
     dt1 = time.perf_counter() - t1
-    return {"value": n_clips * 16 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": n_clips * 16 / dt, "unit": "frames/s", "cores": cores, "kind": "port", "hardware_threads_visible": visible, "cpu_quota": quota,
             "single_thread_value": n1 * 16 / dt1,
             "sample": f"oracle from_frames over a {cores}-thread pool, {n_clips} clips of 16x64x64 "
                       f"(single thread: {n1} clips)"}
@@ -1348,7 +1371,7 @@ def leg_cache_ingest(args, vdf, eng, tol_int):
     tm = runs[-1]
     st = eng.last_stats()
     host_ms = t_dec + tm["rank_ms"] + tm["upload_ms"] + tm["sort_ms"] + tm["map_ms"]
-    return {"entries": n, "cache_MB": data.size / 1e6, "host_threads": os.cpu_count(), "generation_s": t_gen,
+    return {"entries": n, "cache_MB": data.size / 1e6, "host_threads": os.cpu_count(), "cpu_quota": host_cpus()[2], "generation_s": t_gen,
             "decode_ms": dec_auto[0], "decode_ms_min": dec_auto[1], "decode_GB_per_s": data.size / (dec_auto[1] * 1e-3) / 1e9,
             "decode_one_thread_ms": dec_one[0], "decode_in_this_call_ms": t_dec,
             "search_cache_entries": {k: tm[k] for k in ("rank_ms", "upload_ms", "sort_ms", "search_ms", "map_ms", "total_ms", "wall_ms")},
