@@ -386,7 +386,7 @@ int vdf_cache_decode(const uint8_t *data, size_t len, vdf_cache_soa *out); /* ma
 /* The same on n_threads host threads (0 = one per 8 MB of file, at most 32 and at most the machine's; what vdf_cache_decode does).
  * bincode has no entry index, so the file is cut where the byte pattern of an Ok entry's hash words resynchronises, every range
  * is parsed by its own thread, and the ranges must meet exactly: if they do not, the file is decoded front to back instead - the
- * result never depends on the speculation.  Measured (profiles/r05_cache_ingest.txt, the GPU box's 256-thread host): 10 M entries
+ * result never depends on the speculation.  Measured (profiles/r05_cache_ingest.txt, the GPU box: 256 hardware threads under a 16-CPU cgroup quota): 10 M entries
  * (2.69 GB) in 35 ms with the automatic thread count, 0.42 s on one thread.  The output arrays ask for transparent huge pages. */
 int vdf_cache_decode_mt(const uint8_t *data, size_t len, int n_threads, vdf_cache_soa *out);
 unsigned long long vdf_cache_decode_fallbacks(void); /* diagnostics: how often this process fell back to the front-to-back decode */
