@@ -6,6 +6,8 @@
 //                                 with the prefixes are the candidates / references; prints "key<TAB>reference or -<TAB>duplicates..."
 // File format: u64 n, then n x {16 x u64 hash, u32 duration, u32 path_len, path bytes}.
 #include <cassert>
+#include <chrono>
+#include <random>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -142,6 +144,36 @@ int main(int argc, char **argv)
             std::cout << '\n';
         }
         return 0;
+    }
+    if (argc >= 3 && !std::strcmp(argv[1], "bench")) {  // what vdf::search() costs around the GPU call at n hashes (plain paths of a media library)
+        const size_t n = std::strtoull(argv[2], nullptr, 10);
+        std::mt19937_64 rng(7);
+        std::vector<vdf::VideoHash> hs;
+        hs.reserve(n);
+        for (size_t i = 0; i < n; i++) {
+            std::array<uint64_t, 16> h;
+            for (auto &w : h) w = rng();
+            h[15] &= (1ull << 40) - 1;
+            char path[96];
+            const uint64_t id = rng() % (4 * n + 1);
+            std::snprintf(path, sizeof path, "/srv/media/lib_%02u/show_%04u/season_%02u/clip_%08llu.mkv", (unsigned)(id % 100), (unsigned)(id / 40 % 10000),
+                          (unsigned)(id / 8 % 5), (unsigned long long)id);
+            hs.emplace_back(h, path, (uint32_t)(5 + rng() % 7200));
+        }
+        if (n >= 2) hs[1] = vdf::VideoHash(hs[0].words(), "/srv/media/copy.mkv", hs[0].duration());  // one pair to find
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        vdf::search(std::vector<vdf::VideoHash>(hs.begin(), hs.begin() + std::min<size_t>(n, 1000)), 0.35);  // context, code objects
+        const auto t0 = now();
+        const auto order_host = vdf::detail::sort_order_host(hs);
+        const auto t1 = now();
+        const auto order = vdf::detail::sort_order(hs, &vdf::Context::default_context());
+        const auto t2 = now();
+        const auto groups = vdf::search(hs, 0.35);
+        const auto t3 = now();
+        std::printf("n=%zu: Search::sort on the host (PathKey) %.1f ms, through vdf_sort_order_paths %.1f ms (same order: %s), whole vdf::search %.1f ms, %zu groups\n", n,
+                    ms(t0, t1), ms(t1, t2), order == order_host ? "yes" : "NO", ms(t2, t3), groups.size());
+        return order == order_host ? 0 : 1;
     }
     std::fprintf(stderr, "usage: selftest | search <file> <tol> | refs <file> <n_ref> <tol> | cache <cache.bin> <tol> <cand prefix> <ref prefix | ->\n");
     return 2;

@@ -106,3 +106,12 @@ def test_cpp_search_disk_on_a_cache_file(tmp_path):
     want = orc.search_with_references(words[ri], dur[ri], [paths[i] for i in ri], words[ci], dur[ci], [paths[i] for i in ci], 0.3)
     assert [(r[1], r[2:]) for r in rows] == [(r, m) for r, m in want] and len(want) > 5
     assert [int(r[0]) for r in rows] == [key(m + [r]) for r, m in want]
+
+
+@pytest.mark.gpu
+def test_cpp_search_sorts_large_sets_through_the_engine():
+    """vdf::search from 2048 hashes on takes Search::sort's order from the library (vdf_sort_order_paths) instead of a PathKey per entry:
+    the mirror's own `bench` mode checks that both orders are the same one and prints what each costs."""
+    exe = _build()
+    out = subprocess.run([exe, "bench", "20000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "same order: yes" in out.stdout and " 1 groups" in out.stdout, (out.stdout, out.stderr[-1000:])

@@ -176,6 +176,33 @@ def test_public_api_matches_oracle(engine):
     assert vdf.search([], 1.0, engine=engine) == []
 
 
+@pytest.mark.parametrize("plain", [True, False])
+def test_public_api_sorts_large_sets_through_the_engine(engine, plain):
+    """From 2048 hashes on, search() / search_with_references() take Search::sort's order from the library (vdf_sort_order_paths: device for
+    plain paths, the native component comparator otherwise) instead of a Python key per entry: the same order, the same groups."""
+    import vid_dup_finder_lib_amd as vdf
+    from vid_dup_finder_lib_amd import api
+
+    rng = np.random.default_rng(31 + plain)
+    words, dur = hg.planted_set(rng, 6000, n_clusters=80, durations="windowed")
+    n = len(words)
+
+    def path(i):
+        d = int(rng.integers(0, 7))
+        if plain:
+            return [f"/m/dir{d}/v{i}.mp4", f"/m/dir.{d}/v{i}.mp4", f"/m/dir{d}/sub/v{i % 50}.mp4", f"m/dir{d} x/v{i}.mp4"][i % 4]
+        return [f"/m//dir{d}/./v{i}.mp4", f"../m/dir{d}/v{i}.mp4", f"./m/dir{d}/v{i % 50}.mp4", f"/m/dir{d}/v{i}.mp4/"][i % 4]
+
+    paths = [path(i) for i in range(n)]
+    hashes = [vdf.VideoHash(words[i], paths[i], int(dur[i])) for i in range(n)]
+    assert api.sort_order(hashes, engine) == api.sort_order(hashes)  # the library's order = the Python keys' (equal paths: input order)
+    got = vdf.search(hashes, 0.35, engine=engine)
+    assert [list(g.duplicates()) for g in got] == orc.search(words, dur, paths, 0.35) and len(got) >= 40
+    got_r = vdf.search_with_references(hashes[:60], hashes[30:], 0.25, engine=engine)
+    want_r = orc.search_with_references(words[:60], dur[:60], paths[:60], words[30:], dur[30:], paths[30:], 0.25)
+    assert [(g.reference(), list(g.duplicates())) for g in got_r] == want_r
+
+
 @pytest.mark.parametrize("n", [1, 31, 257, 700])
 def test_large_tolerances_match_everything(engine, n):
     """tolerance >= 0.5: the fp4 backend's threshold 1024 - 2 tol goes <= 0, so even its zero padding rows/columns

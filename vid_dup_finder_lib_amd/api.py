@@ -190,8 +190,15 @@ def rust_path_key(path) -> tuple:
     return tuple(comps)
 
 
-def sort_order(hashes: Sequence["VideoHash"]) -> List[int]:
-    """Stable permutation that Search::sort applies (search_algorithm.rs:55-61)."""
+def sort_order(hashes: Sequence["VideoHash"], engine: Optional[Engine] = None) -> List[int]:
+    """Stable permutation that Search::sort applies (search_algorithm.rs:55-61).  With an engine and more than a handful of hashes the
+    order comes from the library (vdf_sort_order_paths: the path half on the device for plain paths, the native component comparator
+    otherwise - the same order): a million Python keys cost seconds beside a 0.1 s search."""
+    if engine is not None and len(hashes) >= 2048:
+        from .cache import sort_order_paths
+
+        order, _used_device = sort_order_paths(engine, [h.duration() for h in hashes], [h.src_path() for h in hashes])
+        return order.tolist()
     idx = list(range(len(hashes)))
     idx.sort(key=lambda i: (hashes[i].duration(), rust_path_key(hashes[i].src_path())))
     return idx
@@ -373,9 +380,10 @@ def search(hashes: Iterable[VideoHash], tolerance: float, engine: Optional[Engin
     hashes = list(hashes)
     if not hashes:
         return []  # search_algorithm.rs:89-91
-    order = sort_order(hashes)
+    engine = engine or default_engine()
+    order = sort_order(hashes, engine)
     words, dur = _soa(hashes, order)
-    groups = (engine or default_engine()).search_self_sorted(words, dur, tolerance_int(tolerance))
+    groups = engine.search_self_sorted(words, dur, tolerance_int(tolerance))
     out = []
     for g in groups:
         try:
@@ -392,10 +400,11 @@ def search_with_references(ref_hashes: Iterable[VideoHash], new_hashes: Iterable
     news = list(new_hashes)
     if not refs or not news:
         return []
-    order = sort_order(news)
+    engine = engine or default_engine()
+    order = sort_order(news, engine)
     words, dur = _soa(news, order)
     rwords, rdur = _soa(refs, list(range(len(refs))))
-    res = (engine or default_engine()).search_refs_sorted(words, dur, rwords, rdur, tolerance_int(tolerance))
+    res = engine.search_refs_sorted(words, dur, rwords, rdur, tolerance_int(tolerance))
     return [MatchGroup.new_with_reference(refs[r].src_path(), [news[order[m]].src_path() for m in ms])
             for r, ms in res]
 

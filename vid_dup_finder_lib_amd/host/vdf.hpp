@@ -232,8 +232,9 @@ private:
 };
 
 namespace detail {
-// Search::sort, search_algorithm.rs:55-61: stable by (duration, src_path) with Path ordering.
-inline std::vector<size_t> sort_order(const std::vector<VideoHash> &h)
+// Search::sort, search_algorithm.rs:55-61: stable by (duration, src_path) with Path ordering - on the host, a PathKey per entry (the
+// readable form; what sort_order() below falls back to for a handful of hashes or without a context).
+inline std::vector<size_t> sort_order_host(const std::vector<VideoHash> &h)
 {
     std::vector<PathKey> keys;
     keys.reserve(h.size());
@@ -245,6 +246,22 @@ inline std::vector<size_t> sort_order(const std::vector<VideoHash> &h)
         return keys[a] < keys[b];
     });
     return idx;
+}
+// The same order through the engine (vdf_sort_order_paths: the path half on the device for plain paths, the library's multi-threaded
+// component comparator otherwise).  A million PathKeys and their comparisons cost seconds on the host - beside a 0.1 s search.
+inline std::vector<size_t> sort_order(const std::vector<VideoHash> &h, Context *ctx = nullptr)
+{
+    if (h.size() < 2048 || !ctx) return sort_order_host(h);
+    std::vector<uint32_t> dur(h.size());
+    std::vector<uint64_t> offs(h.size() + 1, 0);
+    for (size_t i = 0; i < h.size(); i++) { dur[i] = h[i].duration(); offs[i + 1] = offs[i] + h[i].src_path().size(); }
+    std::string blob;
+    blob.reserve((size_t)offs.back());
+    for (const auto &x : h) blob += x.src_path();
+    std::vector<uint32_t> order32(h.size());
+    if (vdf_sort_order_paths(ctx->get(), dur.data(), offs.data(), blob.data(), h.size(), order32.data(), nullptr) != VDF_OK)
+        return sort_order_host(h);  // (more than 2^32 - 1 entries, a device error: the host's order is the same one)
+    return std::vector<size_t>(order32.begin(), order32.end());
 }
 inline void to_soa(const std::vector<VideoHash> &h, const std::vector<size_t> &order, std::vector<uint64_t> &words,
                    std::vector<uint32_t> &dur)
@@ -268,7 +285,7 @@ inline std::vector<MatchGroup> search(const std::vector<VideoHash> &hashes, doub
 {
     std::vector<MatchGroup> out;
     if (hashes.empty()) return out;  // search_algorithm.rs:89-91
-    const auto order = detail::sort_order(hashes);
+    const auto order = detail::sort_order(hashes, &ctx);
     std::vector<uint64_t> words;
     std::vector<uint32_t> dur;
     detail::to_soa(hashes, order, words, dur);
@@ -290,7 +307,7 @@ inline std::vector<MatchGroup> search_with_references(const std::vector<VideoHas
 {
     std::vector<MatchGroup> out;
     if (ref_hashes.empty() || new_hashes.empty()) return out;
-    const auto order = detail::sort_order(new_hashes);
+    const auto order = detail::sort_order(new_hashes, &ctx);
     std::vector<uint64_t> words, rwords;
     std::vector<uint32_t> dur, rdur;
     detail::to_soa(new_hashes, order, words, dur);
