@@ -1,7 +1,8 @@
 //! Seams 2 and 3: `Search::search_self` (search_algorithm.rs:81-171) and the per-reference loop of
 //! `search_with_references` (video_dup_finder.rs:25-45 -> search_one / duration_slice, search_algorithm.rs:63-77,173-185).
 //!
-//! `Search::sort` (:55-61) stays as it is: it needs the paths.  Each replacement extracts SoA arrays in the sorted order,
+//! `Search::sort` (:55-61) keeps its meaning and may keep its body; `sort_through_the_engine` below is the drop-in for large sets
+//! (a `PathBuf` clone per comparison costs seconds at a million entries - beside a 0.1 s search).  Each replacement extracts SoA arrays in the sorted order,
 //! makes ONE call, and maps the returned indices back to paths.  Group and member order come back exactly as the original
 //! builds them (search(): hits ascending then the target, groups in descending target order; references: input order,
 //! members ascending), so video_dup_finder.rs:7-13 and MatchGroup are untouched.
@@ -41,6 +42,38 @@ unsafe fn take_groups(g: &mut vdf_groups) -> Vec<(i64, Vec<usize>)> {
 }
 
 impl Search {
+    /// Optional replacement for the body of `sort` (:55-61): the same stable order by (duration, src_path) - `PathBuf` order, the path
+    /// half on the device for plain paths - from ONE call over the entries' durations and path bytes (vdf_sort_order_paths), applied as
+    /// a permutation.  Falls back to the crate's own `sort_by_key` on any non-OK status or without a context.
+    #[cfg(unix)]
+    pub fn sort_through_the_engine(&mut self) {
+        use std::os::unix::ffi::OsStrExt;
+        let n = self.entries.len();
+        if n >= 2048 {
+            if let Some(ctx) = ctx() {
+                let durs: Vec<u32> = self.entries.iter().map(|e| e.value.duration()).collect();
+                let mut offs: Vec<u64> = Vec::with_capacity(n + 1);
+                let mut blob: Vec<u8> = Vec::new();
+                offs.push(0);
+                for e in &self.entries {
+                    blob.extend_from_slice(e.value.src_path().as_os_str().as_bytes());
+                    offs.push(blob.len() as u64);
+                }
+                let mut order = vec![0u32; n];
+                let rc = unsafe {
+                    vdf_sort_order_paths(ctx, durs.as_ptr(), offs.as_ptr(), blob.as_ptr() as *const _, n, order.as_mut_ptr(), null_mut())
+                };
+                if rc == VDF_OK {
+                    let mut taken: Vec<Option<_>> = std::mem::take(&mut self.entries).into_iter().map(Some).collect();
+                    self.entries = order.iter().map(|&k| taken[k as usize].take().expect("a permutation")).collect();
+                    return;
+                }
+                log::warn!(target: "gpu_search", "vdf_sort_order_paths failed ({rc}): {}; sorting on the host", last_error(ctx));
+            }
+        }
+        self.sort(); // the crate's ORIGINAL body
+    }
+
     /// Replaces the body of search_self (:81-171).  `self.entries` are already sorted (seed() sorts, :31-34).
     pub fn search_self(&mut self, tolerance: f64) -> Vec<Vec<PathBuf>> {
         if self.entries.is_empty() {
