@@ -369,7 +369,8 @@ class MatchGroup:
 def _soa(hashes: Sequence[VideoHash], order: Sequence[int]):
     if not order:
         return np.zeros((0, HASH_WORDS), np.uint64), np.zeros(0, np.uint32)
-    words = np.stack([hashes[i].hash for i in order])
+    # (one bytes object of all words: half the time of np.stack over a million 16-word arrays)
+    words = np.frombuffer(b"".join([hashes[i].hash.tobytes() for i in order]), np.uint64).reshape(-1, HASH_WORDS)
     dur = np.array([hashes[i].duration() for i in order], dtype=np.uint32)
     return words, dur
 
